@@ -1,0 +1,161 @@
+// extern "C" surface of libdws.so for the model and sampler entry points
+// (include/dws.h); the Cauchy entry points live in cauchy_kernels.hip.
+#include "model.h"
+
+namespace dws {
+int sampler_run(dws_model* m, float* x, const float* alpha, const float* alpha_bar, const float* sigma, int T,
+                const float* noise, uint64_t seed, int init_from_seed, int use_graph, hipStream_t s);
+int sampler_steps(dws_model* m, float* x, const float* alpha, const float* alpha_bar, const float* sigma, int T,
+                  int t_start, int n_steps, uint64_t seed, int use_graph, hipStream_t s);
+}  // namespace dws
+
+dws_model::~dws_model() {
+    drop_graph();
+    for (auto* p : params) delete p;
+}
+
+void dws_model::drop_graph() {
+    if (smp_graph) hipGraphExecDestroy(smp_graph);
+    smp_graph = nullptr;
+}
+
+dws::ParamSpec* dws_model::add_param(const std::string& name, std::vector<int64_t> shape, int dtype) {
+    auto* p = new dws::ParamSpec();
+    p->name = name;
+    p->shape = std::move(shape);
+    p->dtype = dtype;
+    index[name] = (int)params.size();
+    params.push_back(p);
+    return p;
+}
+
+float* dws_model::P(const std::string& name) const {
+    auto it = index.find(name);
+    if (it == index.end()) return nullptr;
+    return params[it->second]->buf.f();
+}
+
+int dws_model::alloc_params() {
+    for (auto* p : params) {
+        DWS_TRY(p->buf.ensure(p->nbytes()));
+        DWS_HIP(hipMemset(p->buf.p, 0, p->nbytes()));
+    }
+    return DWS_OK;
+}
+
+extern "C" {
+
+int dws_model_create(const dws_model_desc* desc, dws_model** out) {
+    DWS_CHECK(desc && out, DWS_ERR_INVALID, "dws_model_create: null argument");
+    const dws_model_desc& d = *desc;
+    DWS_CHECK(d.in_channels > 0 && d.out_channels > 0, DWS_ERR_INVALID, "in/out channels must be positive");
+    DWS_CHECK(d.diffusion_step_embed_dim_in > 0 && d.diffusion_step_embed_dim_in % 2 == 0, DWS_ERR_INVALID,
+              "diffusion_step_embed_dim_in must be even (`models/utils.py:20`)");
+    DWS_CHECK(d.diffusion_step_embed_dim_in <= 1024 && d.diffusion_step_embed_dim_mid <= 1024 &&
+                  d.diffusion_step_embed_dim_out <= 1024,
+              DWS_ERR_UNSUPPORTED, "embedding dims above 1024 are not supported");
+    dws_model* m = nullptr;
+    if (d.kind == DWS_KIND_WAVENET) {
+        DWS_CHECK(d.res_channels > 0 && d.skip_channels > 0 && d.num_res_layers > 0 && d.dilation_cycle > 0,
+                  DWS_ERR_INVALID, "wavenet: bad channel/layer counts");
+        DWS_CHECK(d.dilation_cycle <= 24, DWS_ERR_UNSUPPORTED, "dilation_cycle > 24");
+        m = dws::make_wavenet(d);
+    } else if (d.kind == DWS_KIND_SASHIMI) {
+        m = dws::make_sashimi(d);
+        if (!m) return DWS_ERR_UNSUPPORTED;
+    } else {
+        return dws::set_error(DWS_ERR_INVALID, "unknown model kind %d (model._name_ must be wavenet|sashimi, "
+                                               "`models/__init__.py:6-9`)", d.kind);
+    }
+    int st = m->alloc_params();
+    if (st != DWS_OK) {
+        delete m;
+        return st;
+    }
+    *out = m;
+    return DWS_OK;
+}
+
+int dws_model_destroy(dws_model* m) {
+    delete m;
+    return DWS_OK;
+}
+
+int dws_model_num_params(const dws_model* m) { return m ? (int)m->params.size() : 0; }
+
+int dws_model_param_info(const dws_model* m, int i, const char** name, int64_t* shape, int* ndim, int* dtype) {
+    DWS_CHECK(m && i >= 0 && i < (int)m->params.size(), DWS_ERR_INVALID, "param index %d out of range", i);
+    const dws::ParamSpec* p = m->params[i];
+    DWS_CHECK(p->shape.size() <= 8, DWS_ERR_INVALID, "rank > 8");
+    if (name) *name = p->name.c_str();
+    if (ndim) *ndim = (int)p->shape.size();
+    if (dtype) *dtype = p->dtype;
+    if (shape)
+        for (size_t k = 0; k < p->shape.size(); ++k) shape[k] = p->shape[k];
+    return DWS_OK;
+}
+
+int dws_model_set_param(dws_model* m, const char* name, const void* data, const int64_t* shape, int ndim, int dtype,
+                        void* stream) {
+    DWS_CHECK(m && name && data && shape, DWS_ERR_INVALID, "dws_model_set_param: null argument");
+    auto it = m->index.find(name);
+    DWS_CHECK(it != m->index.end(), DWS_ERR_INVALID, "unexpected key '%s' in state_dict", name);
+    dws::ParamSpec* p = m->params[it->second];
+    DWS_CHECK(dtype == p->dtype, DWS_ERR_INVALID, "'%s': dtype %d, expected %d", name, dtype, p->dtype);
+    bool same = (int)p->shape.size() == ndim;
+    for (int k = 0; same && k < ndim; ++k) same = p->shape[k] == shape[k];
+    if (!same) {
+        std::string got = "[", want = "[";
+        for (int k = 0; k < ndim; ++k) got += std::to_string(shape[k]) + (k + 1 < ndim ? "," : "");
+        for (size_t k = 0; k < p->shape.size(); ++k) want += std::to_string(p->shape[k]) + (k + 1 < p->shape.size() ? "," : "");
+        return dws::set_error(DWS_ERR_INVALID, "size mismatch for %s: got %s], expected %s]", name, got.c_str(),
+                              want.c_str());
+    }
+    DWS_HIP(hipMemcpyAsync(p->buf.p, data, p->nbytes(), hipMemcpyDefault, (hipStream_t)stream));
+    m->dirty = true;
+    m->drop_graph();
+    return DWS_OK;
+}
+
+int dws_model_commit(dws_model* m, void* stream) {
+    DWS_CHECK(m, DWS_ERR_INVALID, "null model");
+    return m->commit((hipStream_t)stream);
+}
+
+int dws_model_prepare(dws_model* m, int64_t B, int64_t L) {
+    DWS_CHECK(m, DWS_ERR_INVALID, "null model");
+    return m->prepare(B, L);
+}
+
+int dws_model_set_condition(dws_model* m, const float* mel, int64_t Bm, int64_t Tmel, void* stream) {
+    DWS_CHECK(m, DWS_ERR_INVALID, "null model");
+    m->drop_graph();
+    return m->set_condition(mel, Bm, Tmel, (hipStream_t)stream);
+}
+
+int dws_model_forward(dws_model* m, const float* audio, const float* steps, float* out, void* stream) {
+    DWS_CHECK(m && audio && steps && out, DWS_ERR_INVALID, "dws_model_forward: null argument");
+    return m->forward(audio, steps, out, (hipStream_t)stream);
+}
+
+int dws_model_read_tap(dws_model* m, const char* tap, float* dst, int64_t capacity, void* stream) {
+    DWS_CHECK(m && tap && dst, DWS_ERR_INVALID, "dws_model_read_tap: null argument");
+    return m->read_tap(tap, dst, capacity, (hipStream_t)stream);
+}
+
+int dws_sampler_run(dws_model* m, float* x, const float* alpha, const float* alpha_bar, const float* sigma,
+                    int32_t T, const float* noise, uint64_t seed, int32_t init_from_seed, int32_t use_graph,
+                    void* stream) {
+    DWS_CHECK(m && x, DWS_ERR_INVALID, "dws_sampler_run: null argument");
+    return dws::sampler_run(m, x, alpha, alpha_bar, sigma, T, noise, seed, init_from_seed, use_graph,
+                            (hipStream_t)stream);
+}
+
+int dws_sampler_steps(dws_model* m, float* x, const float* alpha, const float* alpha_bar, const float* sigma,
+                      int32_t T, int32_t t_start, int32_t n_steps, uint64_t seed, int32_t use_graph, void* stream) {
+    DWS_CHECK(m && x, DWS_ERR_INVALID, "dws_sampler_steps: null argument");
+    return dws::sampler_steps(m, x, alpha, alpha_bar, sigma, T, t_start, n_steps, seed, use_graph,
+                              (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// dws_model: base of the two backbones behind the C ABI (include/dws.h).
+#pragma once
+#include "dws_common.h"
+
+namespace dws {
+
+// RAII device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // (re)allocate when the request grows; contents are not preserved.
+    int ensure(size_t n) {
+        if (n <= bytes && p) return DWS_OK;
+        release();
+        if (n == 0) n = 4;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return set_error(DWS_ERR_HIP, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        }
+        bytes = n;
+        return DWS_OK;
+    }
+    float* f() const { return static_cast<float*>(p); }
+};
+
+struct ParamSpec {
+    std::string name;
+    std::vector<int64_t> shape;
+    int dtype = 0;  // 0 float32, 1 int64
+    DevBuf buf;     // raw copy of the state-dict tensor
+    size_t numel() const {
+        size_t n = 1;
+        for (auto s : shape) n *= (size_t)s;
+        return n;
+    }
+    size_t nbytes() const { return numel() * (dtype == 1 ? 8 : 4); }
+};
+
+}  // namespace dws
+
+struct dws_model {
+    dws_model_desc d;
+    std::vector<dws::ParamSpec*> params;
+    std::map<std::string, int> index;
+    bool dirty = true;
+    int64_t B = 0, L = 0;  // prepared workspace shape
+
+    // sampler state (sampler.hip)
+    dws::DevBuf smp_tables;   // [3][T] c1, c2, sigma
+    int smp_T = 0;            // length of the uploaded tables
+    dws::DevBuf smp_state;    // int32 step index
+    dws::DevBuf smp_eps;      // eps[B, Cout, L]
+    dws::DevBuf smp_steps;    // float steps[B]
+    hipGraphExec_t smp_graph = nullptr;
+    // key of the captured graph
+    int64_t g_B = 0, g_L = 0;
+    int g_T = 0;
+    const void* g_x = nullptr;
+    const void* g_noise = nullptr;
+    uint64_t g_seed = 0;
+    hipStream_t g_stream = nullptr;
+
+    virtual ~dws_model();
+    dws::ParamSpec* add_param(const std::string& name, std::vector<int64_t> shape, int dtype = 0);
+    float* P(const std::string& name) const;  // raw device pointer of a parameter
+    int alloc_params();
+    void drop_graph();
+
+    virtual int commit(hipStream_t s) = 0;
+    virtual int prepare(int64_t B, int64_t L) = 0;
+    virtual int set_condition(const float* mel, int64_t Bm, int64_t Tmel, hipStream_t s) = 0;
+    virtual int forward(const float* audio, const float* steps, float* out, hipStream_t s) = 0;
+    virtual int read_tap(const char* tap, float* dst, int64_t capacity, hipStream_t s) = 0;
+};
+
+namespace dws {
+dws_model* make_wavenet(const dws_model_desc& d);
+dws_model* make_sashimi(const dws_model_desc& d);
+}  // namespace dws

@@ -1,0 +1,55 @@
+// Launch interface of wavenet_kernels.hip (internal to libdws.so).
+#pragma once
+#include "dws_common.h"
+
+namespace dws {
+
+constexpr int WN_LAYER_KC = 32;  // channels per staged K chunk of the fused layer kernel
+
+struct WnLayerArgs {
+    const float* x_in;     // [B, C, L]
+    float* x_out;          // [B, C, L]   (ping-pong partner of x_in)
+    float* skip;           // [B, S, L]   running skip sum
+    const float* part_t;   // fc_t(emb) of this layer, element (b, c) at part_t[b*part_t_bstride + c]
+    int part_t_bstride;
+    const float* A1;       // packed dilated-conv weights (MFMA path)
+    const float* A2;       // packed [res; skip] weights   (MFMA path)
+    const float* Wd;       // folded [2C][C][3]            (generic path)
+    const float* Wr;       // folded [C][C]
+    const float* Ws;       // folded [S][C]
+    const float* bias1;    // [2C]
+    const float* bias2;    // [C + S]  (res bias, then skip bias)
+    const float* melc;     // nullable: conditioner term [Bm, 2C, L] of this layer
+    int mel_bstride;       // 0: broadcast batch-1 mel, 1: per-batch
+    float* gate_ws;        // generic path scratch [B, C, L]
+    int B, L, dilation, first_layer, last_layer;
+};
+
+struct WnFinalArgs {
+    const float* skip;  // [B, S, L]
+    const float* Af;    // packed final_conv[0] weight (MFMA path)
+    const float* Wf;    // folded [S][S]              (generic path)
+    const float* bf;    // [S]
+    const float* Wz;    // [Cout][S]
+    const float* bz;    // [Cout]
+    float* out;         // [B, Cout, L]
+    float* tap;         // nullable: relu(final_conv[0]) [B, S, L]
+    float scale;        // sqrt(1 / num_res_layers)
+    int B, L, Cout;
+};
+
+int launch_fold_weight_norm(const float* v, const float* g, float* out, int O, int inner, hipStream_t s);
+int launch_permute_dconv(const float* w, float* out, int C, int KC, hipStream_t s);
+int launch_pack_a_frag(const float* w, float* out, int M, int K, hipStream_t s);
+int launch_step_embed(const float* steps, const float* freq, float* emb, int B, int half, hipStream_t s);
+int launch_linear_rows(const float* in, const float* W, const float* bias, float* out, int B, int K, int O,
+                       int act, hipStream_t s);
+int launch_init_conv(const float* audio, const float* W, const float* bias, float* x, int B, int Cin, int C, int L,
+                     hipStream_t s);
+bool wn_layer_mfma_supported(int C, int S);
+int launch_wn_layer_mfma(int C, int S, const WnLayerArgs& a, hipStream_t s);
+int launch_wn_layer_generic(int C, int S, const WnLayerArgs& a, hipStream_t s);
+bool wn_final_mfma_supported(int S);
+int launch_wn_final(int S, const WnFinalArgs& a, hipStream_t s);
+
+}  // namespace dws

@@ -1,0 +1,606 @@
+// WaveNet backbone kernels for gfx950 (MI355X).
+//
+// Hot path: one fused kernel per residual layer,
+//   h = x + fc_t(emb)            (zero outside [0,L): padding applies to h)
+//   H = Wd (*) h  (k=3, dilation d)      -> exact-f32 MFMA, K = 3C
+//   g = tanh(H[:C]) * sigmoid(H[C:])     -> registers
+//   [res; skip] = [Wr; Ws] g             -> exact-f32 MFMA, K = C
+//   x' = (x + res) * sqrt(.5) ; skip_acc += skip
+// following `models/wavenet.py:82-121,149-165`.
+//
+// Data layout: activations [B, C, L] fp32, L contiguous (the reference's
+// layout): the MFMA B operand of v_mfma_f32_32x32x2_f32 wants, per k, 32
+// consecutive positions -> a coalesced 128-byte row segment.  Weights are
+// folded (weight-norm) and pre-packed ONCE into MFMA A-fragment order so every
+// wave streams them with 1 KiB dwordx4 loads from L2.
+#include "dws_common.h"
+#include "wavenet.h"
+
+namespace dws {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// Weight preparation (runs once per weight load, not per step)
+// ---------------------------------------------------------------------------
+
+// out[o,:] = g[o] * v[o,:] / ||v[o,:]||_2   (torch weight_norm, dim=0; `wavenet.py:21`)
+__global__ void fold_weight_norm_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                        float* __restrict__ out, int inner) {
+    const int o = blockIdx.x;
+    const float* vr = v + (size_t)o * inner;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < inner; i += blockDim.x) s += vr[i] * vr[i];
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    const float scale = g[o] / sqrtf(red[0]);
+    for (int i = threadIdx.x; i < inner; i += blockDim.x) out[(size_t)o * inner + i] = vr[i] * scale;
+}
+
+int launch_fold_weight_norm(const float* v, const float* g, float* out, int O, int inner, hipStream_t s) {
+    hipLaunchKernelGGL(fold_weight_norm_kernel, dim3(O), dim3(256), 0, s, v, g, out, inner);
+    return DWS_OK;
+}
+
+// Dilated-conv weight [2C][C][3] -> row-major [2C][3C] with the K order the
+// fused kernel walks: k = ((cb*3 + tap)*KC + cc), c = cb*KC + cc.
+__global__ void permute_dconv_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int KC, int M) {
+    const int K = 3 * C;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * K) return;
+    int o = (int)(i / K), k = (int)(i % K);
+    int cb = k / (3 * KC), rem = k % (3 * KC), tap = rem / KC, cc = rem % KC;
+    out[i] = w[((size_t)o * C + cb * KC + cc) * 3 + tap];
+}
+
+int launch_permute_dconv(const float* w, float* out, int C, int KC, hipStream_t s) {
+    size_t n = (size_t)2 * C * 3 * C;
+    hipLaunchKernelGGL(permute_dconv_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, out, C, KC, 2 * C);
+    return DWS_OK;
+}
+
+// Row-major W[M][K] -> A-fragment order of v_mfma_f32_32x32x2_f32:
+//   pack[mt][kg][lane][j] = W[mt*32 + (lane&31)][(kg*4 + j)*2 + (lane>>5)]
+// so one dwordx4 load per lane yields the A operands of 4 consecutive k-steps.
+__global__ void pack_a_frag_kernel(const float* __restrict__ w, float* __restrict__ out, int M, int K) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * K) return;
+    int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    size_t r = i >> 8;  // mt * (K/8) + kg
+    int kg = (int)(r % (K / 8)), mt = (int)(r / (K / 8));
+    int row = mt * 32 + (lane & 31), col = (kg * 4 + j) * 2 + (lane >> 5);
+    out[i] = w[(size_t)row * K + col];
+}
+
+int launch_pack_a_frag(const float* w, float* out, int M, int K, hipStream_t s) {
+    size_t n = (size_t)M * K;
+    hipLaunchKernelGGL(pack_a_frag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, out, M, K);
+    return DWS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Diffusion-step embedding (`models/utils.py:20-27`) and small dense layers
+// ---------------------------------------------------------------------------
+
+// emb[b, i] = sin(t_b * f_i), emb[b, half+i] = cos(t_b * f_i)
+__global__ void step_embed_kernel(const float* __restrict__ steps, const float* __restrict__ freq,
+                                  float* __restrict__ emb, int half) {
+    const int b = blockIdx.x;
+    const float t = steps[b];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float a = t * freq[i];
+        emb[(size_t)b * 2 * half + i] = sinf(a);
+        emb[(size_t)b * 2 * half + half + i] = cosf(a);
+    }
+}
+
+int launch_step_embed(const float* steps, const float* freq, float* emb, int B, int half, hipStream_t s) {
+    hipLaunchKernelGGL(step_embed_kernel, dim3(B), dim3(64), 0, s, steps, freq, emb, half);
+    return DWS_OK;
+}
+
+// out[b, o] = act(bias[o] + W[o,:] . in[b,:]); one wave per output row, the
+// row is held in registers and reused for every batch element.
+// act: 0 = identity, 1 = swish (`wavenet.py:10-11`).
+template <int ACT>
+__global__ void linear_rows_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                   const float* __restrict__ bias, float* __restrict__ out, int B, int K, int O) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (o >= O) return;
+    constexpr int MAXR = 16;  // K <= 1024
+    float w[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        int k = lane + 64 * i;
+        w[i] = (k < K) ? W[(size_t)o * K + k] : 0.f;
+    }
+    const float bo = bias[o];
+    for (int b = 0; b < B; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            int k = lane + 64 * i;
+            if (k < K) acc = fmaf(w[i], in[(size_t)b * K + k], acc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) {
+            float y = acc + bo;
+            if (ACT == 1) y = y / (1.f + expf(-y));
+            out[(size_t)b * O + o] = y;
+        }
+    }
+}
+
+int launch_linear_rows(const float* in, const float* W, const float* bias, float* out, int B, int K, int O,
+                       int act, hipStream_t s) {
+    DWS_CHECK(K <= 1024, DWS_ERR_UNSUPPORTED, "linear_rows: K=%d > 1024 not supported", K);
+    dim3 grid(ceil_div(O, 4)), block(256);
+    if (act == 1)
+        hipLaunchKernelGGL(linear_rows_kernel<1>, grid, block, 0, s, in, W, bias, out, B, K, O);
+    else
+        hipLaunchKernelGGL(linear_rows_kernel<0>, grid, block, 0, s, in, W, bias, out, B, K, O);
+    return DWS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// init_conv: x[b,c,l] = relu(b_i[c] + sum_ci W_i[c,ci] * audio[b,ci,l])   (`wavenet.py:184,206`)
+// ---------------------------------------------------------------------------
+__global__ void init_conv_kernel(const float* __restrict__ audio, const float* __restrict__ W,
+                                 const float* __restrict__ bias, float* __restrict__ x, int Cin, int C, int L) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const float bc = bias[c];
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
+        float acc = bc;
+        for (int ci = 0; ci < Cin; ++ci) acc = fmaf(W[c * Cin + ci], audio[((size_t)b * Cin + ci) * L + l], acc);
+        x[((size_t)b * C + c) * L + l] = fmaxf(acc, 0.f);
+    }
+}
+
+int launch_init_conv(const float* audio, const float* W, const float* bias, float* x, int B, int Cin, int C, int L,
+                     hipStream_t s) {
+    ProfileScope ps("init_conv", s);
+    dim3 grid(min(ceil_div(L, 256), 64), C, B);
+    hipLaunchKernelGGL(init_conv_kernel, grid, dim3(256), 0, s, audio, W, bias, x, Cin, C, L);
+    return DWS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Fused residual layer, exact-f32 MFMA path
+// ---------------------------------------------------------------------------
+template <int C, int S>
+struct WnTile {
+    static constexpr int P = 64;                            // positions per workgroup
+    static constexpr int WAVES = 4;
+    static constexpr int WM = (C / 32 >= 4) ? 4 : C / 32;   // waves along M
+    static constexpr int WN = WAVES / WM;                   // waves along N
+    static constexpr int NT = (P / 32) / WN;                // N tiles per wave
+    static constexpr int MP = C / 32 / WM;                  // (tanh, sigmoid) tile pairs per wave
+    static constexpr int MR = C / 32 / WM;                  // res tiles per wave
+    static constexpr int MS = S / 32 / WM;                  // skip tiles per wave
+    static constexpr int KC = WN_LAYER_KC;                  // channels per staged chunk
+    static constexpr int NCB = C / KC;
+    static constexpr int XS_FLOATS = 2 * 3 * KC * P;        // double-buffered x window
+    static constexpr int G_FLOATS = C * P;                  // gate tile
+    static constexpr int LDS_FLOATS = XS_FLOATS > G_FLOATS ? XS_FLOATS : G_FLOATS;
+    static_assert(WN * NT * 32 == P, "N split");
+    static_assert(C % (32 * WM) == 0 && S % (32 * WM) == 0 && C % KC == 0, "channel counts");
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int C, int S>
+__global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
+    using T = WnTile<C, S>;
+    constexpr int P = T::P, KC = T::KC, NT = T::NT, MP = T::MP, MR = T::MR, MS = T::MS;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % T::WM, wn = wave / T::WM;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int ntl = (a.L + P - 1) / P;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = tile / ntl;
+    const int l0 = (tile % ntl) * P;
+    const int L = a.L, dil = a.dilation;
+
+    const float* xb = a.x_in + (size_t)b * C * L;
+    const float* pt = a.part_t + (size_t)b * a.part_t_bstride;
+
+    // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 3 taps x P positions
+    constexpr int ROWS = 3 * KC;            // rows per chunk
+    constexpr int RPW = ROWS / T::WAVES;    // rows per wave
+    float stg[RPW];
+    auto stage_load = [&](int cb) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + T::WAVES * i;
+            const int tap = row / KC, cc = row % KC;
+            const int c = cb * KC + cc;
+            const int pos = l0 + lane + (tap - 1) * dil;
+            float v = 0.f;
+            if (pos >= 0 && pos < L) v = xb[(size_t)c * L + pos] + pt[c];
+            stg[i] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float* xs = lds + buf * (3 * KC * P);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + T::WAVES * i;
+            xs[row * P + lane] = stg[i];
+        }
+    };
+
+    // ---- GEMM1: H[2C x P] = Wd[2C x 3C] . Xs[3C x P]
+    f32x16 acc[2 * MP][NT];
+#pragma unroll
+    for (int m = 0; m < 2 * MP; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    constexpr int NKG1 = 3 * C / 8;  // k-groups (of 4 k-steps) per M tile
+    const float4* A1 = reinterpret_cast<const float4*>(a.A1);
+    // tile ids of this wave: tanh tiles wm*MP+i, sigmoid tiles C/32 + wm*MP+i
+    auto a1_ptr = [&](int m, int kg) -> const float4* {
+        const int mt = (m < MP) ? (wm * MP + m) : (C / 32 + wm * MP + (m - MP));
+        return A1 + ((size_t)mt * NKG1 + kg) * 64 + lane;
+    };
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    float4 a_cur[2 * MP], a_nxt[2 * MP];
+#pragma unroll
+    for (int m = 0; m < 2 * MP; ++m) a_cur[m] = *a1_ptr(m, 0);
+
+    for (int cb = 0; cb < T::NCB; ++cb) {
+        if (cb + 1 < T::NCB) stage_load(cb + 1);
+        const float* xs = lds + (cb & 1) * (3 * KC * P);
+#pragma unroll
+        for (int it = 0; it < 3 * KC / 8; ++it) {  // (tap, kg) flattened: 8 consecutive k per iteration
+            const int kg = cb * (3 * KC / 8) + it;
+            const int kgn = (kg + 1 < NKG1) ? kg + 1 : kg;
+#pragma unroll
+            for (int m = 0; m < 2 * MP; ++m) a_nxt[m] = *a1_ptr(m, kgn);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int krow = it * 8 + j * 2 + lhi;  // row inside the chunk (tap*KC + cc)
+                float bf[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bf[n] = xs[krow * P + (wn * NT + n) * 32 + l31];
+#pragma unroll
+                for (int m = 0; m < 2 * MP; ++m) {
+                    const float av = (j == 0) ? a_cur[m].x : (j == 1) ? a_cur[m].y : (j == 2) ? a_cur[m].z : a_cur[m].w;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc[m][n], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2 * MP; ++m) a_cur[m] = a_nxt[m];
+        }
+        if (cb + 1 < T::NCB) stage_store((cb + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- gate: g = tanh(H_t + b_t (+mel_t)) * sigmoid(H_s + b_s (+mel_s)) -> LDS [C][P]
+    float* gt = lds;
+    const float* melb = a.melc ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;
+#pragma unroll
+    for (int m = 0; m < MP; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = (wn * NT + n) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (wm * MP + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float ht = acc[m][n][r] + a.bias1[ch];
+                float hs = acc[MP + m][n][r] + a.bias1[C + ch];
+                if (melb) {
+                    const int pos = l0 + col;
+                    if (pos < L) {
+                        ht += melb[(size_t)ch * L + pos];
+                        hs += melb[(size_t)(C + ch) * L + pos];
+                    }
+                }
+                gt[ch * P + col] = tanhf(ht) * sigmoidf_(hs);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- GEMM2: [res; skip][(C+S) x P] = [Wr; Ws][(C+S) x C] . g[C x P]
+    f32x16 acc2[MR + MS][NT];
+#pragma unroll
+    for (int m = 0; m < MR + MS; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
+
+    constexpr int NKG2 = C / 8;
+    const float4* A2 = reinterpret_cast<const float4*>(a.A2);
+    auto a2_ptr = [&](int m, int kg) -> const float4* {
+        const int mt = (m < MR) ? (wm * MR + m) : (C / 32 + wm * MS + (m - MR));
+        return A2 + ((size_t)mt * NKG2 + kg) * 64 + lane;
+    };
+    float4 c_cur[MR + MS], c_nxt[MR + MS];
+#pragma unroll
+    for (int m = 0; m < MR + MS; ++m) c_cur[m] = *a2_ptr(m, 0);
+#pragma unroll 2
+    for (int kg = 0; kg < NKG2; ++kg) {
+        const int kgn = (kg + 1 < NKG2) ? kg + 1 : kg;
+#pragma unroll
+        for (int m = 0; m < MR + MS; ++m) c_nxt[m] = *a2_ptr(m, kgn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int krow = kg * 8 + j * 2 + lhi;
+            float bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = gt[krow * P + (wn * NT + n) * 32 + l31];
+#pragma unroll
+            for (int m = 0; m < MR + MS; ++m) {
+                const float av = (j == 0) ? c_cur[m].x : (j == 1) ? c_cur[m].y : (j == 2) ? c_cur[m].z : c_cur[m].w;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc2[m][n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MR + MS; ++m) c_cur[m] = c_nxt[m];
+    }
+
+    // ---- epilogue: x' = (x + res + b_r) * sqrt(.5);  skip_acc (+)= skip + b_s
+    const float rs = 0.70710678118654752440f;
+    float* xo = a.x_out + (size_t)b * C * L;
+    float* sk = a.skip + (size_t)b * S * L;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int pos = l0 + (wn * NT + n) * 32 + l31;
+        if (pos < L) {
+            if (!a.last_layer) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        const size_t idx = (size_t)ch * L + pos;
+                        xo[idx] = (xb[idx] + (acc2[m][n][r] + a.bias2[ch])) * rs;
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < MS; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const size_t idx = (size_t)sc * L + pos;
+                    const float v = acc2[MR + m][n][r] + a.bias2[C + sc];
+                    sk[idx] = a.first_layer ? v : sk[idx] + v;
+                }
+        }
+    }
+}
+
+template <int C, int S>
+static int launch_layer_t(const WnLayerArgs& a, hipStream_t s) {
+    ProfileScope ps("wn_layer_mfma", s);
+    const int ntl = ceil_div(a.L, WnTile<C, S>::P);
+    hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S>), dim3(a.B * ntl), dim3(256), 0, s, a);
+    return DWS_OK;
+}
+
+bool wn_layer_mfma_supported(int C, int S) {
+    return (C == 64 && S == 64) || (C == 128 && S == 128) || (C == 128 && S == 256) || (C == 256 && S == 256);
+}
+
+int launch_wn_layer_mfma(int C, int S, const WnLayerArgs& a, hipStream_t s) {
+    if (C == 64 && S == 64) return launch_layer_t<64, 64>(a, s);
+    if (C == 128 && S == 128) return launch_layer_t<128, 128>(a, s);
+    if (C == 128 && S == 256) return launch_layer_t<128, 256>(a, s);
+    if (C == 256 && S == 256) return launch_layer_t<256, 256>(a, s);
+    return set_error(DWS_ERR_UNSUPPORTED, "wn_layer_mfma: (C=%d,S=%d) not instantiated", C, S);
+}
+
+// ---------------------------------------------------------------------------
+// Generic residual layer (any C, S): plain FMA kernels used for channel counts
+// the MFMA tiling does not cover (tiny test models).  Same math, same order of
+// stages; two kernels because the gate needs all of H.
+// ---------------------------------------------------------------------------
+__global__ void wn_gate_generic_kernel(WnLayerArgs a, int C) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int L = a.L, d = a.dilation;
+    const float* xb = a.x_in + (size_t)b * C * L;
+    const float* pt = a.part_t + (size_t)b * a.part_t_bstride;
+    const float* wt = a.Wd + (size_t)c * C * 3;        // folded [2C][C][3]
+    const float* ws = a.Wd + (size_t)(C + c) * C * 3;
+    const float* melb = a.melc ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
+        float ht = a.bias1[c], hs = a.bias1[C + c];
+        for (int ci = 0; ci < C; ++ci) {
+            const float p = pt[ci];
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int pos = l + (tap - 1) * d;
+                if (pos >= 0 && pos < L) {
+                    const float hv = xb[(size_t)ci * L + pos] + p;
+                    ht = fmaf(wt[ci * 3 + tap], hv, ht);
+                    hs = fmaf(ws[ci * 3 + tap], hv, hs);
+                }
+            }
+        }
+        if (melb) {
+            ht += melb[(size_t)c * L + l];
+            hs += melb[(size_t)(C + c) * L + l];
+        }
+        a.gate_ws[((size_t)b * C + c) * L + l] = tanhf(ht) * sigmoidf_(hs);
+    }
+}
+
+__global__ void wn_resskip_generic_kernel(WnLayerArgs a, int C, int S) {
+    const int b = blockIdx.z, o = blockIdx.y;  // o < C: res row, else skip row o-C
+    const int L = a.L;
+    const float* g = a.gate_ws + (size_t)b * C * L;
+    const float* w = (o < C) ? a.Wr + (size_t)o * C : a.Ws + (size_t)(o - C) * C;
+    const float bias = a.bias2[o];
+    if (o < C && a.last_layer) return;
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int ci = 0; ci < C; ++ci) acc = fmaf(w[ci], g[(size_t)ci * L + l], acc);
+        acc += bias;
+        if (o < C) {
+            const size_t idx = ((size_t)b * C + o) * L + l;
+            a.x_out[idx] = (a.x_in[idx] + acc) * 0.70710678118654752440f;
+        } else {
+            const size_t idx = ((size_t)b * S + (o - C)) * L + l;
+            a.skip[idx] = a.first_layer ? acc : a.skip[idx] + acc;
+        }
+    }
+}
+
+int launch_wn_layer_generic(int C, int S, const WnLayerArgs& a, hipStream_t s) {
+    ProfileScope ps("wn_layer_generic", s);
+    const int gx = min(ceil_div(a.L, 256), 256);
+    hipLaunchKernelGGL(wn_gate_generic_kernel, dim3(gx, C, a.B), dim3(256), 0, s, a, C);
+    hipLaunchKernelGGL(wn_resskip_generic_kernel, dim3(gx, C + S, a.B), dim3(256), 0, s, a, C, S);
+    return DWS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// final_conv: out = Wz . relu(Wf . (skip * scale) + bf) + bz   (`wavenet.py:165,198-200,208`)
+// ---------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256, 2) void wn_final_mfma_kernel(WnFinalArgs a) {
+    constexpr int P = 64, WAVES = 4;
+    constexpr int WM = (S / 32 >= 4) ? 4 : S / 32, WN = WAVES / WM, NT = (P / 32) / WN, MT = S / 32 / WM;
+    __shared__ __attribute__((aligned(16))) float lds[S * P];
+    __shared__ float red[WAVES][P];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int L = a.L;
+    const int ntl = (L + P - 1) / P;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = tile / ntl, l0 = (tile % ntl) * P;
+
+    const float* sk = a.skip + (size_t)b * S * L;
+    for (int i = tid; i < S * P; i += 256) {
+        const int row = i / P, col = i % P;
+        const int pos = l0 + col;
+        lds[i] = (pos < L) ? sk[(size_t)row * L + pos] * a.scale : 0.f;
+    }
+    __syncthreads();
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    constexpr int NKG = S / 8;
+    const float4* A = reinterpret_cast<const float4*>(a.Af);
+#pragma unroll 2
+    for (int kg = 0; kg < NKG; ++kg) {
+        float4 av4[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av4[m] = A[((size_t)(wm * MT + m) * NKG + kg) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int krow = kg * 8 + j * 2 + lhi;
+            float bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = lds[krow * P + (wn * NT + n) * 32 + l31];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float av = (j == 0) ? av4[m].x : (j == 1) ? av4[m].y : (j == 2) ? av4[m].z : av4[m].w;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+    // y = relu(acc + bf[row]); optional tap; out[oc] = bz[oc] + sum_row Wz[oc,row] * y
+    for (int oc = 0; oc < a.Cout; ++oc) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float part = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float y = fmaxf(acc[m][n][r] + a.bf[row], 0.f);
+                    part = fmaf(a.Wz[oc * S + row], y, part);
+                    if (oc == 0 && a.tap) {
+                        const int pos = l0 + (wn * NT + n) * 32 + l31;
+                        if (pos < L) a.tap[((size_t)b * S + row) * L + pos] = y;
+                    }
+                }
+            part += __shfl_xor(part, 32);
+            if (lhi == 0) red[wave][(wn * NT + n) * 32 + l31] = part;
+        }
+        __syncthreads();
+        if (tid < P) {
+            // waves with the same wn cover the same columns; sum over wm
+            const int col = tid;
+            const int wn_of_col = (col / 32) / NT;
+            float sacc = a.bz[oc];
+            for (int w = 0; w < WM; ++w) sacc += red[wn_of_col * WM + w][col];
+            const int pos = l0 + col;
+            if (pos < L) a.out[((size_t)b * a.Cout + oc) * L + pos] = sacc;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void wn_final_generic_kernel(WnFinalArgs a, int S) {
+    // one thread per position; y rows computed on the fly (tiny models only)
+    const int b = blockIdx.y, L = a.L;
+    const float* sk = a.skip + (size_t)b * S * L;
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
+        for (int oc = 0; oc < a.Cout; ++oc) {
+            float o = a.bz[oc];
+            for (int r = 0; r < S; ++r) {
+                float acc = 0.f;
+                for (int k = 0; k < S; ++k) acc = fmaf(a.Wf[(size_t)r * S + k], sk[(size_t)k * L + l] * a.scale, acc);
+                const float y = fmaxf(acc + a.bf[r], 0.f);
+                if (oc == 0 && a.tap) a.tap[((size_t)b * S + r) * L + l] = y;
+                o = fmaf(a.Wz[oc * S + r], y, o);
+            }
+            a.out[((size_t)b * a.Cout + oc) * L + l] = o;
+        }
+    }
+}
+
+bool wn_final_mfma_supported(int S) { return S == 64 || S == 128 || S == 256; }
+
+int launch_wn_final(int S, const WnFinalArgs& a, hipStream_t s) {
+    ProfileScope ps("wn_final", s);
+    const int ntl = ceil_div(a.L, 64);
+    if (S == 64)
+        hipLaunchKernelGGL((wn_final_mfma_kernel<64>), dim3(a.B * ntl), dim3(256), 0, s, a);
+    else if (S == 128)
+        hipLaunchKernelGGL((wn_final_mfma_kernel<128>), dim3(a.B * ntl), dim3(256), 0, s, a);
+    else if (S == 256)
+        hipLaunchKernelGGL((wn_final_mfma_kernel<256>), dim3(a.B * ntl), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(wn_final_generic_kernel, dim3(min(ceil_div(a.L, 128), 1024), a.B), dim3(128), 0, s, a, S);
+    return DWS_OK;
+}
+
+}  // namespace dws

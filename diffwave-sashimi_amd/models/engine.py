@@ -1,0 +1,126 @@
+"""Shared host-side plumbing of the two model shims: owns the ``dws_model``
+handle, mirrors the module's state_dict into it, runs forward / sampling."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class EngineModule(nn.Module):
+    """Base of :class:`WaveNet` and :class:`Sashimi`.
+
+    Subclasses register parameters in the reference's state_dict layout and
+    implement ``_desc()``.  ``forward`` keeps the reference contract
+    ``net((audio[B,in,L], diffusion_steps[B,1]), mel_spec=None)``
+    (``models/wavenet.py:202-210``, ``models/sashimi.py:277-313``)."""
+
+    def __init__(self):
+        super().__init__()
+        self._handle = None
+        self._versions = {}
+        self._shape = None
+        self._mel_key = None
+
+    # -- handle management ---------------------------------------------------
+    def _desc(self):
+        raise NotImplementedError
+
+    def _ensure_handle(self):
+        if self._handle is None:
+            lib = _lib.load()
+            h = ctypes.c_void_p()
+            desc = self._desc()
+            _lib.check(lib.dws_model_create(ctypes.byref(desc), ctypes.byref(h)))
+            self._handle = h
+            self._versions = {}
+        return self._handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None and _lib._lib is not None:
+                _lib._lib.dws_model_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _engine_state(self):
+        """(name, tensor) pairs handed to dws_model_set_param: the state_dict."""
+        return self.state_dict(keep_vars=True).items()
+
+    def _sync_params(self):
+        """Hand every changed state_dict tensor to the engine (raw: weight_g /
+        weight_v / bias ...; folding and packing happen in dws_model_commit)."""
+        lib = _lib.load()
+        h = self._ensure_handle()
+        stream = _lib.current_stream()
+        for name, t in self._engine_state():
+            key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+            if self._versions.get(name) == key:
+                continue
+            if t.dtype == torch.int64:
+                src, dtype = t.detach().contiguous(), 1
+            else:
+                src, dtype = t.detach().to(torch.float32).contiguous(), 0
+            shape = (ctypes.c_int64 * max(src.dim(), 1))(*src.shape)
+            _lib.check(lib.dws_model_set_param(h, name.encode(), src.data_ptr(), shape, src.dim(), dtype, stream))
+            if src.device.type != "cuda":
+                torch.cuda.synchronize()
+            self._versions[name] = key
+            self._mel_key = None  # conditioner terms depend on the weights
+
+    def _prepare(self, B, L):
+        if self._shape != (B, L):
+            _lib.check(_lib.load().dws_model_prepare(self._ensure_handle(), B, L))
+            self._shape = (B, L)
+            self._mel_key = None
+
+    def _set_condition(self, mel_spec):
+        lib = _lib.load()
+        h = self._ensure_handle()
+        if mel_spec is None:
+            if self._mel_key is not None:
+                _lib.check(lib.dws_model_set_condition(h, 0, 0, 0, _lib.current_stream()))
+                self._mel_key = None
+            return
+        key = (mel_spec.data_ptr(), mel_spec._version, tuple(mel_spec.shape))
+        if key == self._mel_key:
+            return
+        mel = mel_spec.detach().to(torch.float32).contiguous()
+        if mel.dim() != 3:
+            raise RuntimeError("mel_spec must be [B or 1, mel_bands, Tmel]")
+        _lib.check(lib.dws_model_set_condition(h, mel.data_ptr(), mel.shape[0], mel.shape[2], _lib.current_stream()))
+        self._mel_key = key
+
+    # -- reference surface -----------------------------------------------------
+    def forward(self, input_data, mel_spec=None):
+        audio, diffusion_steps = input_data
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "the backward/training path (SURVEY.md 8a rows a19-a20) is not built yet; "
+                "call under torch.no_grad() or .eval()")
+        if audio.device.type != "cuda":
+            raise RuntimeError("libdws runs on the GPU only: move the model and inputs to cuda "
+                               "(there is no CPU fallback)")
+        if audio.dim() != 3:
+            raise RuntimeError("audio must be [B, in_channels, L]")
+        B, Cin, L = audio.shape
+        with torch.no_grad():
+            self._sync_params()
+            self._prepare(B, L)
+            self._set_condition(mel_spec)
+            x = audio.detach().to(torch.float32).contiguous()
+            steps = diffusion_steps.detach().to(device=audio.device, dtype=torch.float32).reshape(-1).contiguous()
+            if steps.numel() != B:
+                raise RuntimeError(f"diffusion_steps must hold B={B} entries, got {tuple(diffusion_steps.shape)}")
+            out = torch.empty((B, self.out_channels, L), device=audio.device, dtype=torch.float32)
+            _lib.check(_lib.load().dws_model_forward(self._handle, x.data_ptr(), steps.data_ptr(), out.data_ptr(),
+                                                     _lib.current_stream()))
+        return out
+
+    def read_tap(self, name, shape):
+        """Parity/debug tap of an internal activation (see dws_model_read_tap)."""
+        out = torch.empty(shape, device="cuda", dtype=torch.float32)
+        _lib.check(_lib.load().dws_model_read_tap(self._handle, name.encode(), out.data_ptr(), out.numel(),
+                                                  _lib.current_stream()))
+        return out

@@ -1,0 +1,182 @@
+/*
+ * dws.h -- flat C ABI of libdws.so, the MI355X (gfx950) DiffWave denoising-loop engine.
+ *
+ * This is the drop-in boundary.  Everything below is
+ * `extern "C"`, plain pointers + explicit sizes + a stream handle; there are no
+ * torch types in any signature.  All data pointers are DEVICE pointers unless a
+ * parameter is documented as host memory.  Outputs are allocated by the caller
+ * (the reference allocates them through torch, `cauchy_cuda.cu:355,462-463`);
+ * inputs are borrowed for the duration of the call and never written.
+ *
+ * Threading / streams: every entry point enqueues on the `stream` it is given
+ * (a `hipStream_t` passed as `void*`; NULL = the default stream) and returns
+ * without synchronising, exactly like the reference kernels which launch on
+ * `at::cuda::getCurrentCUDAStream()` (`cauchy_cuda.cu:124,222,356,464`).
+ * One process <-> one device (`generate.py:86`, `distributed_util.py:55`).
+ *
+ * Errors: every function returns an `int` status: 0 = ok, negative = error
+ * class (below).  `dws_last_error()` returns a thread-local message.  The
+ * Python host side turns DWS_ERR_UNSUPPORTED into `NotImplementedError`
+ * (`extensions/cauchy/cauchy.py:72-77,95-101`) and everything else into
+ * `RuntimeError` (the reference's `TORCH_CHECK`s, `cauchy.cpp:6-7,58-64`).
+ * Nothing fails silently: an unsupported N raises instead of falling through
+ * the `switch` as the reference does (`cauchy_cuda.cu:366-372`).
+ *
+ * Reference citations are `path:line` relative to albertfgu/diffwave-sashimi.
+ */
+#ifndef DWS_H_
+#define DWS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWS_OK               0
+#define DWS_ERR_INVALID     -1   /* bad argument / shape mismatch (reference: TORCH_CHECK -> RuntimeError) */
+#define DWS_ERR_UNSUPPORTED -2   /* size the kernels do not cover (reference: NotImplementedError)         */
+#define DWS_ERR_HIP         -3   /* a HIP runtime / hipFFT call failed                                      */
+#define DWS_ERR_STATE       -4   /* call order violated (e.g. forward before prepare)                       */
+
+/* Thread-local description of the last non-zero status returned on this thread. */
+const char* dws_last_error(void);
+/* ABI version of the library (bumped when a signature changes). */
+int dws_abi_version(void);
+/* Name of the GPU architecture the kernels were compiled for ("gfx950"). */
+const char* dws_arch(void);
+
+/* ------------------------------------------------------------------------
+ * Cauchy multiply -- replaces the pybind module `cauchy_mult`
+ * (`extensions/cauchy/cauchy.cpp:86-95`).  Complex64 tensors are passed as
+ * interleaved (re,im) float pairs, i.e. the memory of a contiguous
+ * torch.cfloat tensor.
+ *
+ *   v, w : [B, N]   z : [L]   out, dout : [B, L]   dv, dw : [B, N]
+ * ------------------------------------------------------------------------ */
+
+/* cauchy_mult_sym_fwd (`cauchy.cpp:55-66`, kernel `cauchy_cuda.cu:242-375`):
+ *   out[b,l] = sum_{n<N} v[b,n]/(z[l]-w[b,n]) + conj(v[b,n])/(z[l]-conj(w[b,n]))
+ * N is the HALF state size.  Any 1 <= N <= 1024 is accepted (the reference
+ * accepts powers of two 2..1024 only, `cauchy.py:95-98`). */
+int dws_cauchy_sym_fwd(const float* v, const float* z, const float* w, float* out,
+                       int64_t B, int64_t N, int64_t L, void* stream);
+
+/* cauchy_mult_sym_bwd (`cauchy.cpp:68-82`, kernel `cauchy_cuda.cu:377-487`):
+ *   dv[b,n] = sum_l dout/(conj z - conj w) + conj(dout)/(z - conj w)
+ *   dw[b,n] = conj(v) * sum_l dout/(conj z - conj w)^2 + conj(dout)/(z - conj w)^2 */
+int dws_cauchy_sym_bwd(const float* v, const float* z, const float* w, const float* dout,
+                       float* dv, float* dw, int64_t B, int64_t N, int64_t L, void* stream);
+
+/* cauchy_mult_fwd (`cauchy.cpp:25-36`, kernel `cauchy_cuda.cu:44-139`), non-symmetric:
+ *   out[b,l] = sum_{n<N} v[b,n]/(z[l]-w[b,n]) */
+int dws_cauchy_fwd(const float* v, const float* z, const float* w, float* out,
+                   int64_t B, int64_t N, int64_t L, void* stream);
+
+/* cauchy_mult_bwd (`cauchy.cpp:38-53`, kernel `cauchy_cuda.cu:141-240`):
+ *   dv[b,n] = sum_l dout/conj(z-w),  dw[b,n] = conj(v) * sum_l dout/conj(z-w)^2 */
+int dws_cauchy_bwd(const float* v, const float* z, const float* w, const float* dout,
+                   float* dv, float* dw, int64_t B, int64_t N, int64_t L, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Model -- replaces `models.construct_model(cfg)` + `net((audio, t), mel)`
+ * (`models/__init__.py:4-12`, `models/wavenet.py:202-210`,
+ * `models/sashimi.py:277-313`).
+ * ------------------------------------------------------------------------ */
+
+#define DWS_KIND_WAVENET 1   /* model._name_ == "wavenet" */
+#define DWS_KIND_SASHIMI 2   /* model._name_ == "sashimi" */
+#define DWS_MAX_POOL 8
+
+/* Field names follow the YAML keys of configs/model/{wavenet,sashimi}.yaml. */
+typedef struct dws_model_desc {
+    int32_t kind;
+    int32_t in_channels, out_channels;
+    int32_t diffusion_step_embed_dim_in, diffusion_step_embed_dim_mid, diffusion_step_embed_dim_out;
+    int32_t unconditional;            /* 1: no mel path */
+    int32_t mel_upsample[2];          /* conditional only; default {16,16} (`wavenet.py:50`) */
+    int32_t mel_bands;                /* 80 (`wavenet.py:70`) */
+    /* wavenet */
+    int32_t res_channels, skip_channels, num_res_layers, dilation_cycle;
+    /* sashimi */
+    int32_t d_model, n_layers, n_pool, pool[DWS_MAX_POOL], expand, ff, unet, L;
+} dws_model_desc;
+
+typedef struct dws_model dws_model;
+
+int dws_model_create(const dws_model_desc* desc, dws_model** out);
+int dws_model_destroy(dws_model* m);
+
+/* Number of state-dict entries the model expects and their names/shapes, in
+ * the reference's state_dict key layout.  `shape` must
+ * hold 8 entries; returns ndim through *ndim.  dtype: 0 = float32, 1 = int64. */
+int dws_model_num_params(const dws_model* m);
+int dws_model_param_info(const dws_model* m, int index, const char** name,
+                         int64_t* shape, int* ndim, int* dtype);
+
+/* Hand one RAW state-dict tensor (weight_g / weight_v / bias / S4 parameters as
+ * real (...,2) views, `s4.py:631-638`) to the model.  `data` may be a device or
+ * host pointer; it is copied, not retained.  Weight-norm folding, MFMA operand
+ * packing and S4 kernel generation happen inside dws_model_commit(). */
+int dws_model_set_param(dws_model* m, const char* name, const void* data,
+                        const int64_t* shape, int ndim, int dtype, void* stream);
+
+/* Fold / pack everything that depends only on the weights.  Called implicitly
+ * by forward when parameters changed since the last commit. */
+int dws_model_commit(dws_model* m, void* stream);
+
+/* Size the workspace for inputs of shape audio[B, in_channels, L]. */
+int dws_model_prepare(dws_model* m, int64_t B, int64_t L);
+
+/* Install (or with mel == NULL remove) the mel-spectrogram condition
+ * mel[Bm, mel_bands, Tmel], Bm in {1, B} (`generate.py:140,155`).  The
+ * upsample + 1x1 terms of every block (`wavenet.py:98-111`,
+ * `sashimi.py:160-175`) are evaluated once here, not per step. */
+int dws_model_set_condition(dws_model* m, const float* mel, int64_t Bm, int64_t Tmel, void* stream);
+
+/* eps[B, out_channels, L] = net((audio[B, in_channels, L], steps[B]))  (fp32).
+ * `steps` holds the diffusion step of every batch element as float32
+ * (`generate.py:50`; the int64 steps of `train.py:218` are converted by the host side). */
+int dws_model_forward(dws_model* m, const float* audio, const float* steps, float* out, void* stream);
+
+/* Debug/parity tap: copy an internal activation into `dst` (device pointer,
+ * `capacity` floats).  WaveNet: "pre_final" = ReLU(final_conv[0](skip)) [B,S,L],
+ * "skip" [B,S,L], "x" (last residual output) [B,C,L]. */
+int dws_model_read_tap(dws_model* m, const char* tap, float* dst, int64_t capacity, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Reverse-diffusion sampler -- replaces `generate.sampling`
+ * (`generate.py:23-55`).  One reverse step is captured as a hipGraph on first
+ * use and replayed T times; step index, schedule coefficients and the RNG
+ * counter live in device memory.
+ *
+ *   x          [B, C, L]  in: x_T (or anything when seed-driven, see below); out: x_0
+ *   alpha, alpha_bar, sigma  HOST float[T] tables from calc_diffusion_hyperparams
+ *                            (`utils.py:121-151`)
+ *   noise      optional DEVICE [T, B, C, L]: noise[t] is added after step t
+ *              (t > 0).  NULL -> on-device Philox4x32-10 + Box-Muller keyed by
+ *              (seed, t, element).
+ *   init_from_seed  non-zero: also draw x_T ~ N(0, I) from the Philox stream.
+ * ------------------------------------------------------------------------ */
+int dws_sampler_run(dws_model* m, float* x, const float* alpha, const float* alpha_bar,
+                    const float* sigma, int32_t T, const float* noise, uint64_t seed,
+                    int32_t init_from_seed, int32_t use_graph, void* stream);
+
+/* Run `n_steps` reverse steps starting at step index t_start (for benchmarking
+ * a bounded number of steps of the T-step loop with the same graph). */
+int dws_sampler_steps(dws_model* m, float* x, const float* alpha, const float* alpha_bar,
+                      const float* sigma, int32_t T, int32_t t_start, int32_t n_steps,
+                      uint64_t seed, int32_t use_graph, void* stream);
+
+/* Timing of the dominant kernel, measured with HIP events on the stream the
+ * kernel was launched on (bench.py roofline leg).  Enables per-launch event
+ * recording for kernels whose name contains `substr`; query returns the number
+ * of launches and their total milliseconds since enable. */
+int dws_profile_enable(const char* substr);
+int dws_profile_query(int64_t* launches, double* total_ms);
+int dws_profile_disable(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DWS_H_ */

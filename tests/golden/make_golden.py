@@ -1,0 +1,192 @@
+"""Generate the committed golden vectors by importing the reference from
+``/root/reference`` (build container only; see ``_refimport.py``).
+
+    python tests/golden/make_golden.py [group ...]
+
+Writes ``tests/golden/<group>.npz``.  Every group records inputs and the
+reference's outputs (or the seeds that regenerate the inputs, see
+``tests/cases.py``).  SaShiMi vectors are produced with the extension's
+*symmetric* Cauchy semantics (``symmetric_cauchy = 1`` in the file)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import _refimport  # noqa: E402
+from tests import cases  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays")
+
+
+def sd_arrays(sd, prefix="sd/"):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def ref_model(cfg, state_dict):
+    models, _, _, _ = _refimport.load()
+    net = models.construct_model(dict(cfg)).eval()
+    missing = net.load_state_dict(state_dict, strict=True)
+    return net
+
+
+# ---------------------------------------------------------------------------
+def g_embedding():
+    from models.utils import calc_diffusion_step_embedding as ref_emb
+    t = torch.tensor([[0.], [1.], [7.], [49.], [199.]])
+    save("embedding", t_float=t, emb_float=ref_emb(t, 128), t_int=t.long(), emb_int=ref_emb(t.long(), 128),
+         emb_float_64=ref_emb(t, 64))
+
+
+def g_schedule():
+    _, _, utils, _ = _refimport.load()
+    out = {}
+    for tag, (T, b0, bT) in {"sc09": (200, 1e-4, 0.02), "ljspeech": (50, 1e-4, 0.05), "tiny": (6, 1e-4, 0.05)}.items():
+        dh = utils.calc_diffusion_hyperparams(T, b0, bT, fast=True)
+        for k in ("Beta", "Alpha", "Alpha_bar", "Sigma"):
+            out[f"{tag}/{k}"] = dh[k]
+        out[f"{tag}/args"] = np.array([T, b0, bT], dtype=np.float64)
+    # fast-sampling hook (`utils.py:136-138`)
+    beta = [1e-4, 1e-3, 1e-2, 5e-2, 2e-1, 5e-1]
+    dh = utils.calc_diffusion_hyperparams(200, 1e-4, 0.02, beta=beta, fast=True)
+    out["fast/beta"] = np.array(beta, dtype=np.float64)
+    for k in ("Beta", "Alpha", "Alpha_bar", "Sigma"):
+        out[f"fast/{k}"] = dh[k]
+    save("schedule", **out)
+
+
+def g_wavenet():
+    out = {}
+    for name, (cfg, B, L, wseed, iseed, store) in cases.WAVENET_CASES.items():
+        ours = cases.build_ours(cfg, wseed)
+        sd = {k: v.detach().clone() for k, v in ours.state_dict().items()}
+        net = ref_model(cfg, sd)   # strict load: proves state_dict key/shape compatibility
+        audio, steps = cases.wavenet_inputs(B, L, cfg["in_channels"], iseed)
+        with torch.no_grad():
+            taps = {}
+            h = net.final_conv[1].register_forward_hook(lambda m, i, o: taps.__setitem__("pre_final", o.detach()))
+            eps = net((audio, steps))
+            h.remove()
+            eps_int = net((audio, steps.long()))
+        assert torch.equal(eps, eps_int)
+        out[f"{name}/eps"] = eps
+        for k, v in cases.summarize(taps["pre_final"], stride=64).items():
+            out[f"{name}/pre_final/{k}"] = v
+        out[f"{name}/sd_digest"] = np.array([sum(float(v.double().sum()) for v in sd.values()),
+                                             sum(float((v.double() ** 2).sum()) for v in sd.values())])
+        if store:
+            out.update(sd_arrays(sd, f"{name}/sd/"))
+            out[f"{name}/audio"] = audio
+            out[f"{name}/steps"] = steps
+        print(name, "eps absmax", float(eps.abs().max()))
+    save("wavenet", **out)
+
+
+def g_wavenet_cond():
+    out = {}
+    for name, (cfg, B, L, Tmel, wseed, iseed, store) in cases.WAVENET_COND_CASES.items():
+        ours = cases.build_ours(cfg, wseed)
+        sd = {k: v.detach().clone() for k, v in ours.state_dict().items()}
+        net = ref_model(cfg, sd)
+        audio, steps = cases.wavenet_inputs(B, L, cfg["in_channels"], iseed)
+        for Bm in (1, B):
+            mel = cases.mel_inputs(Bm, Tmel, iseed)
+            with torch.no_grad():
+                eps = net((audio, steps), mel_spec=mel)
+            out[f"{name}/eps_bm{Bm}"] = eps
+            if store:
+                out[f"{name}/mel_bm{Bm}"] = mel
+        with torch.no_grad():
+            out[f"{name}/eps_nomel"] = net((audio, steps))
+        if store:
+            out.update(sd_arrays(sd, f"{name}/sd/"))
+            out[f"{name}/audio"] = audio
+            out[f"{name}/steps"] = steps
+    save("wavenet_cond", **out)
+
+
+def g_sampler():
+    """`generate.sampling` trajectories with recorded noise (T=6 and T=50 on the tiny net)."""
+    _, generate, utils, _ = _refimport.load()
+    cfg, B, L, wseed, iseed, _ = cases.WAVENET_CASES["wn_tiny"]
+    ours = cases.build_ours(cfg, wseed)
+    net = ref_model(cfg, {k: v.detach().clone() for k, v in ours.state_dict().items()})
+    out = {}
+    for tag, (T, b0, bT) in {"T6": (6, 1e-4, 0.05), "T50": (50, 1e-4, 0.05)}.items():
+        dh = utils.calc_diffusion_hyperparams(T, b0, bT, fast=True)
+        size = (B, 1, L)
+        torch.manual_seed(1234)
+        x_T = torch.normal(0, 1, size=size)
+        noise = torch.zeros((T,) + size)
+        for t in range(T - 1, 0, -1):  # the reference draws in this order (`generate.py:47,54`)
+            noise[t] = torch.normal(0, 1, size=size)
+        torch.manual_seed(1234)
+        x0 = generate.sampling(net, size, dh)
+        out[f"{tag}/x_T"] = x_T
+        out[f"{tag}/noise"] = noise
+        out[f"{tag}/x_0"] = x0
+        out[f"{tag}/args"] = np.array([T, b0, bT], dtype=np.float64)
+        print(tag, "x0 absmax", float(x0.abs().max()))
+    save("sampler", **out)
+
+
+def g_cauchy():
+    """fp64 known answers from the reference's own formula + autograd
+    (`extensions/cauchy/cauchy.py:19-26`, method of `test_cauchy.py:53-95`)."""
+    import types
+    stub = types.ModuleType("cauchy_mult")  # the compiled CUDA extension is not loadable here
+    for n in ("cauchy_mult_fwd", "cauchy_mult_bwd", "cauchy_mult_sym_fwd", "cauchy_mult_sym_bwd"):
+        setattr(stub, n, None)
+    sys.modules["cauchy_mult"] = stub
+    sys.path.insert(0, os.path.join(_refimport.REF, "extensions", "cauchy"))
+    from cauchy import cauchy_mult_torch
+    from oracle.cauchy import generate_data
+    out = {}
+    for N in (4, 16, 64):
+        for L in (3, 17, 489, 1024):
+            v_half, z, w_half = generate_data(4, N, L, symmetric=True, seed=2357)
+            v = torch.cat([v_half, v_half.conj()], dim=-1).cdouble().requires_grad_(True)
+            w = torch.cat([w_half, w_half.conj()], dim=-1).cdouble().requires_grad_(True)
+            o = cauchy_mult_torch(v, z.cdouble(), w, symmetric=True)
+            g = torch.Generator().manual_seed(99)
+            dout = torch.randn(o.shape, dtype=torch.complex64, generator=g)
+            dv, dw = torch.autograd.grad(o, (v, w), dout.cdouble())
+            tag = f"sym/N{N}_L{L}"
+            out[f"{tag}/v_half"], out[f"{tag}/z"], out[f"{tag}/w_half"], out[f"{tag}/dout"] = v_half, z, w_half, dout
+            out[f"{tag}/out"], out[f"{tag}/dv"], out[f"{tag}/dw"] = o.detach(), dv[:, :N // 2], dw[:, :N // 2]
+            # non-symmetric on the same draw (full vectors)
+            vf, zf, wf = generate_data(2, N, L, symmetric=False, seed=2357)
+            vf64 = vf.cdouble().requires_grad_(True)
+            wf64 = wf.cdouble().requires_grad_(True)
+            of = cauchy_mult_torch(vf64, zf.cdouble(), wf64, symmetric=False)
+            doutf = torch.randn(of.shape, dtype=torch.complex64, generator=g)
+            dvf, dwf = torch.autograd.grad(of, (vf64, wf64), doutf.cdouble())
+            tag = f"nonsym/N{N}_L{L}"
+            out[f"{tag}/v"], out[f"{tag}/z"], out[f"{tag}/w"], out[f"{tag}/dout"] = vf, zf, wf, doutf
+            out[f"{tag}/out"], out[f"{tag}/dv"], out[f"{tag}/dw"] = of.detach(), dvf, dwf
+    save("cauchy", **out)
+
+
+GROUPS = {"cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
+          "wavenet_cond": g_wavenet_cond, "sampler": g_sampler}
+
+if __name__ == "__main__":
+    _refimport.load()
+    todo = sys.argv[1:] or list(GROUPS)
+    for g in todo:
+        GROUPS[g]()

@@ -1,0 +1,91 @@
+"""GPU: the Cauchy operator against the reference's known-answer method
+(`extensions/cauchy/test_cauchy.py:53-95`): fp64 formula as truth, error budget
+relative to a second fp32 implementation (there pykeops, here the fp32 torch
+evaluation of the same sum)."""
+import pytest
+import torch
+
+from oracle import cauchy as oc
+from tests.conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4
+TOL_FACTOR = 10.0
+
+
+def _relerr(x, ref):
+    return (x.cdouble().cpu() - ref).abs() / ref.abs()
+
+
+@pytest.mark.parametrize("L", [3, 17, 489, 2 ** 10, 1047, 2 ** 11, 2 ** 12, 2 ** 13, 2 ** 14, 2 ** 18])
+@pytest.mark.parametrize("N", [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048])
+def test_cauchy_mult_symmetric(gpu, N, L):
+    from diffwave_sashimi_amd.extensions.cauchy import cauchy_mult
+    if N * L > 2 ** 27:
+        pytest.skip("oracle too slow on the host for this size")
+    batch_size = 4
+    v_half, z, w_half = oc.generate_data(batch_size, N, L, symmetric=True, seed=2357)
+    ref = oc.cauchy_sym_direct(v_half.cdouble(), z.cdouble(), w_half.cdouble())
+    alt = oc.cauchy_sym_direct(v_half, z, w_half)  # fp32 comparison implementation
+    vg = v_half.to(gpu).requires_grad_(True)
+    wg = w_half.to(gpu).requires_grad_(True)
+    out = cauchy_mult(vg, z.to(gpu), wg, symmetric=True)
+    e, ea = _relerr(out.detach(), ref), _relerr(alt, ref)
+    assert e.amax() <= ea.amax() * TOL_FACTOR + ATOL
+    assert e.mean() <= ea.mean() * TOL_FACTOR + ATOL
+    g = torch.Generator().manual_seed(5)
+    dout = torch.randn(out.shape, dtype=torch.complex64, generator=g)
+    dv_ref, dw_ref = oc.cauchy_sym_bwd(v_half.cdouble(), z.cdouble(), w_half.cdouble(), dout.cdouble())
+    dv_alt, dw_alt = oc.cauchy_sym_bwd(v_half, z, w_half, dout)
+    dv, dw = torch.autograd.grad(out, (vg, wg), dout.to(gpu))
+    for got, alt_, ref_ in ((dv, dv_alt, dv_ref), (dw, dw_alt, dw_ref)):
+        e, ea = _relerr(got, ref_), _relerr(alt_, ref_)
+        assert e.amax() <= ea.amax() * TOL_FACTOR + ATOL
+        assert e.mean() <= ea.mean() * TOL_FACTOR + ATOL
+
+
+@pytest.mark.parametrize("N,L", [(4, 3), (16, 17), (64, 489), (64, 1024)])
+def test_cauchy_golden_vectors(gpu, N, L):
+    """Committed fp64 answers from the reference formula + autograd."""
+    from diffwave_sashimi_amd.extensions import cauchy as ext
+    g = load_golden("cauchy")
+    t = f"sym/N{N}_L{L}"
+    v, z, w, dout = (torch.from_numpy(g[f"{t}/{k}"]).to(gpu) for k in ("v_half", "z", "w_half", "dout"))
+    out = ext.cauchy_mult_sym_fwd(v, z, w)
+    dv, dw = ext.cauchy_mult_sym_bwd(v, z, w, dout)
+    assert rel_err(torch.view_as_real(out), torch.view_as_real(torch.from_numpy(g[f"{t}/out"]))) < 1e-4
+    assert rel_err(torch.view_as_real(dv), torch.view_as_real(torch.from_numpy(g[f"{t}/dv"]))) < 1e-4
+    assert rel_err(torch.view_as_real(dw), torch.view_as_real(torch.from_numpy(g[f"{t}/dw"]))) < 1e-4
+    t = f"nonsym/N{N}_L{L}"
+    v, z, w, dout = (torch.from_numpy(g[f"{t}/{k}"]).to(gpu) for k in ("v", "z", "w", "dout"))
+    out = ext.cauchy_mult(v, z, w, symmetric=False)
+    dv, dw = ext.cauchy_mult_bwd(v, z, w, dout)
+    assert rel_err(torch.view_as_real(out), torch.view_as_real(torch.from_numpy(g[f"{t}/out"]))) < 1e-4
+    assert rel_err(torch.view_as_real(dv), torch.view_as_real(torch.from_numpy(g[f"{t}/dv"]))) < 1e-4
+    assert rel_err(torch.view_as_real(dw), torch.view_as_real(torch.from_numpy(g[f"{t}/dw"]))) < 1e-4
+
+
+def test_cauchy_broadcast_front_end_and_errors(gpu):
+    from diffwave_sashimi_amd.extensions import cauchy as ext
+    g = torch.Generator().manual_seed(1)
+    # the model's call shape: v (2,3,H,N), w (H,N) broadcast, z (L/2+1)  (`s4.py:752-758`)
+    v = torch.randn(2, 3, 5, 32, dtype=torch.complex64, generator=g)
+    w = torch.randn(5, 32, dtype=torch.complex64, generator=g) - 2.0
+    z = torch.exp(1j * torch.randn(33, generator=g))
+    out = ext.cauchy_mult(v.to(gpu), z.to(gpu), w.to(gpu), symmetric=True)
+    assert out.shape == (2, 3, 5, 33)
+    wb = w.expand(2, 3, 5, 32).reshape(-1, 32)
+    ref = oc.cauchy_sym_direct(v.reshape(-1, 32).cdouble(), z.cdouble(), wb.cdouble()).reshape(2, 3, 5, 33)
+    assert rel_err(torch.view_as_real(out), torch.view_as_real(ref)) < 1e-4
+    with pytest.raises(RuntimeError):
+        ext.cauchy_mult_sym_fwd(v.reshape(-1, 32), z.to(gpu), w.to(gpu))          # v on CPU
+    with pytest.raises(RuntimeError):
+        ext.cauchy_mult_sym_fwd(v.reshape(-1, 32).to(gpu), z.to(gpu), w.to(gpu))  # shape mismatch
+    with pytest.raises(NotImplementedError):
+        big = torch.zeros(1, 2048, dtype=torch.complex64, device=gpu)
+        ext.cauchy_mult_sym_fwd(big, z.to(gpu), big)
+    # empty inputs
+    e = ext.cauchy_mult_sym_fwd(torch.zeros(0, 4, dtype=torch.complex64, device=gpu), z.to(gpu),
+                                torch.zeros(0, 4, dtype=torch.complex64, device=gpu))
+    assert e.shape == (0, 33)
