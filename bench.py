@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio samples/sec of `generate.py`-style reverse-diffusion
+sampling (BASELINE.json `metric`), on BASELINE config 2:
+
+    SC09 unconditional, WaveNet wnet_h256_d36_T200, B=16 per GPU, L=16000
+
+A "step" is one reverse-diffusion step (network forward + x update + noise) over
+the whole batch, replayed from the captured hipGraph; `value` is
+B*L*n_gpus / (T * seconds_per_step), i.e. finished audio samples per second of
+the full T=200 loop, with x, weights and schedule resident in HBM.
+
+    python bench.py --gpus 1 --steps 200 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: sampling shards by independent clips -- every rank runs its own batch
+with its own Philox stream and there is NO data-path collective ("weak" scaling;
+`generate.py:217-227`).  RCCL is used only for the timing barrier / max.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1]
+    "wnet_h256_d36_T200": dict(
+        model=dict(_name_="wavenet", unconditional=True, in_channels=1, out_channels=1,
+                   diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512,
+                   diffusion_step_embed_dim_out=512, res_channels=256, skip_channels=256,
+                   num_res_layers=36, dilation_cycle=12),
+        diffusion=dict(T=200, beta_0=1e-4, beta_T=0.02), B=16, L=16000),
+    # BASELINE.json configs[0] (the reference's CPU-runnable case)
+    "wnet_h128_d30_T200": dict(
+        model=dict(_name_="wavenet", unconditional=True, in_channels=1, out_channels=1,
+                   diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512,
+                   diffusion_step_embed_dim_out=512, res_channels=128, skip_channels=256,
+                   num_res_layers=30, dilation_cycle=10),
+        diffusion=dict(T=200, beta_0=1e-4, beta_T=0.02), B=16, L=16000),
+}
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def build_model(cfg, device):
+    """Random-init weights of the named architecture (no checkpoints exist offline):
+    reference initialisers under manual_seed(0), final zero-conv re-initialised
+    N(0, 0.1^2) so the network output is not identically zero."""
+    from diffwave_sashimi_amd.models import construct_model
+    torch.manual_seed(0)
+    net = construct_model(dict(cfg["model"]))
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        sd = net.state_dict()
+        for k in ("final_conv.2.conv.weight", "final_conv.2.conv.bias"):
+            sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.1)
+    return net.to(device).eval()
+
+
+def layer_algorithmic_work(cfg):
+    """Per launch of the fused residual-layer kernel:
+    flops = B*L*(14 C^2 + 2 C S); compulsory HBM bytes = B*L*4*(2C + 2S)."""
+    m = cfg["model"]
+    C, S, B, L = m["res_channels"], m["skip_channels"], cfg["B"], cfg["L"]
+    return B * L * (14 * C * C + 2 * C * S), B * L * 4 * (2 * C + 2 * S)
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The oracle (reference-equivalent PyTorch-CPU graph: conv1d per layer, weight-norm
+    per call, no hoisting) timed on this box's host cores at B=1; bounded sample.
+    MKL-DNN convolutions of this size get *slower* with hundreds of threads, so a few
+    thread counts are probed first and the best one is used (`cores` = threads used)."""
+    from oracle import wavenet as own
+    from diffwave_sashimi_amd.models import construct_model
+    ncpu = os.cpu_count() or 1
+    torch.manual_seed(0)
+    net = construct_model(dict(cfg["model"]))
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    L, T = cfg["L"], cfg["diffusion"]["T"]
+    audio = torch.randn(1, 1, L)
+    steps = torch.full((1, 1), float(T - 1))
+
+    def one():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            own.wavenet_forward(sd, cfg["model"], audio, steps)
+        return time.perf_counter() - t0
+
+    t_begin = time.perf_counter()
+    best, best_t = None, float("inf")
+    for th in [c for c in (8, 16, 32, 64) if c <= ncpu] or [ncpu]:
+        torch.set_num_threads(th)
+        one()                      # warm-up at this thread count
+        t = one()
+        if t < best_t:
+            best, best_t = th, t
+        if time.perf_counter() - t_begin > seconds_budget * 0.6 or t > 2.5 * best_t:
+            break
+    torch.set_num_threads(best)
+    one()
+    times = []
+    while len(times) < 3 or (time.perf_counter() - t_begin < seconds_budget and len(times) < 10):
+        times.append(one())
+        if time.perf_counter() - t_begin > 2 * seconds_budget:
+            break
+    per_step = sum(times) / len(times)
+    return {"value": L / (T * per_step), "unit": "audio samples/s", "cores": best, "host_cpus": ncpu, "kind": "port",
+            "sample": f"{len(times)} forward steps at B=1, L={L} with {best} threads (best of a probe over 8..64), "
+                      f"extrapolated to the T={T} loop",
+            "ms_per_step_b1": per_step * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="wnet_h256_d36_T200", choices=list(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from diffwave_sashimi_amd import _lib
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    import ctypes
+    import numpy as np
+
+    lib = _lib.load()  # no fallback: fails loudly without the HIP engine
+    B, L = cfg["B"], cfg["L"]
+    dcfg = cfg["diffusion"]
+    T = dcfg["T"]
+    net = build_model(cfg, dev)
+    dh = calc_diffusion_hyperparams(**dcfg)
+    tabs = [np.ascontiguousarray(dh[k].numpy()) for k in ("Alpha", "Alpha_bar", "Sigma")]
+    ptabs = [t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) for t in tabs]
+    net._sync_params()
+    net._prepare(B, L)
+    x = torch.randn(B, 1, L, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+    stream = _lib.current_stream()
+    seed = 1234 + rank
+
+    def run(n_steps):
+        """n_steps reverse steps of the T-loop (wrapping to t=T-1 when the loop ends)."""
+        done = 0
+        while done < n_steps:
+            k = min(T, n_steps - done)
+            _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, k, seed, 1, stream))
+            done += k
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    run(max(args.warmup, 1))  # >= 1: captures the graph outside the timed region
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * L / (T * ms_per_step * 1e-3)
+
+    result = {
+        "metric": "audio samples/sec (generate.py-style reverse-diffusion sampling, T=%d)" % T,
+        "value": value, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded reference initialisers, x_T ~ N(0,1))",
+        "config": {"workload": args.config, "backbone": cfg["model"]["_name_"], "batch_per_gpu": B, "L": L, "T": T,
+                   "parallelism": "independent clips per GPU, no collective",
+                   "sampler": "hipGraph replay, on-device Philox noise"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel: the fused residual layer.  Timed with HIP events on its own
+        # launch stream inside the engine (eager launches, outside any capture).
+        flops, bytes_ = layer_algorithmic_work(cfg)
+        _lib.check(lib.dws_profile_enable(b"wn_layer"))
+        nprof = 3
+        _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, nprof, seed, 0, stream))
+        torch.cuda.synchronize()
+        n_launch, tot_ms = ctypes.c_int64(), ctypes.c_double()
+        _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
+        lib.dws_profile_disable()
+        avg_ms = tot_ms.value / max(n_launch.value, 1)
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_wavenet_traffic.json")
+        if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and os.path.exists(tfile):
+            # PMC-derived HBM bytes per launch of this kernel (collected with rocprofv3 in
+            # separate --pmc passes on the same command; corrected as the guide prescribes)
+            traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
+        result["roofline"] = {
+            "kernel": "wn_layer_mfma_kernel<%d,%d>" % (cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
+            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "avg_launch_ms": avg_ms, "launches_timed": n_launch.value,
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
+            "hbm_achieved_GBs": bytes_ / (avg_ms * 1e-3) / 1e9,
+            "hbm_frac": bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg)
+        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,9 @@ int sampler_steps(dws_model* m, float* x, const float* alpha, const float* alpha
 
 dws_model::~dws_model() {
     drop_graph();
+    if (smp_ev_in) hipEventDestroy(smp_ev_in);
+    if (smp_ev_out) hipEventDestroy(smp_ev_out);
+    if (smp_stream) hipStreamDestroy(smp_stream);
     for (auto* p : params) delete p;
 }
 

@@ -141,9 +141,10 @@ __global__ __launch_bounds__(256) void cauchy_bwd_kernel(const float2* __restric
 
 static int check_shapes(const char* fn, const void* a, const void* b, const void* c, const void* d, int64_t B,
                         int64_t N, int64_t L) {
-    DWS_CHECK(a && b && c && d, DWS_ERR_INVALID, "%s: null pointer", fn);
     DWS_CHECK(B >= 0 && N >= 1 && L >= 0, DWS_ERR_INVALID, "%s: bad shape B=%lld N=%lld L=%lld", fn, (long long)B,
               (long long)N, (long long)L);
+    // empty tensors legitimately carry null data pointers
+    DWS_CHECK((a && b && c && d) || B == 0 || L == 0, DWS_ERR_INVALID, "%s: null pointer", fn);
     DWS_CHECK(N <= CAUCHY_MAX_N, DWS_ERR_UNSUPPORTED, "%s: N=%lld > %d is not supported (`cauchy.py:95-98`)", fn,
               (long long)N, CAUCHY_MAX_N);
     DWS_CHECK(L <= (int64_t)1 << 31 && B <= 65535LL * 32768LL, DWS_ERR_UNSUPPORTED,
@@ -171,8 +172,9 @@ template <bool SYM>
 static int cauchy_bwd(const float* v, const float* z, const float* w, const float* dout, float* dv, float* dw,
                       int64_t B, int64_t N, int64_t L, hipStream_t s) {
     DWS_TRY(check_shapes(SYM ? "cauchy_mult_sym_bwd" : "cauchy_mult_bwd", v, z, w, dout, B, N, L));
-    DWS_CHECK(dv && dw, DWS_ERR_INVALID, "cauchy bwd: null output");
     if (B == 0) return DWS_OK;
+    DWS_CHECK(dv && dw, DWS_ERR_INVALID, "cauchy bwd: null output");
+    DWS_CHECK(L == 0 || (v && z && w && dout), DWS_ERR_INVALID, "cauchy bwd: null pointer");
     ProfileScope ps(SYM ? "cauchy_sym_bwd" : "cauchy_bwd", s);
     constexpr int NG = 4;
     dim3 grid((unsigned)B, (unsigned)ceil_div(N, NG));

@@ -63,13 +63,14 @@ struct dws_model {
     dws::DevBuf smp_eps;      // eps[B, Cout, L]
     dws::DevBuf smp_steps;    // float steps[B]
     hipGraphExec_t smp_graph = nullptr;
+    hipStream_t smp_stream = nullptr;  // capture/replay stream (the caller's may be the null stream)
+    hipEvent_t smp_ev_in = nullptr, smp_ev_out = nullptr;
     // key of the captured graph
     int64_t g_B = 0, g_L = 0;
     int g_T = 0;
     const void* g_x = nullptr;
     const void* g_noise = nullptr;
     uint64_t g_seed = 0;
-    hipStream_t g_stream = nullptr;
 
     virtual ~dws_model();
     dws::ParamSpec* add_param(const std::string& name, std::vector<int64_t> shape, int dtype = 0);

