@@ -65,7 +65,7 @@ int dws_model_create(const dws_model_desc* desc, dws_model** out) {
         m = dws::make_wavenet(d);
     } else if (d.kind == DWS_KIND_SASHIMI) {
         m = dws::make_sashimi(d);
-        if (!m) return DWS_ERR_UNSUPPORTED;
+        if (!m) return DWS_ERR_INVALID;  // message set by make_sashimi
     } else {
         return dws::set_error(DWS_ERR_INVALID, "unknown model kind %d (model._name_ must be wavenet|sashimi, "
                                                "`models/__init__.py:6-9`)", d.kind);

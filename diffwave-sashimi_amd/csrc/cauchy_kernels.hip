@@ -19,11 +19,12 @@ __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x)
 template <bool SYM, int IPT>
 __global__ __launch_bounds__(256) void cauchy_fwd_kernel(const float2* __restrict__ v, const float2* __restrict__ z,
                                                          const float2* __restrict__ w, float2* __restrict__ out,
-                                                         int N, int L) {
+                                                         int N, int L, int wmod) {
     __shared__ float4 vw[CAUCHY_MAX_N];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int bw = wmod ? b % wmod : b;  // w broadcast over leading dims of v (s4.py:752-758: v (2,3,H,N), w (H,N))
     for (int n = tid; n < N; n += 256) {
-        const float2 vv = v[(size_t)b * N + n], ww = w[(size_t)b * N + n];
+        const float2 vv = v[(size_t)b * N + n], ww = w[(size_t)bw * N + n];
         vw[n] = make_float4(vv.x, vv.y, ww.x, ww.y);
     }
     float zr[IPT], zi[IPT], ar[IPT], ai[IPT];
@@ -154,7 +155,7 @@ static int check_shapes(const char* fn, const void* a, const void* b, const void
 
 template <bool SYM>
 static int cauchy_fwd(const float* v, const float* z, const float* w, float* out, int64_t B, int64_t N, int64_t L,
-                      hipStream_t s) {
+                      hipStream_t s, int wmod = 0) {
     DWS_TRY(check_shapes(SYM ? "cauchy_mult_sym_fwd" : "cauchy_mult_fwd", v, z, w, out, B, N, L));
     if (B == 0 || L == 0) return DWS_OK;
     ProfileScope ps(SYM ? "cauchy_sym_fwd" : "cauchy_fwd", s);
@@ -163,7 +164,7 @@ static int cauchy_fwd(const float* v, const float* z, const float* w, float* out
     DWS_CHECK(ceil_div(L, 256 * IPT) <= 65535, DWS_ERR_UNSUPPORTED, "L too large for one launch");
     dim3 grid((unsigned)B, (unsigned)ceil_div(L, 256 * IPT));
     hipLaunchKernelGGL((cauchy_fwd_kernel<SYM, IPT>), grid, dim3(256), 0, s, (const float2*)v, (const float2*)z,
-                       (const float2*)w, (float2*)out, (int)N, (int)L);
+                       (const float2*)w, (float2*)out, (int)N, (int)L, wmod);
     DWS_HIP(hipGetLastError());
     return DWS_OK;
 }
@@ -182,6 +183,12 @@ static int cauchy_bwd(const float* v, const float* z, const float* w, const floa
                        (const float2*)w, (const float2*)dout, (float2*)dv, (float2*)dw, (int)N, (int)L);
     DWS_HIP(hipGetLastError());
     return DWS_OK;
+}
+
+// internal: symmetric forward with w[B % wmod] (no materialised broadcast of w)
+int launch_cauchy_sym_fwd_bcast(const float* v, const float* z, const float* w, float* out, int64_t B, int64_t N,
+                                int64_t L, int wmod, hipStream_t s) {
+    return cauchy_fwd<true>(v, z, w, out, B, N, L, s, wmod);
 }
 
 }  // namespace dws

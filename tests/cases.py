@@ -38,6 +38,40 @@ WAVENET_COND_CASES = {
 }
 
 
+SS_BASE = dict(_name_="sashimi", unconditional=True, in_channels=1, out_channels=1,
+               diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512,
+               diffusion_step_embed_dim_out=512, unet=True, pool=[4, 4], expand=2, ff=2)
+
+
+def ss_cfg(**kw):
+    c = dict(SS_BASE)
+    c.update(kw)
+    return c
+
+
+# name -> (cfg, B, weight_seed, input_seed, store_weights); input length is cfg["L"]
+SASHIMI_CASES = {
+    # generic (non-MFMA) kernels; small embedding MLP so the stored state_dict stays small
+    "ss_tiny": (ss_cfg(d_model=8, n_layers=2, L=1024, diffusion_step_embed_dim_mid=64), 2, 111, 112, True),
+    # snet variant: no blocks on the down path, skip-add only after UpPool (`sashimi.py:243,306`)
+    "ss_snet": (ss_cfg(d_model=8, n_layers=2, L=256, unet=False, diffusion_step_embed_dim_mid=64), 2, 121, 122, True),
+    # one pooling stage, pool 2, expand 3, ff 1: the non-default knobs
+    "ss_knobs": (ss_cfg(d_model=6, n_layers=1, L=250, pool=[2], expand=3, ff=1, diffusion_step_embed_dim_mid=64), 3, 131, 132, True),
+    # channel counts of BASELINE config 3 (H = 64/128/256), shortened
+    "ss_d64_short": (ss_cfg(d_model=64, n_layers=2, L=1024), 2, 141, 142, False),
+    # BASELINE config 3 architecture: unet_d64_n6 pool[4,4] ff2, L=16000, at B=1
+    "ss_unet_d64": (ss_cfg(d_model=64, n_layers=6, L=16000), 1, 151, 152, False),
+}
+
+# conditional SaShiMi: name -> (cfg, B, Tmel, weight_seed, input_seed, store)
+SASHIMI_COND_CASES = {
+    "ss_cond_tiny": (ss_cfg(unconditional=False, d_model=8, n_layers=1, L=512, mel_upsample=[16, 16],
+                            diffusion_step_embed_dim_mid=64), 2, 2, 161, 162, True),
+    # BASELINE config 4 channel counts (unet_d32), shortened: L=1024 = 4 mel frames * hop 256
+    "ss_cond_d32": (ss_cfg(unconditional=False, d_model=32, n_layers=2, L=1024, mel_upsample=[16, 16]), 2, 4, 171, 172, False),
+}
+
+
 def randomize_zero_conv(model, seed):
     """``final_conv[2]`` is zero-initialised in the reference (`wavenet.py:35-36`)
     so an untrained net outputs 0; re-initialise it N(0, 0.1^2) or parity is

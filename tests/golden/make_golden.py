@@ -182,7 +182,85 @@ def g_cauchy():
     save("cauchy", **out)
 
 
-GROUPS = {"cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
+def _ss_run(cfg, B, wseed, iseed, mel=None):
+    ours = cases.build_ours(cfg, wseed)
+    sd0 = {k: v.detach().clone() for k, v in ours.state_dict().items()}   # raw: L buffers 0, C not yet C~
+    net = ref_model(cfg, sd0)
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], cfg["in_channels"], iseed)
+    taps = {}
+    h = net.final_conv[1].register_forward_hook(lambda m, i, o: taps.__setitem__("pre_final", o.detach()))
+    with torch.no_grad():
+        eps = net((audio, steps), mel_spec=mel)      # first forward: _setup_C mutates C / L (s4.py:686-687)
+    h.remove()
+    sd1 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    return net, sd0, sd1, audio, steps, eps, taps["pre_final"]
+
+
+def g_sashimi():
+    out = {"symmetric_cauchy": np.array(1)}
+    for name, (cfg, B, wseed, iseed, store) in cases.SASHIMI_CASES.items():
+        net, sd0, sd1, audio, steps, eps, pre = _ss_run(cfg, B, wseed, iseed)
+        out[f"{name}/eps"] = eps
+        for k, v in cases.summarize(pre, stride=64).items():
+            out[f"{name}/pre_final/{k}"] = v
+        if store:
+            out.update(sd_arrays(sd0, f"{name}/sd0/"))
+            # after the warm-up forward only C and L differ
+            for k in sd1:
+                if k.endswith("kernel.kernel.C") or k.endswith("kernel.kernel.L"):
+                    out[f"{name}/sd1/{k}"] = sd1[k]
+            out[f"{name}/audio"], out[f"{name}/steps"] = audio, steps
+            with torch.no_grad():
+                # S4 convolution kernel of the first block and of the centre block, and a block output
+                first = "d_layers.0" if cfg["unet"] else "c_layers.0"
+                for pre_, mod in ((first, dict(net.named_modules())[first]), ("c_layers.0", net.c_layers[0])):
+                    Ls = mod.layer.L
+                    k, _ = mod.layer.kernel(L=Ls, rate=1.0)
+                    out[f"{name}/k/{pre_}"] = k
+        print(name, "eps absmax", float(eps.abs().max()))
+    save("sashimi", **out)
+
+
+def g_sashimi_cond():
+    out = {"symmetric_cauchy": np.array(1)}
+    for name, (cfg, B, Tmel, wseed, iseed, store) in cases.SASHIMI_COND_CASES.items():
+        for Bm in (1, B):
+            mel = cases.mel_inputs(Bm, Tmel, iseed)
+            net, sd0, sd1, audio, steps, eps, pre = _ss_run(cfg, B, wseed, iseed, mel=mel)
+            out[f"{name}/eps_bm{Bm}"] = eps
+            if store:
+                out[f"{name}/mel_bm{Bm}"] = mel
+        with torch.no_grad():
+            out[f"{name}/eps_nomel"] = net((audio, steps))
+        if store:
+            out.update(sd_arrays(sd0, f"{name}/sd0/"))
+            out[f"{name}/audio"], out[f"{name}/steps"] = audio, steps
+    save("sashimi_cond", **out)
+
+
+def g_s4_parts():
+    """Function-level vectors: TransposedLN, DownPool/UpPool index maps, FF, setup_C."""
+    models, _, _, s4 = _refimport.load()
+    from models import sashimi as rs
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    x = torch.randn(2, 6, 40, generator=g) * 3 + 1.5
+    ln = rs.TransposedLN(6)
+    with torch.no_grad():
+        ln.m.fill_(0.3); ln.s.fill_(1.7)
+        out["ln/x"], out["ln/y"], out["ln/ms"] = x, ln(x), np.array([0.3, 1.7], dtype=np.float32)
+        # pure index maps (integer exact): feed an arange through einops' rearrange
+        ar = torch.arange(2 * 3 * 20, dtype=torch.float32).reshape(2, 3, 20)
+        from einops import rearrange
+        out["pool/x"] = ar
+        out["pool/down_p4"] = rearrange(ar, '... h (l s) -> ... (h s) l', s=4)
+        ar2 = torch.arange(2 * 12 * 5, dtype=torch.float32).reshape(2, 12, 5)
+        out["pool/y"] = ar2
+        out["pool/up_p4"] = rearrange(ar2, '... (h s) l -> ... h (l s)', s=4)
+    save("s4_parts", **out)
+
+
+GROUPS = {"sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
           "wavenet_cond": g_wavenet_cond, "sampler": g_sampler}
 
 if __name__ == "__main__":

@@ -1,0 +1,122 @@
+"""GPU parity: the HIP SaShiMi / S4 path (through the C ABI) against the reference's
+golden outputs and against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sashimi as osa
+from tests import cases
+from tests.conftest import REL_TOL, load_golden, rel_err
+from tests.test_sashimi_oracle import _sd0, _sd1
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(net, gpu, audio, steps, mel=None):
+    with torch.no_grad():
+        out = net((audio.to(gpu), steps.to(gpu)), mel_spec=None if mel is None else mel.to(gpu))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("name", list(cases.SASHIMI_CASES))
+def test_sashimi_forward_matches_reference(gpu, name):
+    cfg, B, wseed, iseed, store = cases.SASHIMI_CASES[name]
+    g = load_golden("sashimi")
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    if store:  # run on the reference's own post-warm-up parameters (C~, L = l_max)
+        net.load_state_dict({k: v.to(gpu) for k, v in _sd1(g, name).items()})
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    eps = _run(net, gpu, audio, steps)
+    assert eps.shape == (B, 1, cfg["L"])
+    err = rel_err(eps, g[f"{name}/eps"])
+    assert err < REL_TOL, f"{name}: rel err {err:.3e} vs reference"
+    pre = net.read_tap("pre_final", (B, cfg["d_model"], cfg["L"]))
+    dg = cases.summarize(pre.cpu(), stride=64)
+    assert rel_err(dg["strided"], g[f"{name}/pre_final/strided"]) < REL_TOL
+    assert torch.equal(eps, _run(net, gpu, audio, steps))            # deterministic
+    assert torch.equal(eps, _run(net, gpu, audio, steps.long()))     # int64 steps (train.py:218)
+    print(f"{name}: rel err vs reference {err:.3e}")
+
+
+@pytest.mark.parametrize("name", ["ss_tiny", "ss_knobs"])
+def test_s4_kernel_spectrum_matches_reference(gpu, name):
+    """K_f built at weight-load time (Cauchy -> Woodbury -> irfft -> two-sided -> rfft) vs the
+    spectrum of the reference's kernel k (s4.py:1391-1403)."""
+    g = load_golden("sashimi")
+    cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES[name]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    net.load_state_dict({k: v.to(gpu) for k, v in _sd1(g, name).items()})
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    _run(net, gpu, audio, steps)
+    for key in g.files:
+        if not key.startswith(f"{name}/k/"):
+            continue
+        prefix = key.split("/")[-1]
+        k = torch.from_numpy(g[key])                       # (2, H, L)
+        L = k.shape[-1]
+        kk = F.pad(k[0:1], (0, L)) + F.pad(k[1:2].flip(-1), (L, 0))
+        ref = torch.fft.rfft(kk.double(), n=2 * L)[0]      # (H, L+1)
+        got = net.read_tap("kf:" + prefix, (k.shape[1], L + 1, 2)).cpu()
+        assert rel_err(got, torch.view_as_real(ref)) < 1e-4, prefix
+
+
+@pytest.mark.parametrize("name", list(cases.SASHIMI_COND_CASES))
+def test_sashimi_conditional_matches_reference(gpu, name):
+    cfg, B, Tmel, wseed, iseed, store = cases.SASHIMI_COND_CASES[name]
+    g = load_golden("sashimi_cond")
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    for Bm in (1, B):
+        mel = cases.mel_inputs(Bm, Tmel, iseed)
+        err = rel_err(_run(net, gpu, audio, steps, mel), g[f"{name}/eps_bm{Bm}"])
+        assert err < REL_TOL, f"{name} Bm={Bm}: {err:.3e}"
+    assert rel_err(_run(net, gpu, audio, steps), g[f"{name}/eps_nomel"]) < REL_TOL
+
+
+def test_sashimi_matches_oracle_fresh_weights_and_first_forward_mutation(gpu):
+    cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES["ss_knobs"]
+    net = cases.build_ours(cfg, wseed + 9).to(gpu)
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    audio, steps = cases.wavenet_inputs(4, cfg["L"], 1, iseed + 1)
+    with torch.no_grad():
+        ref = osa.sashimi_forward(sd0, cfg, audio, steps)
+    got = _run(net, gpu, audio, steps)
+    assert rel_err(got, ref) < REL_TOL
+    sd1 = net.state_dict()
+    k = "c_layers.0.layer.kernel.kernel"
+    assert int(sd0[k + ".L"]) == 0 and int(sd1[k + ".L"]) == cfg["L"] // 2   # pool [2]
+    assert not torch.equal(sd0[k + ".C"], sd1[k + ".C"].cpu())
+
+
+def test_sashimi_sampler_matches_oracle(gpu):
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    from oracle import diffusion as odiff
+    cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES["ss_tiny"]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    T = 5
+    dh = calc_diffusion_hyperparams(T, 1e-4, 0.05)
+    g = torch.Generator().manual_seed(3)
+    x_T = torch.randn(B, 1, cfg["L"], generator=g)
+    noise = torch.randn(T, B, 1, cfg["L"], generator=g)
+    x_graph = sampling(net, (B, 1, cfg["L"]), dh, x_T=x_T, noise=noise, use_graph=True)
+    x_eager = sampling(net, (B, 1, cfg["L"]), dh, x_T=x_T, noise=noise, use_graph=False)
+    assert torch.equal(x_graph, x_eager)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = odiff.sampling(osa.SashimiOracle(sd, cfg), (B, 1, cfg["L"]), odiff.calc_diffusion_hyperparams(T, 1e-4, 0.05),
+                         x_T=x_T, noise=noise)
+    assert rel_err(x_graph, ref) < REL_TOL
+
+
+def test_sashimi_errors_are_loud(gpu):
+    cfg = cases.SASHIMI_CASES["ss_tiny"][0]
+    net = cases.build_ours(cfg, 1).to(gpu)
+    with pytest.raises(NotImplementedError):   # variable-length input is not built
+        net((torch.zeros(1, 1, 512, device=gpu), torch.zeros(1, 1, device=gpu)))
+    from diffwave_sashimi_amd.models import construct_model
+    with pytest.raises(ValueError):
+        construct_model(dict(cfg, diffusion_step_embed_dim_out=64))
+    with pytest.raises(RuntimeError):
+        construct_model(dict(cfg, L=1000, pool=[3, 7])).to(gpu)((torch.zeros(1, 1, 1000, device=gpu),
+                                                                 torch.zeros(1, 1, device=gpu)))
