@@ -44,6 +44,20 @@ CONFIGS = {
                    diffusion_step_embed_dim_out=512, res_channels=128, skip_channels=256,
                    num_res_layers=30, dilation_cycle=10),
         diffusion=dict(T=200, beta_0=1e-4, beta_T=0.02), B=16, L=16000),
+    # BASELINE.json configs[2]
+    "unet_d64_n6_T200": dict(
+        model=dict(_name_="sashimi", unconditional=True, in_channels=1, out_channels=1,
+                   diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512,
+                   diffusion_step_embed_dim_out=512, unet=True, d_model=64, n_layers=6, pool=[4, 4],
+                   expand=2, ff=2, L=16000),
+        diffusion=dict(T=200, beta_0=1e-4, beta_T=0.02), B=16, L=16000),
+    # BASELINE.json configs[3] (mel conditioner installed once per utterance)
+    "unet_d32_n6_T50_cond": dict(
+        model=dict(_name_="sashimi", unconditional=False, in_channels=1, out_channels=1,
+                   diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512,
+                   diffusion_step_embed_dim_out=512, unet=True, d_model=32, n_layers=6, pool=[4, 4],
+                   expand=2, ff=2, L=16000, mel_upsample=[16, 16]),
+        diffusion=dict(T=50, beta_0=1e-4, beta_T=0.05), B=32, L=16000, Tmel=63),
 }
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
@@ -78,6 +92,7 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     per call, no hoisting) timed on this box's host cores at B=1; bounded sample.
     MKL-DNN convolutions of this size get *slower* with hundreds of threads, so a few
     thread counts are probed first and the best one is used (`cores` = threads used)."""
+    from oracle import sashimi as osa
     from oracle import wavenet as own
     from diffwave_sashimi_amd.models import construct_model
     ncpu = os.cpu_count() or 1
@@ -87,11 +102,15 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     L, T = cfg["L"], cfg["diffusion"]["T"]
     audio = torch.randn(1, 1, L)
     steps = torch.full((1, 1), float(T - 1))
+    mel = None
+    if "Tmel" in cfg:
+        mel = torch.rand(1, 80, cfg["Tmel"]) * 13.5 - 11.5
+    fwd = own.wavenet_forward if cfg["model"]["_name_"] == "wavenet" else osa.sashimi_forward
 
     def one():
         t0 = time.perf_counter()
         with torch.no_grad():
-            own.wavenet_forward(sd, cfg["model"], audio, steps)
+            fwd(sd, cfg["model"], audio, steps, mel_spec=mel)
         return time.perf_counter() - t0
 
     t_begin = time.perf_counter()
@@ -160,6 +179,10 @@ def main():
     ptabs = [t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) for t in tabs]
     net._sync_params()
     net._prepare(B, L)
+    if "Tmel" in cfg:  # vocoder config: mel [B, 80, 63] ~ U(-11.5, 2), installed once (hoisted conditioner)
+        gm = torch.Generator().manual_seed(4321 + rank)
+        mel = (torch.rand(B, 80, cfg["Tmel"], generator=gm) * 13.5 - 11.5).to(dev)
+        net._set_condition(mel)
     x = torch.randn(B, 1, L, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     stream = _lib.current_stream()
     seed = 1234 + rank
@@ -200,7 +223,7 @@ def main():
                    "sampler": "hipGraph replay, on-device Philox noise"},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and cfg["model"]["_name_"] == "wavenet":
         # dominant kernel: the fused residual layer.  Timed with HIP events on its own
         # launch stream inside the engine (eager launches, outside any capture).
         flops, bytes_ = layer_algorithmic_work(cfg)
