@@ -1,0 +1,41 @@
+// Launch interface of sashimi_mfma.hip (internal to libdws.so).
+#pragma once
+#include "dws_common.h"
+
+namespace dws {
+
+struct S4TailArgs {
+    const float* g;       // [B,H,L] GELU(conv + D u)
+    const float* x;       // [B,H,L] block input (residual)
+    const float* Ao;      // packed output_linear weight [2H x H]
+    const float* bo;      // [2H]
+    const float* mel;     // nullable conditioner term [Bm,H,L]
+    int mel_bstride;
+    const float* ln_m;    // norm2.m, norm2.s (device scalars)
+    const float* ln_s;
+    const float* A1;      // packed ff[0] weight [ff*H x H]
+    const float* b1;      // [ff*H]
+    const float* rs1;     // [ff*H] row sums of the folded ff[0] weight
+    const float* A2;      // packed ff[2] weight [H x ff*H]
+    const float* b2;      // [H]
+    const float* addend;  // nullable U-Net skip [B,H,L]
+    float* out;           // [B,H,L]
+    int B, L;
+};
+
+struct PwMfmaArgs {
+    const float* in;
+    const float* A;       // packed weight [M x K]
+    const float* bias;    // [M]
+    const float* addend;  // UpPool only, nullable
+    float* out;
+    int B, K, M, L, p;    // L = GEMM columns per batch element (DownPool: output length; UpPool: input length)
+};
+
+bool s4_tail_mfma_supported(int H, int ff);
+int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s);
+int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s);
+bool pw_mfma_supported(int mode, int K, int M, int p);
+int launch_pw_mfma(int mode, const PwMfmaArgs& a, hipStream_t s);
+
+}  // namespace dws

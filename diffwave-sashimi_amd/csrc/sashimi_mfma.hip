@@ -1,0 +1,427 @@
+// MFMA (exact-f32 v_mfma_f32_32x32x2_f32) kernels of the SaShiMi per-position path.
+//
+// s4_tail_mfma_kernel fuses everything of DiffWaveBlock.forward after the S4
+// convolution (`sashimi.py:177-184`, `s4.py:1435`) for a tile of P positions:
+//   o  = Wo g + bo                      (H -> 2H)          GEMM-o
+//   x1 = x + o[:H] * sigmoid(o[H:]) (+ mel)                GLU + residual   -> LDS
+//   LN2 statistics down each column; tile centred in place (x1 - mean)
+//   u  = GELU(W1 LN2(x1) + b1)          (H -> ff*H)        GEMM-1, LN folded into the epilogue:
+//        W1 (a (xc + m_p)) = a (W1 xc) + a m_p rowsum(W1)
+//   f  = W2 u + b2                      (ff*H -> H)        GEMM-2, accumulated per H-row chunk of u
+//   out = x1 + f (+ addend)
+// so g, x are read once and out written once (3 tensor passes instead of ~15).
+//
+// pw_mfma_kernel: the pooling 1x1 convs (`sashimi.py:23-58`) with the index
+// maps folded into the B-operand gather (DownPool) / the float4 scatter (UpPool).
+#include "sashimi.h"
+#include "sashimi_mfma.h"
+
+namespace dws {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float gelu_erf_m(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_m(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float f4_get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+template <int H, int WM, int WN, int NT, int FFE>
+struct TailCfg {
+    static constexpr int P = 32 * WN * NT;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int MT = H / 32 / WM;            // 32-row tiles per wave for an H-row GEMM
+    static constexpr int PARTS = THREADS / P;         // row partitions of the LN column reduction
+    static constexpr int LDS_FLOATS = 2 * H * P + 2 * P + 2 * PARTS * P;
+    static_assert(H % (32 * WM) == 0, "H split");
+    static_assert(THREADS % P == 0 && H % PARTS == 0, "LN split");
+};
+
+// One H-row x K GEMM slab on the wave's MT tiles: acc[m][n] += A[tile rows] . Bt[K x P]
+// A packed as pack[mt][kg][lane][4]; Bt in LDS row-major [K][P].
+template <int MT, int NT, int P>
+__device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* __restrict__ A, int nkg_total,
+                                          int kg0, int nkg, const int (&mt)[MT], const float* __restrict__ bt, int wn,
+                                          int lane) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    float4 cur[MT], nxt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) cur[m] = A[((size_t)mt[m] * nkg_total + kg0) * 64 + lane];
+    for (int kg = 0; kg < nkg; ++kg) {
+        const int kgn = (kg + 1 < nkg) ? kg + 1 : kg;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) nxt[m] = A[((size_t)mt[m] * nkg_total + kg0 + kgn) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int krow = kg * 8 + j * 2 + lhi;
+            float bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = bt[krow * P + (wn * NT + n) * 32 + l31];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(cur[m], j), bf[n], acc[m][n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) cur[m] = nxt[m];
+    }
+}
+
+template <int H, int WM, int WN, int NT, int FFE>
+__global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a) {
+    using T = TailCfg<H, WM, WN, NT, FFE>;
+    constexpr int P = T::P, MT = T::MT, THREADS = T::THREADS, PARTS = T::PARTS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tile = lds;                 // [H][P]: g, then x1 centred
+    float* ut = lds + H * P;           // [H][P]: one H-row chunk of u
+    float* colmean = ut + H * P;       // [P]
+    float* colalpha = colmean + P;     // [P]
+    float* red = colalpha + P;         // [2][PARTS][P]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int L = a.L;
+    const int ntl = (L + P - 1) / P;
+    const int tix = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = tix / ntl, l0 = (tix % ntl) * P;
+
+    // ---- stage g tile
+    const float* __restrict__ gb = a.g + (size_t)b * H * L;
+    for (int i = tid; i < H * P; i += THREADS) {
+        const int row = i / P, col = i % P;
+        const int pos = l0 + col;
+        const float v = gb[(size_t)row * L + (pos < L ? pos : 0)];
+        tile[i] = v * (pos < L ? 1.f : 0.f);
+    }
+    __syncthreads();
+
+    // ---- GEMM-o: rows [tile m] pair with rows [H/32 + tile m] (GLU halves)
+    int mt_a[MT], mt_b[MT], mt_h[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        mt_h[m] = wm * MT + m;
+        mt_a[m] = mt_h[m];
+        mt_b[m] = H / 32 + mt_h[m];
+    }
+    const float4* Ao = reinterpret_cast<const float4*>(a.Ao);
+    {
+        f32x16 acc_a[MT][NT], acc_b[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc_a[m][n][r] = 0.f; acc_b[m][n][r] = 0.f; }
+        gemm_slab<MT, NT, P>(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane);
+        gemm_slab<MT, NT, P>(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane);
+        __syncthreads();  // every wave is done reading g
+        // x1 = x + GLU(o) (+ mel) -> tile
+        const float* __restrict__ xb = a.x + (size_t)b * H * L;
+        const float* __restrict__ melb = a.mel ? a.mel + (size_t)(a.mel_bstride ? b : 0) * H * L : nullptr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = (wn * NT + n) * 32 + l31;
+                const int pos = l0 + col;
+                const int posc = pos < L ? pos : 0;
+                float xr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    xr[r] = xb[(size_t)h * L + posc];
+                    if (melb) xr[r] += melb[(size_t)h * L + posc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float oa = acc_a[m][n][r] + a.bo[h], ob = acc_b[m][n][r] + a.bo[H + h];
+                    tile[h * P + col] = xr[r] + oa * sigmoid_m(ob);
+                }
+            }
+    }
+    __syncthreads();
+
+    // ---- LN2 statistics per column (population std, no eps; `sashimi.py:17-20`), centre in place
+    {
+        const int col = tid % P, part = tid / P;
+        constexpr int RP = H / PARTS;
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < RP; ++r) s += tile[(part * RP + r) * P + col];
+        red[part * P + col] = s;
+        __syncthreads();
+        float mean = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) mean += red[q * P + col];
+        mean *= (1.f / (float)H);
+        float v = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < RP; ++r) {
+            const float d = tile[(part * RP + r) * P + col] - mean;
+            tile[(part * RP + r) * P + col] = d;
+            v = fmaf(d, d, v);
+        }
+        red[(PARTS + part) * P + col] = v;
+        __syncthreads();
+        if (part == 0) {
+            float var = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) var += red[(PARTS + q) * P + col];
+            colmean[col] = mean;
+            colalpha[col] = a.ln_s[0] / sqrtf(var * (1.f / (float)H));
+        }
+        __syncthreads();
+    }
+
+    // ---- FF: per H-row chunk q of u: GEMM-1 chunk -> GELU -> LDS -> GEMM-2 partial
+    const float4* A1 = reinterpret_cast<const float4*>(a.A1);
+    const float4* A2 = reinterpret_cast<const float4*>(a.A2);
+    const float lnm = a.ln_m[0];
+    f32x16 acc2[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
+    for (int q = 0; q < FFE; ++q) {
+        f32x16 acc1[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[m][n][r] = 0.f;
+        int mt_q[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) mt_q[m] = q * (H / 32) + mt_h[m];
+        gemm_slab<MT, NT, P>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
+        if (q > 0) __syncthreads();  // previous chunk of u fully consumed by GEMM-2
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = (wn * NT + n) * 32 + l31;
+                const float al = colalpha[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int hr = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;  // row inside the chunk
+                    const int row = q * H + hr;
+                    const float pre = fmaf(al, acc1[m][n][r], fmaf(al * lnm, a.rs1[row], a.b1[row]));
+                    ut[hr * P + col] = gelu_erf_m(pre);
+                }
+            }
+        __syncthreads();
+        gemm_slab<MT, NT, P>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
+    }
+
+    // ---- out = x1 + f (+ addend);  x1 = centred tile + mean
+    float* __restrict__ ob = a.out + (size_t)b * H * L;
+    const float* __restrict__ addb = a.addend ? a.addend + (size_t)b * H * L : nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = (wn * NT + n) * 32 + l31;
+            const int pos = l0 + col;
+            const bool ok = pos < L;
+            const int posc = ok ? pos : 0;
+            const float mean = colmean[col];
+            float ad[16];
+            if (addb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    ad[r] = addb[(size_t)h * L + posc];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ad[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const float v = (tile[h * P + col] + mean) + (acc2[m][n][r] + a.b2[h]) + ad[r];
+                if (ok) ob[(size_t)h * L + pos] = v;
+            }
+        }
+}
+
+template <int H, int WM, int WN, int NT>
+static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
+    using T = TailCfg<H, WM, WN, NT, 2>;
+    ProfileScope ps("s4_tail_mfma", s);
+    const int ntl = ceil_div(a.L, T::P);
+    const size_t lds = (size_t)T::LDS_FLOATS * 4;
+    auto kern = s4_tail_mfma_kernel<H, WM, WN, NT, 2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+    return DWS_OK;
+}
+
+bool s4_tail_mfma_supported(int H, int ff) { return ff == 2 && (H == 32 || H == 64 || H == 128 || H == 256); }
+
+int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
+    switch (H) {
+        case 32: return launch_tail_t<32, 1, 4, 1>(a, s);
+        case 64: return launch_tail_t<64, 2, 2, 2>(a, s);
+        case 128: return launch_tail_t<128, 4, 1, 2>(a, s);
+        case 256: return launch_tail_t<256, 8, 1, 2>(a, s);
+    }
+    return set_error(DWS_ERR_UNSUPPORTED, "s4_tail_mfma: H=%d not instantiated", H);
+}
+
+// rs[o] = sum_k W[o][k]
+__global__ void row_sum_kernel(const float* __restrict__ W, float* __restrict__ rs, int K) {
+    const int o = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += W[(size_t)o * K + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) rs[o] = s;
+}
+
+int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s) {
+    hipLaunchKernelGGL(row_sum_kernel, dim3(O), dim3(64), 0, s, W, rs, K);
+    return DWS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Pooling 1x1 convs on MFMA.  M = 128*MT output rows, 4 waves along M, P = 64.
+//   MODE 0 (DownPool): B operand row k = h*p + j is x[b, h, (l0+col)*p + j]; out[b, o, l]
+//   MODE 1 (UpPool):   B operand row k is x[b, k, l]; out[b, o/p, l*p + o%p] (+ addend), p == 4:
+//                      a lane's 4 consecutive accumulator rows are the 4 j of one channel -> one float4 store
+// ---------------------------------------------------------------------------
+template <int MT, int MODE>
+__global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
+    constexpr int P = 64, NT = 2, KC = 64;
+    __shared__ __attribute__((aligned(16))) float lds[2 * KC * P];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int L = a.L, K = a.K, p = a.p;   // L = number of GEMM columns per batch element
+    const int ntl = (L + P - 1) / P;
+    const int tix = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = tix / ntl, l0 = (tix % ntl) * P;
+    const int nchunk = K / KC;
+    const float* __restrict__ xb = a.in + (size_t)b * K * L;  // DownPool: [K/p][L*p] has the same element count
+
+    float stg[KC * P / 256];
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < KC * P / 256; ++i) {
+            const int e = tid + 256 * i;
+            if (MODE == 0) {
+                // element e of the contiguous run of (KC/p) channels x (P*p) samples
+                const int hh = e / (P * p), w = e % (P * p);
+                const int h = c * (KC / p) + hh;
+                const size_t Lin = (size_t)L * p;
+                const size_t src = (size_t)l0 * p + w;
+                const bool ok = src < Lin;
+                stg[i] = xb[(size_t)h * Lin + (ok ? src : 0)] * (ok ? 1.f : 0.f);
+            } else {
+                const int row = e / P, col = e % P;
+                const int pos = l0 + col;
+                const bool ok = pos < L;
+                stg[i] = xb[(size_t)(c * KC + row) * L + (ok ? pos : 0)] * (ok ? 1.f : 0.f);
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float* d = lds + buf * KC * P;
+#pragma unroll
+        for (int i = 0; i < KC * P / 256; ++i) {
+            const int e = tid + 256 * i;
+            if (MODE == 0) {
+                const int hh = e / (P * p), w = e % (P * p);
+                d[(hh * p + (w % p)) * P + (w / p)] = stg[i];
+            } else {
+                d[e] = stg[i];
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    int mt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mt[m] = wave * MT + m;
+    const float4* A = reinterpret_cast<const float4*>(a.A);
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) stage_load(c + 1);
+        gemm_slab<MT, NT, P>(acc, A, K / 8, c * (KC / 8), KC / 8, mt, lds + (c & 1) * KC * P, 0, lane);
+        if (c + 1 < nchunk) stage_store((c + 1) & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int pos = l0 + n * 32 + l31;
+            const bool ok = pos < L;
+            if (MODE == 0) {
+                float* __restrict__ ob = a.out + (size_t)b * a.M * L;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (ok) ob[(size_t)o * L + pos] = acc[m][n][r] + a.bias[o];
+                }
+            } else {
+                const int Ho = a.M / 4;
+                float* __restrict__ ob = a.out + (size_t)b * Ho * L * 4;
+                const float* __restrict__ adb = a.addend ? a.addend + (size_t)b * Ho * L * 4 : nullptr;
+                const int posc = ok ? pos : 0;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int o0 = mt[m] * 32 + 8 * qd + 4 * lhi;   // rows o0..o0+3 = channel o0/4, j = 0..3
+                    const size_t idx = ((size_t)(o0 / 4) * L + posc) * 4;
+                    float4 v = make_float4(acc[m][n][qd * 4 + 0] + a.bias[o0], acc[m][n][qd * 4 + 1] + a.bias[o0 + 1],
+                                           acc[m][n][qd * 4 + 2] + a.bias[o0 + 2], acc[m][n][qd * 4 + 3] + a.bias[o0 + 3]);
+                    if (adb) {
+                        const float4 ad = *reinterpret_cast<const float4*>(adb + idx);
+                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    }
+                    if (ok) *reinterpret_cast<float4*>(ob + idx) = v;
+                }
+            }
+        }
+}
+
+bool pw_mfma_supported(int mode, int K, int M, int p) {
+    if (K % 64 != 0 || (M != 128 && M != 256 && M != 512)) return false;
+    if (mode == 0) return p >= 1 && 64 % p == 0;
+    return p == 4;
+}
+
+template <int MODE>
+static int launch_pw_mode(const PwMfmaArgs& a, hipStream_t s) {
+    const int grid = a.B * ceil_div(a.L, 64);
+    if (a.M == 128) hipLaunchKernelGGL((pw_mfma_kernel<1, MODE>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.M == 256) hipLaunchKernelGGL((pw_mfma_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pw_mfma_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a);
+    return DWS_OK;
+}
+
+int launch_pw_mfma(int mode, const PwMfmaArgs& a, hipStream_t s) {
+    ProfileScope ps(mode == 0 ? "pw_mfma_down" : "pw_mfma_up", s);
+    return mode == 0 ? launch_pw_mode<0>(a, s) : launch_pw_mode<1>(a, s);
+}
+
+}  // namespace dws

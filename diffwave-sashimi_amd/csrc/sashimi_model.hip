@@ -10,10 +10,12 @@
 #include <hipfft/hipfft.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "conditioner.h"
 #include "model.h"
 #include "sashimi.h"
+#include "sashimi_mfma.h"
 #include "wavenet.h"
 
 namespace dws {
@@ -57,6 +59,8 @@ struct SLayer {
     int pt_off = 0;       // offset of this block's fc_t rows in the stacked projection
     int stage = 0;        // index into per-(H,L) workspaces
     DevBuf W1, W2, Wp;    // folded ff / pool weights
+    DevBuf Ao, A1, A2, rs1, Ap;  // MFMA-packed copies (+ row sums of W1 for the folded LayerNorm)
+    bool mfma = false;
     DevBuf Kf;            // [H][L+1] complex spectrum of the two-sided kernel
     DevBuf melW0, melW1, melWc, melc;
     DevBuf out;           // activation produced by this layer
@@ -246,6 +250,17 @@ struct SashimiModel : dws_model {
                 DWS_TRY(l->W2.ensure((size_t)FF * H * H * 4));
                 DWS_TRY(fold(l->prefix + ".ff.ff.0.conv", l->W1.f(), FF * H, H, s));
                 DWS_TRY(fold(l->prefix + ".ff.ff.2.conv", l->W2.f(), H, FF * H, s));
+                l->mfma = s4_tail_mfma_supported(H, FF) && !getenv("DWS_SASHIMI_GENERIC");
+                if (l->mfma) {
+                    DWS_TRY(l->Ao.ensure((size_t)2 * H * H * 4));
+                    DWS_TRY(l->A1.ensure((size_t)FF * H * H * 4));
+                    DWS_TRY(l->A2.ensure((size_t)FF * H * H * 4));
+                    DWS_TRY(l->rs1.ensure((size_t)FF * H * 4));
+                    DWS_TRY(launch_pack_a_frag(P(l->prefix + ".layer.output_linear.0.weight"), l->Ao.f(), 2 * H, H, s));
+                    DWS_TRY(launch_pack_a_frag(l->W1.f(), l->A1.f(), FF * H, H, s));
+                    DWS_TRY(launch_pack_a_frag(l->W2.f(), l->A2.f(), H, FF * H, s));
+                    DWS_TRY(launch_row_sum(l->W1.f(), l->rs1.f(), FF * H, H, s));
+                }
                 DWS_TRY(build_kernel(l, s));
                 if (cond) {
                     for (int i = 0; i < 2; ++i) {
@@ -262,6 +277,11 @@ struct SashimiModel : dws_model {
                 const int K = (l->kind == L_DOWN) ? l->H * l->p : l->H;
                 DWS_TRY(l->Wp.ensure((size_t)O * K * 4));
                 DWS_TRY(fold(l->prefix + ".linear.conv", l->Wp.f(), O, K, s));
+                l->mfma = pw_mfma_supported(l->kind == L_DOWN ? 0 : 1, K, O, l->p) && !getenv("DWS_SASHIMI_GENERIC");
+                if (l->mfma) {
+                    DWS_TRY(l->Ap.ensure((size_t)O * K * 4));
+                    DWS_TRY(launch_pack_a_frag(l->Wp.f(), l->Ap.f(), O, K, s));
+                }
             }
         }
         DWS_TRY(Wf.ensure((size_t)D * D * 4));
@@ -372,6 +392,16 @@ struct SashimiModel : dws_model {
             DWS_FFT(hipfftExecC2R(plan, (hipfftComplex*)st->Uf.p, (hipfftReal*)st->Y.p));
         }
         DWS_TRY(launch_s4_post(st->Y.f(), st->U.f(), P(p + ".layer.D"), st->g.f(), nB, H, Ls, s));
+        if (l->mfma) {
+            S4TailArgs t{};
+            t.g = st->g.f(); t.x = x; t.Ao = l->Ao.f(); t.bo = P(p + ".layer.output_linear.0.bias");
+            t.mel = melBm ? l->melc.f() : nullptr; t.mel_bstride = melBm > 1 ? 1 : 0;
+            t.ln_m = P(p + ".norm2.m"); t.ln_s = P(p + ".norm2.s");
+            t.A1 = l->A1.f(); t.b1 = P(p + ".ff.ff.0.conv.bias"); t.rs1 = l->rs1.f();
+            t.A2 = l->A2.f(); t.b2 = P(p + ".ff.ff.2.conv.bias");
+            t.addend = addend; t.out = l->out.f(); t.B = nB; t.L = Ls;
+            return launch_s4_tail_mfma(H, t, s);
+        }
         DWS_TRY(launch_pw_glu_res(st->g.f(), P(p + ".layer.output_linear.0.weight"), P(p + ".layer.output_linear.0.bias"),
                                   x, melBm ? l->melc.f() : nullptr, melBm > 1 ? 1 : 0, st->x1.f(), nB, H, Ls, s));
         DWS_TRY(launch_ln(st->x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, st->n2.f(), nB, H, Ls, (size_t)Ls, s));
@@ -383,6 +413,14 @@ struct SashimiModel : dws_model {
 
     int run_layer(SLayer* l, const float* x, const float* addend, hipStream_t s) {
         if (l->kind == L_BLOCK) return run_block(l, x, addend, s);
+        if (l->mfma) {
+            PwMfmaArgs a{};
+            a.in = x; a.A = l->Ap.f(); a.bias = P(l->prefix + ".linear.conv.bias"); a.out = l->out.f();
+            a.B = (int)B; a.p = l->p;
+            if (l->kind == L_DOWN) { a.K = l->H * l->p; a.M = l->Hout; a.L = l->Lout; a.addend = nullptr; }
+            else { a.K = l->H; a.M = l->Hout * l->p; a.L = l->L; a.addend = addend; }
+            return launch_pw_mfma(l->kind == L_DOWN ? 0 : 1, a, s);
+        }
         if (l->kind == L_DOWN)
             return launch_pw_downpool(x, l->Wp.f(), P(l->prefix + ".linear.conv.bias"), l->out.f(), (int)B, l->H, l->p,
                                       l->Hout, l->Lout, s);
