@@ -151,15 +151,9 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+    from diffwave_sashimi_amd import dist as ddist
+    world, rank, local_rank = ddist.init("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if world == 1:
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -185,7 +179,7 @@ def main():
         net._set_condition(mel)
     x = torch.randn(B, 1, L, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     stream = _lib.current_stream()
-    seed = 1234 + rank
+    seed = ddist.rank_seed(1234, rank)
 
     def run(n_steps):
         """n_steps reverse steps of the T-loop (wrapping to t=T-1 when the loop ends)."""
@@ -195,10 +189,7 @@ def main():
             _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, k, seed, 1, stream))
             done += k
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    barrier = ddist.barrier
 
     run(max(args.warmup, 1))  # >= 1: captures the graph outside the timed region
     barrier()
@@ -206,12 +197,9 @@ def main():
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = ddist.max_over_ranks(elapsed, dev)
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * L / (T * ms_per_step * 1e-3)
+    value = ddist.aggregate_throughput(B * L / T, world, ms_per_step * 1e-3)
 
     result = {
         "metric": "audio samples/sec (generate.py-style reverse-diffusion sampling, T=%d)" % T,
@@ -257,8 +245,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    ddist.shutdown()
 
 
 if __name__ == "__main__":

@@ -139,11 +139,61 @@ __global__ void ln_kernel(const float* __restrict__ x, const float* __restrict__
     }
 }
 
+// Same op, one HBM pass: a block owns 64 positions x all H channels; thread (col, part) keeps
+// its H/4 values of column `col` in registers (H <= 256), partial sums meet in LDS.
+__global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ m_p,
+                                                      const float* __restrict__ s_p, const float* __restrict__ part_t,
+                                                      int pt_bstride, float* __restrict__ out, int H, int L,
+                                                      size_t ostride) {
+    __shared__ float red[2][4][64];
+    const int b = blockIdx.y, col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int l = blockIdx.x * 64 + col;
+    const bool ok = l < L;
+    const float* __restrict__ xb = x + (size_t)b * H * L + (ok ? l : 0);
+    float v[64];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int h = i * 4 + part;
+        v[i] = (h < H) ? xb[(size_t)h * L] : 0.f;
+        sum += v[i];
+    }
+    red[0][part][col] = sum;
+    __syncthreads();
+    const float mean = (red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]) / (float)H;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int h = i * 4 + part;
+        const float d = (h < H) ? v[i] - mean : 0.f;
+        var = fmaf(d, d, var);
+    }
+    red[1][part][col] = var;
+    __syncthreads();
+    var = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+    const float scale = s_p[0] / sqrtf(var / (float)H);
+    const float shift = m_p[0] - mean;
+    float* __restrict__ ob = out + (size_t)b * H * ostride + l;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int h = i * 4 + part;
+        if (h < H && ok) {
+            float y = scale * (v[i] + shift);
+            if (part_t) y += part_t[(size_t)b * pt_bstride + h];
+            ob[(size_t)h * ostride] = y;
+        }
+    }
+}
+
 int launch_ln(const float* x, const float* m_p, const float* s_p, const float* part_t, int pt_bstride, float* out,
               int B, int H, int L, size_t ostride, hipStream_t s) {
     ProfileScope ps("ln_kernel", s);
-    hipLaunchKernelGGL(ln_kernel, dim3(ceil_div(L, 64), B), dim3(64), 0, s, x, m_p, s_p, part_t, pt_bstride, out, H, L,
-                       ostride);
+    if (H <= 256)
+        hipLaunchKernelGGL(ln_tile_kernel, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, m_p, s_p, part_t, pt_bstride,
+                           out, H, L, ostride);
+    else
+        hipLaunchKernelGGL(ln_kernel, dim3(ceil_div(L, 64), B), dim3(64), 0, s, x, m_p, s_p, part_t, pt_bstride, out,
+                           H, L, ostride);
     return DWS_OK;
 }
 
