@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "conditioner.h"
+#include "fftconv.h"
 #include "model.h"
 #include "sashimi.h"
 #include "sashimi_mfma.h"
@@ -61,14 +62,21 @@ struct SLayer {
     DevBuf W1, W2, Wp;    // folded ff / pool weights
     DevBuf Ao, A1, A2, rs1, Ap;  // MFMA-packed copies (+ row sums of W1 for the folded LayerNorm)
     bool mfma = false;
-    DevBuf Kf;            // [H][L+1] complex spectrum of the two-sided kernel
+    DevBuf Kf;            // rocFFT path: [H][L+1] complex spectrum of the two-sided kernel (n = 2L)
+    DevBuf kfa, kfb, kfs; // fused path: pair-ordered spectrum at the power-of-two size (fftconv.h)
+    int log2m = 0;        // > 0: fused LDS FFT convolution is used for this block
     DevBuf melW0, melW1, melWc, melc;
     DevBuf out;           // activation produced by this layer
 };
 
 struct Stage {
     int H, L;
-    DevBuf U, Uf, Y, g, x1, n2, ffu;
+    bool rocfft = false;  // some block of this stage needs the rocFFT path
+    DevBuf U, Uf, Y, g, x1, n2, ffu, y;
+};
+
+struct FftTables {
+    DevBuf tw, twn, twp;
 };
 
 struct SashimiModel : dws_model {
@@ -79,15 +87,36 @@ struct SashimiModel : dws_model {
     std::vector<Stage*> stages;
     int pt_total = 0;
     FftPlans fft;
+    std::map<int, FftTables*> tables;  // by log2(M)
     DevBuf Wi, Wt_all, bt_all, Wf, Af, freq;
     DevBuf x_init, emb, h1, h2, part_t, nfin, scratch_out;
     // commit scratch
-    DevBuf cv, cwdt, cdt, cr, ckf, ck, cK;
+    DevBuf cv, cwdt, cdt, cr, ckf, ck, cK, cKf;
     int64_t melBm = 0;
 
     ~SashimiModel() override {
         for (auto* l : all) delete l;
         for (auto* s : stages) delete s;
+        for (auto& kv : tables) delete kv.second;
+    }
+
+    int get_tables(int log2m, FftTables** out, hipStream_t s) {
+        auto it = tables.find(log2m);
+        if (it == tables.end()) {
+            auto* t = new FftTables();
+            std::vector<float> tw, twn, twp;
+            build_fft_tables(log2m, tw, twn, twp);
+            DWS_TRY(t->tw.ensure(tw.size() * 4));
+            DWS_TRY(t->twn.ensure(twn.size() * 4));
+            DWS_TRY(t->twp.ensure(twp.size() * 4));
+            DWS_HIP(hipMemcpyAsync(t->tw.p, tw.data(), tw.size() * 4, hipMemcpyHostToDevice, s));
+            DWS_HIP(hipMemcpyAsync(t->twn.p, twn.data(), twn.size() * 4, hipMemcpyHostToDevice, s));
+            DWS_HIP(hipMemcpyAsync(t->twp.p, twp.data(), twp.size() * 4, hipMemcpyHostToDevice, s));
+            DWS_HIP(hipStreamSynchronize(s));
+            it = tables.emplace(log2m, t).first;
+        }
+        *out = it->second;
+        return DWS_OK;
     }
 
     void wn(const std::string& p, std::vector<int64_t> vshape) {
@@ -217,8 +246,6 @@ struct SashimiModel : dws_model {
         DWS_TRY(cr.ensure((size_t)6 * H * Lh * 8));
         DWS_TRY(ckf.ensure((size_t)2 * H * Lh * 8));
         DWS_TRY(ck.ensure((size_t)2 * H * L * 4));
-        DWS_TRY(cK.ensure((size_t)H * 2 * L * 4));
-        DWS_TRY(l->Kf.ensure((size_t)H * (L + 1) * 8));
         DWS_TRY(launch_s4_prep(P(k + ".C"), P(k + ".B"), P(k + ".P"), P(k + ".inv_w_real"), P(k + ".w_imag"),
                                P(k + ".log_dt"), cv.f(), cwdt.f(), cdt.f(), H, N, s));
         DWS_TRY(launch_cauchy_sym_fwd_bcast(cv.f(), P("__z." + std::to_string(L)), cwdt.f(), cr.f(), 6 * H, N, Lh, H, s));
@@ -227,10 +254,32 @@ struct SashimiModel : dws_model {
         DWS_TRY(fft.get(1, L, 2 * H, &plan));
         DWS_FFT(hipfftSetStream(plan, s));
         DWS_FFT(hipfftExecC2R(plan, (hipfftComplex*)ckf.p, (hipfftReal*)ck.p));
-        DWS_TRY(launch_s4_twosided(ck.f(), cK.f(), H, L, s));
-        DWS_TRY(fft.get(0, 2 * L, H, &plan));
-        DWS_FFT(hipfftSetStream(plan, s));
-        DWS_FFT(hipfftExecR2C(plan, (hipfftReal*)cK.p, (hipfftComplex*)l->Kf.p));
+        int lg = 0;
+        if (fftconv_supported(L, &lg) && !getenv("DWS_SASHIMI_ROCFFT")) {
+            // fused path: spectrum at the power-of-two size Nf = 2M with the anti-causal half re-placed,
+            // produced by the same LDS FFT the per-step kernel uses, stored in its pair order
+            const int M = 1 << lg, Nf = 2 * M;
+            FftTables* t;
+            DWS_TRY(get_tables(lg, &t, s));
+            DWS_TRY(cK.ensure((size_t)H * Nf * 4));
+            DWS_TRY(cKf.ensure((size_t)H * (M + 1) * 8));
+            DWS_TRY(l->kfa.ensure((size_t)H * (M / 2) * 8));
+            DWS_TRY(l->kfb.ensure((size_t)H * (M / 2) * 8));
+            DWS_TRY(l->kfs.ensure((size_t)H * 3 * 8));
+            DWS_TRY(launch_s4_twosided_pow2(ck.f(), cK.f(), H, L, Nf, s));
+            DWS_TRY(launch_rfft_rows(lg, cK.f(), cKf.f(), t->tw.f(), t->twn.f(), H, s));
+            DWS_TRY(launch_kf_permute(cKf.f(), l->kfa.f(), l->kfb.f(), l->kfs.f(), H, lg, s));
+            l->log2m = lg;
+        } else {
+            DWS_TRY(cK.ensure((size_t)H * 2 * L * 4));
+            DWS_TRY(l->Kf.ensure((size_t)H * (L + 1) * 8));
+            DWS_TRY(launch_s4_twosided(ck.f(), cK.f(), H, L, s));
+            DWS_TRY(fft.get(0, 2 * L, H, &plan));
+            DWS_FFT(hipfftSetStream(plan, s));
+            DWS_FFT(hipfftExecR2C(plan, (hipfftReal*)cK.p, (hipfftComplex*)l->Kf.p));
+            l->log2m = 0;
+            stages[l->stage]->rocfft = true;
+        }
         return DWS_OK;
     }
 
@@ -313,11 +362,17 @@ struct SashimiModel : dws_model {
         B = nB; L = nL;
         for (auto* st : stages) {
             const size_t rows = (size_t)B * st->H, Ls = st->L;
-            const bool fresh = st->U.bytes < rows * 2 * Ls * 4;
-            DWS_TRY(st->U.ensure(rows * 2 * Ls * 4));
-            if (fresh) DWS_HIP(hipMemset(st->U.p, 0, rows * 2 * Ls * 4));  // zero padding of the FFT input rows
-            DWS_TRY(st->Uf.ensure(rows * (Ls + 1) * 8));
-            DWS_TRY(st->Y.ensure(rows * 2 * Ls * 4));
+            int lg = 0;
+            const bool need_rocfft = !fftconv_supported((int)Ls, &lg) || getenv("DWS_SASHIMI_ROCFFT");
+            if (need_rocfft) {
+                const bool fresh = st->U.bytes < rows * 2 * Ls * 4;
+                DWS_TRY(st->U.ensure(rows * 2 * Ls * 4));
+                if (fresh) DWS_HIP(hipMemset(st->U.p, 0, rows * 2 * Ls * 4));  // zero padding of the FFT input rows
+                DWS_TRY(st->Uf.ensure(rows * (Ls + 1) * 8));
+                DWS_TRY(st->Y.ensure(rows * 2 * Ls * 4));
+            } else {
+                DWS_TRY(st->y.ensure(rows * Ls * 4));
+            }
             DWS_TRY(st->g.ensure(rows * Ls * 4));
             DWS_TRY(st->x1.ensure(rows * Ls * 4));
             DWS_TRY(st->n2.ensure(rows * Ls * 4));
@@ -329,6 +384,8 @@ struct SashimiModel : dws_model {
         }
         // FFT plans allocate: create them here, never inside a stream capture
         for (auto* st : stages) {
+            int lg = 0;
+            if (fftconv_supported(st->L, &lg) && !getenv("DWS_SASHIMI_ROCFFT")) continue;
             hipfftHandle plan;
             DWS_TRY(fft.get(0, 2 * st->L, (int)B * st->H, &plan));
             DWS_TRY(fft.get(1, 2 * st->L, (int)B * st->H, &plan));
@@ -375,6 +432,18 @@ struct SashimiModel : dws_model {
         Stage* st = stages[l->stage];
         const int H = l->H, Ls = l->L, nB = (int)B;
         const std::string& p = l->prefix;
+        if (l->log2m > 0) {
+            DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->y.f(), nB, H,
+                              Ls, (size_t)Ls, s));
+            FftTables* t = tables[l->log2m];
+            FftConvArgs fa{};
+            fa.u = st->y.f(); fa.g = st->g.f(); fa.D = P(p + ".layer.D");
+            fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
+            fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
+            fa.B = nB; fa.H = H; fa.L = Ls;
+            DWS_TRY(launch_fftconv(l->log2m, fa, s));
+            return run_tail(l, st, x, addend, s);
+        }
         DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->U.f(), nB, H, Ls,
                           (size_t)2 * Ls, s));
         hipfftHandle plan;
@@ -392,6 +461,13 @@ struct SashimiModel : dws_model {
             DWS_FFT(hipfftExecC2R(plan, (hipfftComplex*)st->Uf.p, (hipfftReal*)st->Y.p));
         }
         DWS_TRY(launch_s4_post(st->Y.f(), st->U.f(), P(p + ".layer.D"), st->g.f(), nB, H, Ls, s));
+        return run_tail(l, st, x, addend, s);
+    }
+
+    // everything of the block after the S4 convolution (sashimi.py:177-184, s4.py:1435)
+    int run_tail(SLayer* l, Stage* st, const float* x, const float* addend, hipStream_t s) {
+        const int H = l->H, Ls = l->L, nB = (int)B;
+        const std::string& p = l->prefix;
         if (l->mfma) {
             S4TailArgs t{};
             t.g = st->g.f(); t.x = x; t.Ao = l->Ao.f(); t.bo = P(p + ".layer.output_linear.0.bias");
@@ -484,13 +560,14 @@ struct SashimiModel : dws_model {
             DWS_TRY(scratch_out.ensure((size_t)B * Cout * L * 4));
             return final_stage(last_x, scratch_out.f(), dst, s);
         }
-        if (t.rfind("kf:", 0) == 0) {  // K_f of the block with this state_dict prefix: [H][L+1] complex
+        if (t.rfind("k:", 0) == 0) {  // S4 kernel of the block with this prefix: L * k, k = [2][H][L] (s4.py:796-805)
             if (dirty) DWS_TRY(commit(s));
             for (auto* l : all)
-                if (l->kind == L_BLOCK && l->prefix == t.substr(3)) {
-                    const size_t n = (size_t)l->H * (l->L + 1) * 2;
+                if (l->kind == L_BLOCK && l->prefix == t.substr(2)) {
+                    const size_t n = (size_t)2 * l->H * l->L;
                     DWS_CHECK((size_t)capacity >= n, DWS_ERR_INVALID, "tap buffer too small");
-                    DWS_HIP(hipMemcpyAsync(dst, l->Kf.p, n * 4, hipMemcpyDeviceToDevice, s));
+                    DWS_TRY(build_kernel(l, s));  // regenerates the (unnormalised) time-domain kernel into scratch
+                    DWS_HIP(hipMemcpyAsync(dst, ck.p, n * 4, hipMemcpyDeviceToDevice, s));
                     return DWS_OK;
                 }
         }
