@@ -14,6 +14,7 @@ struct WnLayerArgs {
     int part_t_bstride;
     const float* A1;       // packed dilated-conv weights (MFMA path)
     const float* A2;       // packed [res; skip] weights   (MFMA path)
+    const float* Abt;      // MFMA path: step-embedding correction fragments of this layer [B][2C/32][64][4]
     const float* Wd;       // folded [2C][C][3]            (generic path)
     const float* Wr;       // folded [C][C]
     const float* Ws;       // folded [S][C]
@@ -46,6 +47,7 @@ int launch_linear_rows(const float* in, const float* W, const float* bias, float
                        int act, hipStream_t s);
 int launch_init_conv(const float* audio, const float* W, const float* bias, float* x, int B, int Cin, int C, int L,
                      hipStream_t s);
+int launch_wn_bias_tap(const float* Wd_all, const float* part_t, float* Abt, int NL, int B, int C, hipStream_t s);
 bool wn_layer_mfma_supported(int C, int S);
 int launch_wn_layer_mfma(int C, int S, const WnLayerArgs& a, hipStream_t s);
 int launch_wn_layer_generic(int C, int S, const WnLayerArgs& a, hipStream_t s);

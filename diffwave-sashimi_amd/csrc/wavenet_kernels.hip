@@ -188,12 +188,26 @@ struct WnTile {
     static constexpr int NCB = C / KC;
     static constexpr int XS_FLOATS = 2 * 3 * KC * P;        // double-buffered x window
     static constexpr int G_FLOATS = C * P;                  // gate tile
-    static constexpr int LDS_FLOATS = XS_FLOATS > G_FLOATS ? XS_FLOATS : G_FLOATS;
+    static constexpr int IND_FLOATS = 8 * P;                // tap-validity indicator rows (extra K rows)
+    static constexpr int LDS_FLOATS = (XS_FLOATS + IND_FLOATS) > G_FLOATS ? (XS_FLOATS + IND_FLOATS) : G_FLOATS;
     static_assert(WN * NT * 32 == P, "N split");
     static_assert(C % (32 * WM) == 0 && S % (32 * WM) == 0 && C % KC == 0, "channel counts");
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// gate nonlinearities of the fused kernel: v_exp_f32 / v_rcp_f32 based (abs. error ~1e-7, far below
+// the 1e-3 parity bound); tanh(x) = 1 - 2/(exp(2x)+1) saturates cleanly for |x| large
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer load (SGPR descriptor + wave-uniform byte offset + per-lane offset): no 64-bit
+// per-lane address registers, which is what lets the A-fragment double buffer stay in registers.
+__device__ __forceinline__ f32x4 buf_load_f4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 
 template <int C, int S>
 __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
@@ -214,35 +228,36 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     const int L = a.L, dil = a.dilation;
 
     const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
-    const float* __restrict__ pt = a.part_t + (size_t)b * a.part_t_bstride;
 
-    // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 3 taps x P positions
+    // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 3 taps x P positions of RAW x, by LDS-DMA.
+    // One descriptor per (channel) row with num_records = L*4 bytes: a tap position outside [0, L)
+    // is out of range for the row and the hardware returns 0 -- the conv's zero padding for free,
+    // no VGPRs, no address VALU, fully asynchronous.  The step-embedding term h = x + fc_t(e) is NOT
+    // added here; it enters GEMM1 as three extra K rows (see `ind` below).
     constexpr int ROWS = 3 * KC;            // rows per chunk
     constexpr int RPW = ROWS / T::WAVES;    // rows per wave
-    float stg[RPW];
-    auto stage_load = [&](int cb) {
+    auto stage_dma = [&](int cb, int buf) {
+        float* xs = lds + buf * (3 * KC * P);
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int row = wave + T::WAVES * i;
             const int tap = row / KC, cc = row % KC;
             const int c = cb * KC + cc;
-            const int pos = l0 + lane + (tap - 1) * dil;
-            // Unconditional load from a clamped address, zeroed by a 0/1 multiply.  A
-            // conditional load (or a select fed by a load) makes hipcc branch around
-            // every load and wait vmcnt(0) per element: 24 serialized HBM round trips.
-            const bool ok = (unsigned)pos < (unsigned)L;
-            const float v = xb[(size_t)c * L + (ok ? pos : 0)];
-            stg[i] = (v + pt[c]) * (ok ? 1.f : 0.f);
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * L), 0, L * 4, 0x00020000);
+            const int voff = (l0 + lane + (tap - 1) * dil) * 4;  // negative -> huge unsigned -> out of range -> 0
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 4, voff, 0, 0, 0);
         }
     };
-    auto stage_store = [&](int buf) {
-        float* xs = lds + buf * (3 * KC * P);
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int row = wave + T::WAVES * i;
-            xs[row * P + lane] = stg[i];
-        }
-    };
+
+    // indicator rows: ind[t][col] = 1 if tap t of column col lies inside [0, L), rows 3..7 = 0.
+    // GEMM1 gets one extra k-group  Abt[2C x 8] . ind[8 x P]  with Abt[o][t] = sum_c Wd[o,c,t] fc_t(e)[c]
+    // (wn_bias_tap_kernel), which adds exactly Wd (*) (fc_t(e) on the in-range taps).
+    float* ind = lds + T::XS_FLOATS;
+    for (int i = tid; i < 8 * P; i += 256) {
+        const int t = i / P, col = i % P;
+        const int pos = l0 + col + (t - 1) * dil;
+        ind[i] = (t < 3 && (unsigned)pos < (unsigned)L) ? 1.f : 0.f;
+    }
 
     // ---- GEMM1: H[2C x P] = Wd[2C x 3C] . Xs[3C x P]
     f32x16 acc[2 * MP][NT];
@@ -254,30 +269,31 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     constexpr int NKG1 = 3 * C / 8;  // k-groups (of 4 k-steps) per M tile
-    const float4* A1 = reinterpret_cast<const float4*>(a.A1);
+    __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A1, 0, 2 * C * 3 * C * 4, 0x00020000);
+    const int lane16 = lane * 16;
     // tile ids of this wave: tanh tiles wm*MP+i, sigmoid tiles C/32 + wm*MP+i
-    auto a1_ptr = [&](int m, int kg) -> const float4* {
-        const int mt = (m < MP) ? (wm * MP + m) : (C / 32 + wm * MP + (m - MP));
-        return A1 + ((size_t)mt * NKG1 + kg) * 64 + lane;
-    };
+    int mt1[2 * MP];
+#pragma unroll
+    for (int m = 0; m < 2 * MP; ++m) mt1[m] = (m < MP) ? (wm * MP + m) : (C / 32 + wm * MP + (m - MP));
 
-    stage_load(0);
-    stage_store(0);
+    stage_dma(0, 0);
+    f32x4 a_cur[2 * MP], a_nxt[2 * MP];
+#pragma unroll
+    for (int m = 0; m < 2 * MP; ++m) a_cur[m] = buf_load_f4(rA1, lane16, (mt1[m] * NKG1) * 1024);
     __syncthreads();
 
-    float4 a_cur[2 * MP], a_nxt[2 * MP];
-#pragma unroll
-    for (int m = 0; m < 2 * MP; ++m) a_cur[m] = *a1_ptr(m, 0);
-
     for (int cb = 0; cb < T::NCB; ++cb) {
-        if (cb + 1 < T::NCB) stage_load(cb + 1);
+        if (cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
         const float* xs = lds + (cb & 1) * (3 * KC * P);
 #pragma unroll
         for (int it = 0; it < 3 * KC / 8; ++it) {  // (tap, kg) flattened: 8 consecutive k per iteration
             const int kg = cb * (3 * KC / 8) + it;
             const int kgn = (kg + 1 < NKG1) ? kg + 1 : kg;
 #pragma unroll
-            for (int m = 0; m < 2 * MP; ++m) a_nxt[m] = *a1_ptr(m, kgn);
+            for (int m = 0; m < 2 * MP; ++m) a_nxt[m] = buf_load_f4(rA1, lane16, (mt1[m] * NKG1 + kgn) * 1024);
+            // keep the prefetch a full k-group (32 MFMAs) ahead of its use: without this fence hipcc sinks
+            // the loads below the MFMAs into the registers of a_cur and waits vmcnt(0) right after issuing them
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int krow = it * 8 + j * 2 + lhi;  // row inside the chunk (tap*KC + cc)
@@ -285,19 +301,36 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) bf[n] = xs[krow * P + (wn * NT + n) * 32 + l31];
 #pragma unroll
-                for (int m = 0; m < 2 * MP; ++m) {
-                    const float av = (j == 0) ? a_cur[m].x : (j == 1) ? a_cur[m].y : (j == 2) ? a_cur[m].z : a_cur[m].w;
+                for (int m = 0; m < 2 * MP; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc[m][n], 0, 0, 0);
-                }
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j], bf[n], acc[m][n], 0, 0, 0);
             }
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) a_cur[m] = a_nxt[m];
         }
-        if (cb + 1 < T::NCB) stage_store((cb + 1) & 1);
-        __syncthreads();
+        __syncthreads();  // (LDS-DMA of chunk cb+1 has landed: the barrier's release waits vmcnt(0))
     }
+    // extra k-group: step-embedding correction rows
+    {
+        const f32x4* Abt = reinterpret_cast<const f32x4*>(a.Abt) + (size_t)b * (2 * C / 32) * 64;
+        f32x4 ab[2 * MP];
+#pragma unroll
+        for (int m = 0; m < 2 * MP; ++m) ab[m] = Abt[mt1[m] * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {  // k = 0..3 (k = 3 is a zero row); k-steps 2,3 are all-zero and skipped
+            const int krow = j * 2 + lhi;
+            float bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = ind[krow * P + (wn * NT + n) * 32 + l31];
+#pragma unroll
+            for (int m = 0; m < 2 * MP; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[m][j], bf[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // gate tile below aliases the staging + indicator regions
 
     // ---- gate: g = tanh(H_t + b_t (+mel_t)) * sigmoid(H_s + b_s (+mel_s)) -> LDS [C][P]
     float* gt = lds;
@@ -319,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
                         hs += melb[(size_t)(C + ch) * L + pos];
                     }
                 }
-                gt[ch * P + col] = tanhf(ht) * sigmoidf_(hs);
+                gt[ch * P + col] = fast_tanh(ht) * fast_sigmoid(hs);
             }
         }
     }
@@ -335,19 +368,19 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
             for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
 
     constexpr int NKG2 = C / 8;
-    const float4* A2 = reinterpret_cast<const float4*>(a.A2);
-    auto a2_ptr = [&](int m, int kg) -> const float4* {
-        const int mt = (m < MR) ? (wm * MR + m) : (C / 32 + wm * MS + (m - MR));
-        return A2 + ((size_t)mt * NKG2 + kg) * 64 + lane;
-    };
-    float4 c_cur[MR + MS], c_nxt[MR + MS];
+    __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 4, 0x00020000);
+    int mt2[MR + MS];
 #pragma unroll
-    for (int m = 0; m < MR + MS; ++m) c_cur[m] = *a2_ptr(m, 0);
+    for (int m = 0; m < MR + MS; ++m) mt2[m] = (m < MR) ? (wm * MR + m) : (C / 32 + wm * MS + (m - MR));
+    f32x4 c_cur[MR + MS], c_nxt[MR + MS];
+#pragma unroll
+    for (int m = 0; m < MR + MS; ++m) c_cur[m] = buf_load_f4(rA2, lane16, (mt2[m] * NKG2) * 1024);
 #pragma unroll 2
     for (int kg = 0; kg < NKG2; ++kg) {
         const int kgn = (kg + 1 < NKG2) ? kg + 1 : kg;
 #pragma unroll
-        for (int m = 0; m < MR + MS; ++m) c_nxt[m] = *a2_ptr(m, kgn);
+        for (int m = 0; m < MR + MS; ++m) c_nxt[m] = buf_load_f4(rA2, lane16, (mt2[m] * NKG2 + kgn) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int krow = kg * 8 + j * 2 + lhi;
@@ -355,12 +388,10 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) bf[n] = gt[krow * P + (wn * NT + n) * 32 + l31];
 #pragma unroll
-            for (int m = 0; m < MR + MS; ++m) {
-                const float av = (j == 0) ? c_cur[m].x : (j == 1) ? c_cur[m].y : (j == 2) ? c_cur[m].z : c_cur[m].w;
+            for (int m = 0; m < MR + MS; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc2[m][n], 0, 0, 0);
-            }
+                    acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][j], bf[n], acc2[m][n], 0, 0, 0);
         }
 #pragma unroll
         for (int m = 0; m < MR + MS; ++m) c_cur[m] = c_nxt[m];
@@ -412,6 +443,55 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
             }
         }
     }
+}
+
+// Abt[n][b][mt][lane][j]: A fragments (mfma 32x32x2 order, one k-group of 8) of the step-embedding
+// correction  Abt[o][t] = sum_c Wd_n[o,c,t] * fc_t_n(e_b)[c],  t = 0..2 (k = t), k = 3..7 zero.
+// One wave per (layer n, output row o); the folded weight row [C][3] stays in registers for all b.
+__global__ void wn_bias_tap_kernel(const float* __restrict__ Wd_all, const float* __restrict__ part_t,
+                                   float* __restrict__ Abt, int NL, int B, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // n * 2C + o
+    if (row >= NL * 2 * C) return;
+    const int n = row / (2 * C), o = row % (2 * C);
+    const float* w = Wd_all + (size_t)row * C * 3;
+    constexpr int MAXR = 8;  // C <= 512
+    float w0[MAXR], w1[MAXR], w2[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = c < C;
+        w0[i] = ok ? w[c * 3 + 0] : 0.f;
+        w1[i] = ok ? w[c * 3 + 1] : 0.f;
+        w2[i] = ok ? w[c * 3 + 2] : 0.f;
+    }
+    for (int b = 0; b < B; ++b) {
+        const float* pt = part_t + ((size_t)b * NL + n) * C;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int c = lane + 64 * i;
+            const float p = (c < C) ? pt[c] : 0.f;
+            s0 = fmaf(w0[i], p, s0); s1 = fmaf(w1[i], p, s1); s2 = fmaf(w2[i], p, s2);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off);
+        }
+        if (lane == 0) {
+            float* dst = Abt + (((size_t)n * B + b) * (2 * C / 32) + o / 32) * 256;
+            dst[(o % 32) * 4 + 0] = s0;          // k = 0: lane_hi 0, j 0
+            dst[(32 + o % 32) * 4 + 0] = s1;     // k = 1: lane_hi 1, j 0
+            dst[(o % 32) * 4 + 1] = s2;          // k = 2: lane_hi 0, j 1
+        }
+    }
+}
+
+int launch_wn_bias_tap(const float* Wd_all, const float* part_t, float* Abt, int NL, int B, int C, hipStream_t s) {
+    DWS_CHECK(C <= 512, DWS_ERR_UNSUPPORTED, "wn_bias_tap: C=%d > 512", C);
+    hipLaunchKernelGGL(wn_bias_tap_kernel, dim3(ceil_div((int64_t)NL * 2 * C, 4)), dim3(256), 0, s, Wd_all, part_t, Abt, NL,
+                       B, C);
+    return DWS_OK;
 }
 
 template <int C, int S>

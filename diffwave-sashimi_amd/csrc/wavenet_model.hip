@@ -15,7 +15,9 @@ struct WaveNetModel : dws_model {
 
     // folded / packed weights
     DevBuf Wi;                       // init conv [C][Cin]
-    std::vector<DevBuf> Wd, A1, Wrs, A2, bias2;   // per layer
+    std::vector<DevBuf> A1, Wrs, A2, bias2;       // per layer
+    DevBuf Wd_all;                   // folded dilated-conv weights of all layers [NL][2C][C][3]
+    DevBuf Abt;                      // per-step embedding correction fragments [NL][B][2C/32][64][4]
     DevBuf Wt_all, bt_all;           // stacked fc_t [NL*C][Eout], [NL*C]
     DevBuf Wf, Af;                   // final_conv[0]
     DevBuf freq;                     // embedding frequencies [Ein/2]
@@ -71,9 +73,11 @@ struct WaveNetModel : dws_model {
         wn("final_conv.0.conv", {S, S, 1});
         add_param("final_conv.2.conv.weight", {Cout, S, 1});
         add_param("final_conv.2.conv.bias", {Cout});
-        Wd.resize(NL); A1.resize(NL); Wrs.resize(NL); A2.resize(NL); bias2.resize(NL);
+        A1.resize(NL); Wrs.resize(NL); A2.resize(NL); bias2.resize(NL);
         if (cond) { melW0.resize(NL); melW1.resize(NL); melWc.resize(NL); }
     }
+
+    float* Wd(int n) const { return Wd_all.f() + (size_t)n * 2 * C * C * 3; }
 
     int fold(const std::string& p, float* out, int O, int inner, hipStream_t s) {
         return launch_fold_weight_norm(P(p + ".weight_v"), P(p + ".weight_g"), out, O, inner, s);
@@ -84,6 +88,7 @@ struct WaveNetModel : dws_model {
         DWS_TRY(fold("init_conv.0.conv", Wi.f(), C, Cin, s));
         DWS_TRY(Wt_all.ensure((size_t)NL * C * Eout * 4));
         DWS_TRY(bt_all.ensure((size_t)NL * C * 4));
+        DWS_TRY(Wd_all.ensure((size_t)NL * 2 * C * C * 3 * 4));
         if (mfma_layer) DWS_TRY(tmp_pack.ensure((size_t)2 * C * 3 * C * 4));
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
@@ -91,8 +96,7 @@ struct WaveNetModel : dws_model {
                                    hipMemcpyDeviceToDevice, s));
             DWS_HIP(hipMemcpyAsync(bt_all.f() + (size_t)n * C, P(p + ".fc_t.bias"), (size_t)C * 4,
                                    hipMemcpyDeviceToDevice, s));
-            DWS_TRY(Wd[n].ensure((size_t)2 * C * C * 3 * 4));
-            DWS_TRY(fold(p + ".dilated_conv_layer.conv", Wd[n].f(), 2 * C, C * 3, s));
+            DWS_TRY(fold(p + ".dilated_conv_layer.conv", Wd(n), 2 * C, C * 3, s));
             DWS_TRY(Wrs[n].ensure((size_t)(C + S) * C * 4));
             DWS_TRY(fold(p + ".res_conv", Wrs[n].f(), C, C, s));
             DWS_TRY(fold(p + ".skip_conv", Wrs[n].f() + (size_t)C * C, S, C, s));
@@ -101,7 +105,7 @@ struct WaveNetModel : dws_model {
             DWS_HIP(hipMemcpyAsync(bias2[n].f() + C, P(p + ".skip_conv.bias"), (size_t)S * 4, hipMemcpyDeviceToDevice, s));
             if (mfma_layer) {
                 DWS_TRY(A1[n].ensure((size_t)2 * C * 3 * C * 4));
-                DWS_TRY(launch_permute_dconv(Wd[n].f(), tmp_pack.f(), C, WN_LAYER_KC, s));
+                DWS_TRY(launch_permute_dconv(Wd(n), tmp_pack.f(), C, WN_LAYER_KC, s));
                 DWS_TRY(launch_pack_a_frag(tmp_pack.f(), A1[n].f(), 2 * C, 3 * C, s));
                 DWS_TRY(A2[n].ensure((size_t)(C + S) * C * 4));
                 DWS_TRY(launch_pack_a_frag(Wrs[n].f(), A2[n].f(), C + S, C, s));
@@ -152,6 +156,11 @@ struct WaveNetModel : dws_model {
         DWS_TRY(h1.ensure((size_t)B * Emid * 4));
         DWS_TRY(h2.ensure((size_t)B * Eout * 4));
         DWS_TRY(part_t.ensure((size_t)B * NL * C * 4));
+        if (mfma_layer) {
+            const size_t n = (size_t)NL * B * (2 * C / 32) * 256 * 4;
+            DWS_TRY(Abt.ensure(n));
+            DWS_HIP(hipMemset(Abt.p, 0, n));  // k = 3..7 entries of the correction k-group stay zero
+        }
         return DWS_OK;
     }
 
@@ -199,6 +208,7 @@ struct WaveNetModel : dws_model {
         DWS_TRY(launch_linear_rows(h1.f(), P("residual_layer.fc_t2.weight"), P("residual_layer.fc_t2.bias"), h2.f(),
                                    (int)B, Emid, Eout, 1, s));
         DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), (int)B, Eout, NL * C, 0, s));
+        if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
             WnLayerArgs a{};
@@ -208,7 +218,8 @@ struct WaveNetModel : dws_model {
             a.part_t = part_t.f() + (size_t)n * C;
             a.part_t_bstride = NL * C;
             a.A1 = A1[n].f(); a.A2 = A2[n].f();
-            a.Wd = Wd[n].f(); a.Wr = Wrs[n].f(); a.Ws = Wrs[n].f() + (size_t)C * C;
+            a.Abt = mfma_layer ? Abt.f() + (size_t)n * B * (2 * C / 32) * 256 : nullptr;
+            a.Wd = Wd(n); a.Wr = Wrs[n].f(); a.Ws = Wrs[n].f() + (size_t)C * C;
             a.bias1 = P(p + ".dilated_conv_layer.conv.bias");
             a.bias2 = bias2[n].f();
             a.melc = melBm ? melc.f() + (size_t)n * melBm * 2 * C * L : nullptr;
