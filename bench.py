@@ -61,6 +61,7 @@ CONFIGS = {
 }
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA (three bf16 MFMAs per fp32-equivalent product)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -144,6 +145,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="wnet_h256_d36_T200", choices=list(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="WaveNet matrix arithmetic: exact-f32 MFMA (default) or the 3-term bf16 split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -168,6 +171,8 @@ def main():
     dcfg = cfg["diffusion"]
     T = dcfg["T"]
     net = build_model(cfg, dev)
+    if args.precision != "f32":
+        net.set_option("precision", args.precision)
     dh = calc_diffusion_hyperparams(**dcfg)
     tabs = [np.ascontiguousarray(dh[k].numpy()) for k in ("Alpha", "Alpha_bar", "Sigma")]
     ptabs = [t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) for t in tabs]
@@ -205,7 +210,7 @@ def main():
         "metric": "audio samples/sec (generate.py-style reverse-diffusion sampling, T=%d)" % T,
         "value": value, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded reference initialisers, x_T ~ N(0,1))",
+        "dtype": "f32" if args.precision == "f32" else "bf16x3 split (hi/lo bf16 MFMA inputs, fp32 accumulate; ~1e-5 rel)", "data": "synthetic (seeded reference initialisers, x_T ~ N(0,1))",
         "config": {"workload": args.config, "backbone": cfg["model"]["_name_"], "batch_per_gpu": B, "L": L, "T": T,
                    "parallelism": "independent clips per GPU, no collective",
                    "sampler": "hipGraph replay, on-device Philox noise"},
@@ -215,6 +220,7 @@ def main():
         # dominant kernel: the fused residual layer.  Timed with HIP events on its own
         # launch stream inside the engine (eager launches, outside any capture).
         flops, bytes_ = layer_algorithmic_work(cfg)
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
         _lib.check(lib.dws_profile_enable(b"wn_layer"))
         nprof = 3
         _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, nprof, seed, 0, stream))
@@ -231,9 +237,10 @@ def main():
             # separate --pmc passes on the same command; corrected as the guide prescribes)
             traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
         result["roofline"] = {
-            "kernel": "wn_layer_mfma_kernel<%d,%d>" % (cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
-            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "kernel": "%s<%d,%d>" % ("wn_layer_mfma_kernel" if args.precision == "f32" else "wn_layer_bf16x3_kernel",
+                                     cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": traffic if args.precision == "f32" else None,
             "avg_launch_ms": avg_ms, "launches_timed": n_launch.value,
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
             "hbm_achieved_GBs": bytes_ / (avg_ms * 1e-3) / 1e9,

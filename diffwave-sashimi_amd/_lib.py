@@ -49,6 +49,7 @@ _SIGS = {
     "dws_model_set_param": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,
                                            ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p]),
+    "dws_model_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]),
     "dws_model_commit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "dws_model_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]),
     "dws_model_set_condition": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_int64, ctypes.c_int64,

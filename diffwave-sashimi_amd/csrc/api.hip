@@ -32,6 +32,10 @@ dws::ParamSpec* dws_model::add_param(const std::string& name, std::vector<int64_
     return p;
 }
 
+int dws_model::set_option(const std::string& key, const std::string& value) {
+    return dws::set_error(DWS_ERR_INVALID, "unknown option %s=%s for this model", key.c_str(), value.c_str());
+}
+
 float* dws_model::P(const std::string& name) const {
     auto it = index.find(name);
     if (it == index.end()) return nullptr;
@@ -118,6 +122,12 @@ int dws_model_set_param(dws_model* m, const char* name, const void* data, const 
     m->dirty = true;
     m->drop_graph();
     return DWS_OK;
+}
+
+int dws_model_set_option(dws_model* m, const char* key, const char* value) {
+    DWS_CHECK(m && key && value, DWS_ERR_INVALID, "dws_model_set_option: null argument");
+    m->drop_graph();
+    return m->set_option(key, value);
 }
 
 int dws_model_commit(dws_model* m, void* stream) {

@@ -78,6 +78,7 @@ struct dws_model {
     int alloc_params();
     void drop_graph();
 
+    virtual int set_option(const std::string& key, const std::string& value);
     virtual int commit(hipStream_t s) = 0;
     virtual int prepare(int64_t B, int64_t L) = 0;
     virtual int set_condition(const float* mel, int64_t Bm, int64_t Tmel, hipStream_t s) = 0;

@@ -52,6 +52,11 @@ bool wn_layer_mfma_supported(int C, int S);
 int launch_wn_layer_mfma(int C, int S, const WnLayerArgs& a, hipStream_t s);
 int launch_wn_layer_generic(int C, int S, const WnLayerArgs& a, hipStream_t s);
 bool wn_final_mfma_supported(int S);
+// bf16x3 path (wavenet_bf16x3.hip)
+bool wn_layer_bf16x3_supported(int C, int S);
+int launch_wn_layer_bf16x3(int C, int S, const WnLayerArgs& a, hipStream_t s);
+int launch_pack_a_bf16x3(const float* w, void* out, int M, int K, hipStream_t s);
+int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, void* Abt, int NL, int B, int C, hipStream_t s);
 int launch_wn_final(int S, const WnFinalArgs& a, hipStream_t s);
 
 }  // namespace dws

@@ -12,6 +12,7 @@ namespace dws {
 struct WaveNetModel : dws_model {
     int Cin, Cout, C, S, NL, cycle, Ein, Emid, Eout, MB;
     bool cond, mfma_layer, mfma_final;
+    bool bf16x3 = false;             // precision option (see include/dws.h)
 
     // folded / packed weights
     DevBuf Wi;                       // init conv [C][Cin]
@@ -77,6 +78,19 @@ struct WaveNetModel : dws_model {
         if (cond) { melW0.resize(NL); melW1.resize(NL); melWc.resize(NL); }
     }
 
+    int set_option(const std::string& key, const std::string& value) override {
+        if (key == "precision") {
+            if (value == "f32") { bf16x3 = false; dirty = true; return DWS_OK; }
+            if (value == "bf16x3") {
+                DWS_CHECK(wn_layer_bf16x3_supported(C, S), DWS_ERR_UNSUPPORTED,
+                          "precision=bf16x3 is not built for (res_channels=%d, skip_channels=%d)", C, S);
+                bf16x3 = true; dirty = true;
+                return DWS_OK;
+            }
+        }
+        return dws_model::set_option(key, value);
+    }
+
     float* Wd(int n) const { return Wd_all.f() + (size_t)n * 2 * C * C * 3; }
 
     int fold(const std::string& p, float* out, int O, int inner, hipStream_t s) {
@@ -106,9 +120,14 @@ struct WaveNetModel : dws_model {
             if (mfma_layer) {
                 DWS_TRY(A1[n].ensure((size_t)2 * C * 3 * C * 4));
                 DWS_TRY(launch_permute_dconv(Wd(n), tmp_pack.f(), C, WN_LAYER_KC, s));
-                DWS_TRY(launch_pack_a_frag(tmp_pack.f(), A1[n].f(), 2 * C, 3 * C, s));
                 DWS_TRY(A2[n].ensure((size_t)(C + S) * C * 4));
-                DWS_TRY(launch_pack_a_frag(Wrs[n].f(), A2[n].f(), C + S, C, s));
+                if (bf16x3) {
+                    DWS_TRY(launch_pack_a_bf16x3(tmp_pack.f(), A1[n].p, 2 * C, 3 * C, s));
+                    DWS_TRY(launch_pack_a_bf16x3(Wrs[n].f(), A2[n].p, C + S, C, s));
+                } else {
+                    DWS_TRY(launch_pack_a_frag(tmp_pack.f(), A1[n].f(), 2 * C, 3 * C, s));
+                    DWS_TRY(launch_pack_a_frag(Wrs[n].f(), A2[n].f(), C + S, C, s));
+                }
             }
             if (cond) {
                 for (int i = 0; i < 2; ++i) {
@@ -137,6 +156,7 @@ struct WaveNetModel : dws_model {
             DWS_HIP(hipMemcpyAsync(freq.p, f.data(), (size_t)half * 4, hipMemcpyHostToDevice, s));
             DWS_HIP(hipStreamSynchronize(s));  // f goes out of scope
         }
+        if (Abt.p) DWS_HIP(hipMemsetAsync(Abt.p, 0, Abt.bytes, s));  // correction layout depends on the precision
         dirty = false;
         melBm = 0;  // conditioner terms depend on the weights: must be re-installed
         return DWS_OK;
@@ -157,9 +177,9 @@ struct WaveNetModel : dws_model {
         DWS_TRY(h2.ensure((size_t)B * Eout * 4));
         DWS_TRY(part_t.ensure((size_t)B * NL * C * 4));
         if (mfma_layer) {
-            const size_t n = (size_t)NL * B * (2 * C / 32) * 256 * 4;
+            const size_t n = (size_t)NL * B * (2 * C / 32) * 2048;  // sized for the larger (bf16 hi+lo, k-block 16) form
             DWS_TRY(Abt.ensure(n));
-            DWS_HIP(hipMemset(Abt.p, 0, n));  // k = 3..7 entries of the correction k-group stay zero
+            DWS_HIP(hipMemset(Abt.p, 0, n));  // the unused k entries of the correction k-group stay zero
         }
         return DWS_OK;
     }
@@ -208,7 +228,8 @@ struct WaveNetModel : dws_model {
         DWS_TRY(launch_linear_rows(h1.f(), P("residual_layer.fc_t2.weight"), P("residual_layer.fc_t2.bias"), h2.f(),
                                    (int)B, Emid, Eout, 1, s));
         DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), (int)B, Eout, NL * C, 0, s));
-        if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
+        if (mfma_layer && bf16x3) DWS_TRY(launch_wn_bias_tap_bf16(Wd_all.f(), part_t.f(), Abt.p, NL, (int)B, C, s));
+        else if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
             WnLayerArgs a{};
@@ -218,7 +239,7 @@ struct WaveNetModel : dws_model {
             a.part_t = part_t.f() + (size_t)n * C;
             a.part_t_bstride = NL * C;
             a.A1 = A1[n].f(); a.A2 = A2[n].f();
-            a.Abt = mfma_layer ? Abt.f() + (size_t)n * B * (2 * C / 32) * 256 : nullptr;
+            a.Abt = mfma_layer ? Abt.f() + (size_t)n * B * (2 * C / 32) * (bf16x3 ? 512 : 256) : nullptr;
             a.Wd = Wd(n); a.Wr = Wrs[n].f(); a.Ws = Wrs[n].f() + (size_t)C * C;
             a.bias1 = P(p + ".dilated_conv_layer.conv.bias");
             a.bias2 = bias2[n].f();
@@ -228,7 +249,8 @@ struct WaveNetModel : dws_model {
             a.B = (int)B; a.L = (int)L;
             a.dilation = 1 << (n % cycle);
             a.first_layer = (n == 0); a.last_layer = (n == NL - 1);
-            if (mfma_layer) DWS_TRY(launch_wn_layer_mfma(C, S, a, s));
+            if (mfma_layer && bf16x3) DWS_TRY(launch_wn_layer_bf16x3(C, S, a, s));
+            else if (mfma_layer) DWS_TRY(launch_wn_layer_mfma(C, S, a, s));
             else DWS_TRY(launch_wn_layer_generic(C, S, a, s));
         }
         DWS_TRY(final_stage(out, nullptr, s));

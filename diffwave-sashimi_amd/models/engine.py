@@ -44,6 +44,11 @@ class EngineModule(nn.Module):
         except Exception:
             pass
 
+    def set_option(self, key, value):
+        """Engine option, e.g. ``set_option("precision", "bf16x3")`` (see dws_model_set_option)."""
+        _lib.check(_lib.load().dws_model_set_option(self._ensure_handle(), key.encode(), str(value).encode()))
+        return self
+
     def _engine_state(self):
         """(name, tensor) pairs handed to dws_model_set_param: the state_dict."""
         return self.state_dict(keep_vars=True).items()

@@ -121,6 +121,13 @@ int dws_model_param_info(const dws_model* m, int index, const char** name,
 int dws_model_set_param(dws_model* m, const char* name, const void* data,
                         const int64_t* shape, int ndim, int dtype, void* stream);
 
+/* String options (unknown key/value -> DWS_ERR_INVALID):
+ *   "precision" = "f32"    (default) exact-f32 MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain
+ *               = "bf16x3" WaveNet residual layers on the bf16 matrix cores with a 3-term hi/lo split
+ *                          (W_hi x_hi + W_hi x_lo + W_lo x_hi, fp32 accumulate): ~1e-5 relative, 5.3x the
+ *                          matrix rate.  Not part of the reference surface. */
+int dws_model_set_option(dws_model* m, const char* key, const char* value);
+
 /* Fold / pack everything that depends only on the weights.  Called implicitly
  * by forward when parameters changed since the last commit. */
 int dws_model_commit(dws_model* m, void* stream);

@@ -36,6 +36,38 @@ def test_wavenet_forward_matches_reference(gpu, name):
     print(f"{name}: rel err vs reference {err:.3e}")
 
 
+@pytest.mark.parametrize("name", ["wn_c64", "wn_c128", "wn_h128_d30", "wn_h256_d36"])
+def test_wavenet_bf16x3_precision_mode_matches_reference(gpu, name):
+    """Opt-in precision="bf16x3" (3-term bf16 split on the matrix cores, fp32 accumulate) must still
+    meet the 1e-3 parity bound against the reference's fp32 forward -- it sits ~100x inside it."""
+    cfg, B, L, wseed, iseed, store = cases.WAVENET_CASES[name]
+    g = load_golden("wavenet")
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    audio, steps = cases.wavenet_inputs(B, L, cfg["in_channels"], iseed)
+    with torch.no_grad():
+        e32 = net((audio.to(gpu), steps.to(gpu)))
+        net.set_option("precision", "bf16x3")
+        e16 = net((audio.to(gpu), steps.to(gpu)))
+        pre = net.read_tap("pre_final", (B, cfg["skip_channels"], L))
+        net.set_option("precision", "f32")
+        e32b = net((audio.to(gpu), steps.to(gpu)))
+    err = rel_err(e16, g[f"{name}/eps"])
+    assert err < REL_TOL / 10, f"{name}: bf16x3 rel err {err:.3e}"
+    dg = cases.summarize(pre.cpu(), stride=64)
+    assert rel_err(dg["strided"], g[f"{name}/pre_final/strided"]) < REL_TOL / 10
+    assert not torch.equal(e16, e32)          # it really is a different arithmetic path
+    assert torch.equal(e32, e32b)             # and switching back restores the exact-f32 path bit for bit
+    print(f"{name}: bf16x3 rel err vs reference {err:.3e}")
+
+
+def test_bf16x3_rejected_where_not_built(gpu):
+    net = cases.build_ours(cases.WAVENET_CASES["wn_tiny"][0], 1).to(gpu)
+    with pytest.raises(NotImplementedError):
+        net.set_option("precision", "bf16x3")
+    with pytest.raises(RuntimeError):
+        net.set_option("precision", "fp8")
+
+
 @pytest.mark.parametrize("name", ["wn_tiny", "wn_c64"])
 def test_wavenet_matches_oracle_on_fresh_inputs(gpu, name):
     """Same seeded inputs through the oracle and the HIP path (no golden file involved)."""
