@@ -8,8 +8,11 @@
 // Same structure as wn_layer_mfma_kernel (wavenet_kernels.hip) -- LDS-DMA staging of the raw x
 // window with hardware zero padding, the step embedding as extra K rows, gate in registers,
 // [res; skip] GEMM from the LDS gate tile -- but with a 128-position tile and 8 waves so every A
-// fragment (streamed from L2) feeds 4 position tiles, and B fragments built on the fly from the
-// fp32 LDS window: 8 ds_read_b32 down the k axis -> split into (hi, lo) bf16x8.
+// fragment (streamed from L2) feeds 4 position tiles.  After each chunk's DMA lands, ONE cooperative
+// pass splits the fp32 window into (hi, lo) bf16 and stores it in MFMA B-fragment order
+// ([k-octet][position] 16-byte items), so a B fragment is a single conflict-free ds_read_b128.
+#include <cstdlib>
+
 #include "wavenet.h"
 
 namespace dws {
@@ -34,11 +37,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
 __device__ __forceinline__ float fast_sigmoid3(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh3(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
-template <int C, int S>
+template <int C, int S, int P_, int WAVES_>
 struct Bx3Tile {
-    static constexpr int P = 128;
-    static constexpr int WAVES = 8;
-    static constexpr int WM = (C / 32 >= 8) ? 8 : C / 32;
+    static constexpr int P = P_;
+    static constexpr int WAVES = WAVES_;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int WM = (C / 32 >= WAVES) ? WAVES : C / 32;
     static constexpr int WN = WAVES / WM;
     static constexpr int NT = (P / 32) / WN;
     static constexpr int MP = C / 32 / WM;   // (tanh, sigmoid) tile pairs per wave
@@ -46,24 +50,28 @@ struct Bx3Tile {
     static constexpr int MS = S / 32 / WM;
     static constexpr int KC = WN_LAYER_KC;
     static constexpr int NCB = C / KC;
-    static constexpr int XS_FLOATS = 2 * 3 * KC * P;
-    static constexpr int IND_FLOATS = 16 * P;
-    static constexpr int G_FLOATS = C * P;
-    static constexpr int LDS_FLOATS = (XS_FLOATS + IND_FLOATS) > G_FLOATS ? (XS_FLOATS + IND_FLOATS) : G_FLOATS;
+    static constexpr int OCT = 3 * KC / 8;               // k-octets per chunk
+    // LDS map (float units): F = 2 fp32 DMA buffers; X = (hi, lo) bf16x8 items [octet][pos] of the
+    // current chunk; IND = indicator items (2 octets).  The gate tile (hi, lo items [C/8][pos])
+    // aliases everything from offset 0 once GEMM1 is done.
+    static constexpr int F_FLOATS = 2 * 3 * KC * P;
+    static constexpr int X_FLOATS = 2 * OCT * P * 4;
+    static constexpr int IND_FLOATS = 2 * P * 4;
+    static constexpr int G_FLOATS = 2 * (C / 8) * P * 4;
+    static constexpr int GEMM1_FLOATS = F_FLOATS + X_FLOATS + IND_FLOATS;
+    static constexpr int LDS_FLOATS = GEMM1_FLOATS > G_FLOATS ? GEMM1_FLOATS : G_FLOATS;
     static_assert(WN * NT * 32 == P && C % (32 * WM) == 0 && S % (32 * WM) == 0 && C % KC == 0, "tiling");
 };
 
-// acc[m][n] += (Ahi + Alo)[m] . (x_hi + x_lo)[n]  minus the lo*lo term, for one k-block of 16
+// acc[m][n] += (A_hi + A_lo)[m] . (x_hi + x_lo)[n] minus the lo*lo term, for one k-block of 16.
+// B items: bf16x8 at item index (octet*P + col), octet = 2*kb + (lane>>5).
 template <int MT, int NT, int P>
 __device__ __forceinline__ void kblock(f32x16 (&acc)[MT][NT], const bf16x8 (&ahi)[MT], const bf16x8 (&alo)[MT],
-                                       const float* __restrict__ bt, int krow0, int col0) {
+                                       const u32x4* __restrict__ xhi, const u32x4* __restrict__ xlo, int item0) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        float x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = bt[(krow0 + i) * P + col0 + n * 32];
-        bf16x8 bhi, blo;
-        split8(x, bhi, blo);
+        const bf16x8 bhi = __builtin_bit_cast(bf16x8, xhi[item0 + n * 32]);
+        const bf16x8 blo = __builtin_bit_cast(bf16x8, xlo[item0 + n * 32]);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[m], bhi, acc[m][n], 0, 0, 0);
@@ -73,10 +81,11 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[MT][NT], const bf16x8 (&ahi
     }
 }
 
-template <int C, int S>
-__global__ __launch_bounds__(512) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
-    using T = Bx3Tile<C, S>;
-    constexpr int P = T::P, KC = T::KC, NT = T::NT, MP = T::MP, MR = T::MR, MS = T::MS;
+template <int C, int S, int PP, int WV, bool VEC>
+__global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
+    using T = Bx3Tile<C, S, PP, WV>;
+    constexpr int THREADS = T::THREADS;
+    constexpr int P = T::P, KC = T::KC, NT = T::NT, MP = T::MP, MR = T::MR, MS = T::MS, OCT = T::OCT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -92,10 +101,17 @@ __global__ __launch_bounds__(512) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
     const int L = a.L, dil = a.dilation;
     const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
 
-    // ---- staging by LDS-DMA (see wn_layer_mfma_kernel): 3*KC rows x P floats per chunk, two 256-byte
-    // pieces per row; positions outside [0, L) are out of range for the row descriptor -> 0.
+    u32x4* xhi = reinterpret_cast<u32x4*>(lds + T::F_FLOATS);
+    u32x4* xlo = xhi + OCT * P;
+    u32x4* indi = reinterpret_cast<u32x4*>(lds + T::F_FLOATS + T::X_FLOATS);
+
+    // ---- staging by LDS-DMA: 3*KC rows x P floats per chunk, two 256-byte pieces per row, all through ONE
+    // descriptor for this batch element (row = wave-uniform soffset; per-row descriptors as in
+    // wn_layer_mfma_kernel cost 4 SGPRs each and spill here).  A tap position outside [0, L) then reads a
+    // neighbouring row (or 0 beyond the tensor) -- it is zeroed by the mask of the convert pass below.
     constexpr int PIECES = 3 * KC * (P / 64);
     constexpr int PPW = PIECES / T::WAVES;
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
     auto stage_dma = [&](int cb, int buf) {
         float* xs = lds + buf * (3 * KC * P);
 #pragma unroll
@@ -104,18 +120,42 @@ __global__ __launch_bounds__(512) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
             const int row = piece / (P / 64), half = piece % (P / 64);
             const int tap = row / KC, cc = row % KC;
             const int c = cb * KC + cc;
-            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * L), 0, L * 4, 0x00020000);
             const int voff = (l0 + half * 64 + lane + (tap - 1) * dil) * 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P + half * 64, 4, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, xs + row * P + half * 64, 4, voff, c * L * 4, 0, 0);
+        }
+    };
+    // One cooperative fp32 -> (hi, lo) bf16 split per chunk: every element is converted ONCE (not once
+    // per consuming wave) and laid out as the MFMA B fragment wants it: 8 consecutive k per 16-byte
+    // item, items of one octet contiguous over positions -> conflict-free ds_read_b128 / ds_write_b128.
+    // The conv's zero padding is applied here (an octet never straddles two taps: KC % 8 == 0).
+    auto convert = [&](int buf) {
+        const float* xs = lds + buf * (3 * KC * P);
+#pragma unroll
+        for (int i = 0; i < OCT * P / THREADS; ++i) {
+            const int idx = tid + THREADS * i;
+            const int oct = idx / P, pos = idx % P;
+            const int tap = (oct * 8) / KC;
+            const float mask = ((unsigned)(l0 + pos + (tap - 1) * dil) < (unsigned)L) ? 1.f : 0.f;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = xs[(oct * 8 + e) * P + pos] * mask;
+            bf16x8 h, l;
+            split8(x, h, l);
+            xhi[idx] = __builtin_bit_cast(u32x4, h);
+            xlo[idx] = __builtin_bit_cast(u32x4, l);
         }
     };
 
-    // indicator rows (one k-block of 16): rows 0..2 = tap in range, rows 3..15 = 0
-    float* ind = lds + T::XS_FLOATS;
-    for (int i = tid; i < 16 * P; i += 512) {
-        const int t = i / P, col = i % P;
-        const int pos = l0 + col + (t - 1) * dil;
-        ind[i] = (t < 3 && (unsigned)pos < (unsigned)L) ? 1.f : 0.f;
+    // indicator items: octet 0 = {tap0, tap1, tap2 in range, 0...}, octet 1 = 0 (exact in bf16)
+    for (int i = tid; i < 2 * P; i += THREADS) {
+        const int oct = i / P, col = i % P;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pos = l0 + col + (e - 1) * dil;
+            v[e] = (__bf16)((oct == 0 && e < 3 && (unsigned)pos < (unsigned)L) ? 1.f : 0.f);
+        }
+        indi[i] = __builtin_bit_cast(u32x4, v);
     }
 
     f32x16 acc[2 * MP][NT];
@@ -141,12 +181,13 @@ __global__ __launch_bounds__(512) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
         ahi[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1) * 2048);
         alo[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1) * 2048 + 1024);
     }
-    __syncthreads();
 
     for (int cb = 0; cb < T::NCB; ++cb) {
+        __syncthreads();                       // DMA(cb) landed; MFMAs of chunk cb-1 are done with X
         if (cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
-        const float* xs = lds + (cb & 1) * (3 * KC * P);
-#pragma unroll
+        convert(cb & 1);
+        __syncthreads();
+#pragma unroll 1
         for (int it = 0; it < 3 * KC / 16; ++it) {
             const int kb = cb * (3 * KC / 16) + it;
             const int kbn = (kb + 1 < NKB1) ? kb + 1 : kb;
@@ -156,11 +197,10 @@ __global__ __launch_bounds__(512) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
                 nlo[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1 + kbn) * 2048 + 1024);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the A prefetch one k-block ahead (see wavenet_kernels.hip)
-            kblock<2 * MP, NT, P>(acc, ahi, alo, xs, it * 16 + 8 * lhi, col0);
+            kblock<2 * MP, NT, P>(acc, ahi, alo, xhi, xlo, (it * 2 + lhi) * P + col0);
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) { ahi[m] = nhi[m]; alo[m] = nlo[m]; }
         }
-        __syncthreads();
     }
     // step-embedding correction rows (bf16 hi/lo fragments from wn_bias_tap_bf16_kernel); the
     // indicator operand is exact in bf16, so only (hi + lo) x ind is needed
@@ -173,12 +213,7 @@ __global__ __launch_bounds__(512) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            float x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = ind[(8 * lhi + i) * P + col0 + n * 32];
-            bf16x8 bi;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bi[i] = (__bf16)x[i];
+            const bf16x8 bi = __builtin_bit_cast(bf16x8, indi[lhi * P + col0 + n * 32]);
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) {
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[m], bi, acc[m][n], 0, 0, 0);
@@ -188,8 +223,10 @@ __global__ __launch_bounds__(512) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
     }
     __syncthreads();
 
-    // ---- gate -> fp32 tile [C][P] in LDS (aliases the staging buffers)
-    float* gt = lds;
+    // ---- gate -> (hi, lo) bf16 items [C/8][P] in LDS (aliases the GEMM1 buffers).  A lane's four
+    // consecutive accumulator registers are four consecutive channels: half of one 16-byte item.
+    unsigned long long* ghi = reinterpret_cast<unsigned long long*>(lds);
+    unsigned long long* glo = ghi + (C / 8) * P * 2;
     const float* melb = a.melc ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;
 #pragma unroll
     for (int m = 0; m < MP; ++m)
@@ -197,99 +234,223 @@ __global__ __launch_bounds__(512) void wn_layer_bf16x3_kernel(WnLayerArgs a) {
         for (int n = 0; n < NT; ++n) {
             const int col = col0 + n * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = (wm * MP + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                float ht = acc[m][n][r] + a.bias1[ch];
-                float hs = acc[MP + m][n][r] + a.bias1[C + ch];
-                if (melb) {
-                    const int pos = l0 + col;
-                    if (pos < L) {
-                        ht += melb[(size_t)ch * L + pos];
-                        hs += melb[(size_t)(C + ch) * L + pos];
+            for (int q = 0; q < 4; ++q) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 h4, l4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = q * 4 + e;
+                    const int ch = (wm * MP + m) * 32 + 8 * q + 4 * lhi + e;
+                    float ht = acc[m][n][r] + a.bias1[ch];
+                    float hs = acc[MP + m][n][r] + a.bias1[C + ch];
+                    if (melb) {
+                        const int pos = l0 + col;
+                        if (pos < L) {
+                            ht += melb[(size_t)ch * L + pos];
+                            hs += melb[(size_t)(C + ch) * L + pos];
+                        }
                     }
+                    const float g = fast_tanh3(ht) * fast_sigmoid3(hs);
+                    const __bf16 hh = (__bf16)g;
+                    h4[e] = hh;
+                    l4[e] = (__bf16)(g - (float)hh);
                 }
-                gt[ch * P + col] = fast_tanh3(ht) * fast_sigmoid3(hs);
+                const int oct = (wm * MP + m) * 4 + q;
+                ghi[(oct * P + col) * 2 + lhi] = __builtin_bit_cast(unsigned long long, h4);
+                glo[(oct * P + col) * 2 + lhi] = __builtin_bit_cast(unsigned long long, l4);
             }
         }
     __syncthreads();
 
-    // ---- GEMM2: [res; skip] = [Wr; Ws] g
-    f32x16 acc2[MR + MS][NT];
-#pragma unroll
-    for (int m = 0; m < MR + MS; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
+    // ---- GEMM2 + epilogue.
     constexpr int NKB2 = C / 16;
     __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 4, 0x00020000);
-    int mt2[MR + MS];
-#pragma unroll
-    for (int m = 0; m < MR + MS; ++m) mt2[m] = (m < MR) ? (wm * MR + m) : (C / 32 + wm * MS + (m - MR));
-    bf16x8 chi[MR + MS], clo[MR + MS], dhi[MR + MS], dlo[MR + MS];
-#pragma unroll
-    for (int m = 0; m < MR + MS; ++m) {
-        chi[m] = buf_load_bf8(rA2, lane16, (mt2[m] * NKB2) * 2048);
-        clo[m] = buf_load_bf8(rA2, lane16, (mt2[m] * NKB2) * 2048 + 1024);
-    }
-    for (int kb = 0; kb < NKB2; ++kb) {
-        const int kbn = (kb + 1 < NKB2) ? kb + 1 : kb;
-#pragma unroll
-        for (int m = 0; m < MR + MS; ++m) {
-            dhi[m] = buf_load_bf8(rA2, lane16, (mt2[m] * NKB2 + kbn) * 2048);
-            dlo[m] = buf_load_bf8(rA2, lane16, (mt2[m] * NKB2 + kbn) * 2048 + 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        kblock<MR + MS, NT, P>(acc2, chi, clo, gt, kb * 16 + 8 * lhi, col0);
-#pragma unroll
-        for (int m = 0; m < MR + MS; ++m) { chi[m] = dhi[m]; clo[m] = dlo[m]; }
-    }
-
-    // ---- epilogue: x' = (x + res + b_r) * sqrt(.5);  skip_acc (+)= skip + b_s
+    const u32x4* g_hi = reinterpret_cast<const u32x4*>(lds);
+    const u32x4* g_lo = g_hi + (C / 8) * P;
     const float rs = 0.70710678118654752440f;
     float* __restrict__ xo = a.x_out + (size_t)b * C * L;
     float* __restrict__ sk = a.skip + (size_t)b * S * L;
     const bool first = a.first_layer, last = a.last_layer;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int pos = l0 + col0 + n * 32;
-        const bool ok = pos < L;
-        const int posc = ok ? pos : 0;
+
+    auto gemm2 = [&](auto& acc2, const int (&mt2)[1]) {
+        bf16x8 chi[1], clo[1], dhi[1], dlo[1];
+        chi[0] = buf_load_bf8(rA2, lane16, (mt2[0] * NKB2) * 2048);
+        clo[0] = buf_load_bf8(rA2, lane16, (mt2[0] * NKB2) * 2048 + 1024);
+        for (int kb = 0; kb < NKB2; ++kb) {
+            const int kbn = (kb + 1 < NKB2) ? kb + 1 : kb;
+            dhi[0] = buf_load_bf8(rA2, lane16, (mt2[0] * NKB2 + kbn) * 2048);
+            dlo[0] = buf_load_bf8(rA2, lane16, (mt2[0] * NKB2 + kbn) * 2048 + 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            kblock<1, NT, P>(acc2, chi, clo, g_hi, g_lo, (kb * 2 + lhi) * P + col0);
+            chi[0] = dhi[0]; clo[0] = dlo[0];
+        }
+    };
+
+    if constexpr (VEC) {
+        // Vector path (L % 4 == 0, chosen at launch): per-lane dword loads/stores in the accumulator layout are store-ISSUE bound
+        // (131 KB of x' + 131 KB of skip per tile, 4 B per lane per instruction).  Instead: prefetch the
+        // residual x tile as row-major float4 (its latency overlaps the transpose), transpose the accumulators
+        // through LDS (the gate tile is dead by then) and move every output with dwordx4 per lane.
+        constexpr int F4_ROW = P / 4;                 // float4 per tile row
+        constexpr int ROWS_PASS = THREADS / F4_ROW;   // rows covered by one pass of the workgroup
+        const int f4 = tid % F4_ROW, rsub = tid / F4_ROW;
+        const int pos4 = l0 + f4 * 4;
+        const bool ok4 = pos4 < L;                    // L % 4 == 0: a float4 is entirely inside or outside
+        const int pos4c = ok4 ? pos4 : 0;
+        f32x16 accR[MR][NT], accS[MS][NT];
         if (!last) {
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                float xr[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    xr[r] = xb[(size_t)ch * L + posc];
-                }
+                for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (ok) xo[(size_t)ch * L + pos] = (xr[r] + (acc2[m][n][r] + a.bias2[ch])) * rs;
-                }
+                    for (int r = 0; r < 16; ++r) accR[m][n][r] = 0.f;
+                const int mt2[1] = {wm * MR + m};
+                gemm2(*reinterpret_cast<f32x16(*)[1][NT]>(&accR[m]), mt2);
             }
         }
 #pragma unroll
         for (int m = 0; m < MS; ++m) {
-            float sr[16];
-            if (!first) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accS[m][n][r] = 0.f;
+            const int mt2[1] = {C / 32 + wm * MS + m};
+            gemm2(*reinterpret_cast<f32x16(*)[1][NT]>(&accS[m]), mt2);
+        }
+        __syncthreads();  // every wave is done with the gate tile
+        float* ot = lds;  // [rows][P] fp32 transpose buffer
+        if (!last) {
+            // residual x tile as row-major float4; its latency overlaps the LDS transpose below
+            // (holding it across the GEMMs as well would push the kernel past 256 VGPRs)
+            float4 x4[C / ROWS_PASS];
+#pragma unroll
+            for (int i = 0; i < C / ROWS_PASS; ++i)
+                x4[i] = *reinterpret_cast<const float4*>(xb + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        ot[ch * P + col0 + n * 32] = accR[m][n][r] + a.bias2[ch];
+                    }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < C / ROWS_PASS; ++i) {
+                const int row = i * ROWS_PASS + rsub;
+                const float4 v = *reinterpret_cast<const float4*>(ot + row * P + f4 * 4);
+                const float4 o = make_float4((x4[i].x + v.x) * rs, (x4[i].y + v.y) * rs, (x4[i].z + v.z) * rs,
+                                             (x4[i].w + v.w) * rs);
+                if (ok4) *reinterpret_cast<float4*>(xo + (size_t)row * L + pos4) = o;
+            }
+            __syncthreads();
+        }
+        float4 s4[S / ROWS_PASS];
+        if (!first) {
+#pragma unroll
+            for (int i = 0; i < S / ROWS_PASS; ++i)
+                s4[i] = *reinterpret_cast<const float4*>(sk + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
+        } else {
+#pragma unroll
+            for (int i = 0; i < S / ROWS_PASS; ++i) s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    sr[r] = sk[(size_t)sc * L + posc];
+                    ot[sc * P + col0 + n * 32] = accS[m][n][r] + a.bias2[C + sc];
                 }
-            } else {
+        __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+        for (int i = 0; i < S / ROWS_PASS; ++i) {
+            const int row = i * ROWS_PASS + rsub;
+            const float4 v = *reinterpret_cast<const float4*>(ot + row * P + f4 * 4);
+            const float4 o = make_float4(s4[i].x + v.x, s4[i].y + v.y, s4[i].z + v.z, s4[i].w + v.w);
+            if (ok4) *reinterpret_cast<float4*>(sk + (size_t)row * L + pos4) = o;
+        }
+    } else {
+    // Scalar path (L not a multiple of 4: rows are not 16-byte aligned): loads of the residual x /
+    // running skip are issued before the GEMM that produces their partner, stores per lane.
+    float xr[MR][NT][16];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int pos = l0 + col0 + n * 32;
+        const int posc = pos < L ? pos : 0;
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                xr[m][n][r] = xb[(size_t)ch * L + posc];
             }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            f32x16 acc2[1][NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[0][n][r] = 0.f;
+            const int mt2[1] = {wm * MR + m};
+            gemm2(acc2, mt2);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int pos = l0 + col0 + n * 32;
+                const bool ok = pos < L;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (ok) xo[(size_t)ch * L + pos] = (xr[m][n][r] + (acc2[0][n][r] + a.bias2[ch])) * rs;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        float sr[NT][16];
+        if (!first) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int pos = l0 + col0 + n * 32;
+                const int posc = pos < L ? pos : 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    sr[n][r] = sk[(size_t)sc * L + posc];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[n][r] = 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc2[1][NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[0][n][r] = 0.f;
+        const int mt2[1] = {C / 32 + wm * MS + m};
+        gemm2(acc2, mt2);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int pos = l0 + col0 + n * 32;
+            const bool ok = pos < L;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (ok) sk[(size_t)sc * L + pos] = sr[r] + (acc2[MR + m][n][r] + a.bias2[C + sc]);
+                if (ok) sk[(size_t)sc * L + pos] = sr[n][r] + (acc2[0][n][r] + a.bias2[C + sc]);
             }
         }
+    }
     }
 }
 
@@ -366,18 +527,24 @@ int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, void* Abt,
     return DWS_OK;
 }
 
-template <int C, int S>
+template <int C, int S, int PP, int WV>
 static int launch_bx3_t(const WnLayerArgs& a, hipStream_t s) {
-    using T = Bx3Tile<C, S>;
+    using T = Bx3Tile<C, S, PP, WV>;
     ProfileScope ps("wn_layer_bf16x3", s);
-    auto kern = wn_layer_bf16x3_kernel<C, S>;
     const size_t lds = (size_t)T::LDS_FLOATS * 4;
     static bool attr = false;
     if (!attr) {
-        DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DWS_HIP(hipFuncSetAttribute((const void*)wn_layer_bf16x3_kernel<C, S, PP, WV, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DWS_HIP(hipFuncSetAttribute((const void*)wn_layer_bf16x3_kernel<C, S, PP, WV, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.B * ceil_div(a.L, T::P)), dim3(512), lds, s, a);
+    const dim3 grid(a.B * ceil_div(a.L, T::P));
+    if ((a.L & 3) == 0)
+        hipLaunchKernelGGL((wn_layer_bf16x3_kernel<C, S, PP, WV, true>), grid, dim3(T::THREADS), lds, s, a);
+    else
+        hipLaunchKernelGGL((wn_layer_bf16x3_kernel<C, S, PP, WV, false>), grid, dim3(T::THREADS), lds, s, a);
     return DWS_OK;
 }
 
@@ -386,10 +553,12 @@ bool wn_layer_bf16x3_supported(int C, int S) {
 }
 
 int launch_wn_layer_bf16x3(int C, int S, const WnLayerArgs& a, hipStream_t s) {
-    if (C == 64 && S == 64) return launch_bx3_t<64, 64>(a, s);
-    if (C == 128 && S == 128) return launch_bx3_t<128, 128>(a, s);
-    if (C == 128 && S == 256) return launch_bx3_t<128, 256>(a, s);
-    if (C == 256 && S == 256) return launch_bx3_t<256, 256>(a, s);
+    // tile shape: 128 positions x 8 waves, one workgroup per CU.  (64 positions x 4 waves with two
+    // workgroups per CU measured 1.02 ms vs 0.79 ms per launch at C = S = 256: twice the weight traffic.)
+    if (C == 64 && S == 64) return launch_bx3_t<64, 64, 128, 8>(a, s);
+    if (C == 128 && S == 128) return launch_bx3_t<128, 128, 128, 8>(a, s);
+    if (C == 128 && S == 256) return launch_bx3_t<128, 256, 128, 8>(a, s);
+    if (C == 256 && S == 256) return launch_bx3_t<256, 256, 128, 8>(a, s);
     return set_error(DWS_ERR_UNSUPPORTED, "wn_layer_bf16x3: (C=%d,S=%d) not instantiated", C, S);
 }
 

@@ -60,6 +60,20 @@ def test_wavenet_bf16x3_precision_mode_matches_reference(gpu, name):
     print(f"{name}: bf16x3 rel err vs reference {err:.3e}")
 
 
+@pytest.mark.parametrize("L2,B2", [(1, 1), (63, 2), (129, 2), (1001, 1), (1024, 2)])
+def test_wavenet_bf16x3_ragged_lengths_match_oracle(gpu, L2, B2):
+    """Lengths that are not multiples of the 128-position tile / of 4 (scalar epilogue path)."""
+    cfg, B, L, wseed, iseed, _ = cases.WAVENET_CASES["wn_c64"]
+    net = cases.build_ours(cfg, wseed + 3).to(gpu)
+    net.set_option("precision", "bf16x3")
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    audio, steps = cases.wavenet_inputs(B2, L2, 1, iseed + L2)
+    with torch.no_grad():
+        ref = own.wavenet_forward(sd, cfg, audio, steps)
+        got = net((audio.to(gpu), steps.to(gpu)))
+    assert rel_err(got, ref) < REL_TOL / 10, (L2, B2)
+
+
 def test_bf16x3_rejected_where_not_built(gpu):
     net = cases.build_ours(cases.WAVENET_CASES["wn_tiny"][0], 1).to(gpu)
     with pytest.raises(NotImplementedError):
