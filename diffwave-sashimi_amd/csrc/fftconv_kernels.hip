@@ -79,16 +79,20 @@ __device__ __forceinline__ void fft16_regs(float2 (&x)[16]) {
     }
 }
 
-// One fused radix-4 pass over index bits (log2(s)+1, log2(s)); tw[k] = exp(-2 pi i k / M), k < M/2.
-template <int LOG2M, int THREADS, bool INV>
-__device__ __forceinline__ void radix4_pass(float2* __restrict__ X, const float2* __restrict__ tw, int log2s, int tid) {
+// One fused radix-4 pass over index bits (log2(s)+1, log2(s)).  Butterfly t uses W_{4s}^j, j = t mod s;
+// the caller supplies it from registers (w[i] for this thread's i-th butterfly): the twiddles of ALL
+// passes are fetched once at kernel start (radix4_twiddles) instead of one L2 round trip per pass.
+template <int LOG2M, int THREADS, bool INV, bool TOPPASS>
+__device__ __forceinline__ void radix4_pass(float2* __restrict__ X, const float2* __restrict__ tw, float2 wreg,
+                                            int log2s, int tid) {
     constexpr int M = 1 << LOG2M;
     const int s = 1 << log2s;
     const int twstep = M >> (log2s + 2);  // W_{4s}^j = tw[j * M/(4s)]
+#pragma unroll 1
     for (int t = tid; t < M / 4; t += THREADS) {
         const int j = t & (s - 1);
         const int base = ((t >> log2s) << (log2s + 2)) + j;
-        const float2 w1 = tw[j * twstep];
+        const float2 w1 = TOPPASS ? tw[j * twstep] : wreg;   // narrower passes: j = tid mod s, fetched at kernel start
         const float2 w2 = cmul_(w1, w1);
         float2 x0 = X[pidx(base)], x1 = X[pidx(base + s)], x2 = X[pidx(base + 2 * s)], x3 = X[pidx(base + 3 * s)];
         if (!INV) {
@@ -112,6 +116,27 @@ __device__ __forceinline__ void radix4_pass(float2* __restrict__ X, const float2
         X[pidx(base)] = x0; X[pidx(base + s)] = x1; X[pidx(base + 2 * s)] = x2; X[pidx(base + 3 * s)] = x3;
     }
 }
+
+// Register-resident twiddles of the narrower radix-4 passes.  With THREADS = M/16 a thread owns
+// butterflies t = tid + i*THREADS (i < 4).  In the widest pass (s = M/4 or M/8) j = t mod s differs per
+// i and is read from the table in the pass; in every narrower pass s <= THREADS, so j = tid mod s for
+// all i -> ONE value per pass, fetched once at kernel start and reused by forward and inverse.
+template <int LOG2M, int THREADS>
+struct FftTw {
+    static constexpr int M = 1 << LOG2M;
+    static constexpr bool ODD = ((LOG2M - 4) & 1) != 0;
+    static constexpr int TOP = LOG2M - (ODD ? 3 : 2);         // log2(s) of the widest radix-4 pass
+    static constexpr int NLOW = (TOP - 4) / 2;                // narrower passes: log2s = TOP-2, ..., 4
+    static constexpr int NBF = M / 4 / THREADS;
+    float2 wlow[NLOW > 0 ? NLOW : 1];
+    __device__ __forceinline__ void load(const float2* __restrict__ tw, int tid) {
+#pragma unroll
+        for (int p = 0; p < NLOW; ++p) {
+            const int log2s = TOP - 2 * (p + 1);
+            wlow[p] = tw[(tid & ((1 << log2s) - 1)) * (M >> (log2s + 2))];
+        }
+    }
+};
 
 template <int LOG2M, int THREADS, bool INV>
 __device__ __forceinline__ void radix2_top_pass(float2* __restrict__ X, const float2* __restrict__ tw, int tid) {
@@ -143,14 +168,18 @@ __device__ __forceinline__ void low16_pass(float2* __restrict__ X, int tid) {
 }
 
 template <int LOG2M, int THREADS>
-__device__ __forceinline__ void fft_forward(float2* X, const float2* tw, int tid) {
-    constexpr bool ODD = ((LOG2M - 4) & 1) != 0;
-    if (ODD) {
+__device__ __forceinline__ void fft_forward(float2* X, const float2* tw, const FftTw<LOG2M, THREADS>& W, int tid) {
+    using F = FftTw<LOG2M, THREADS>;
+    static_assert(F::NBF * THREADS * 4 == (1 << LOG2M), "one 16-point group per thread");
+    if (F::ODD) {
         radix2_top_pass<LOG2M, THREADS, false>(X, tw, tid);
         __syncthreads();
     }
-    for (int log2s = LOG2M - (ODD ? 3 : 2); log2s >= 4; log2s -= 2) {
-        radix4_pass<LOG2M, THREADS, false>(X, tw, log2s, tid);
+    radix4_pass<LOG2M, THREADS, false, true>(X, tw, make_float2(0.f, 0.f), F::TOP, tid);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < F::NLOW; ++p) {
+        radix4_pass<LOG2M, THREADS, false, false>(X, tw, W.wlow[p], F::TOP - 2 * (p + 1), tid);
         __syncthreads();
     }
     low16_pass<LOG2M, THREADS, false>(X, tid);
@@ -158,15 +187,18 @@ __device__ __forceinline__ void fft_forward(float2* X, const float2* tw, int tid
 }
 
 template <int LOG2M, int THREADS>
-__device__ __forceinline__ void fft_inverse(float2* X, const float2* tw, int tid) {
-    constexpr bool ODD = ((LOG2M - 4) & 1) != 0;
+__device__ __forceinline__ void fft_inverse(float2* X, const float2* tw, const FftTw<LOG2M, THREADS>& W, int tid) {
+    using F = FftTw<LOG2M, THREADS>;
     low16_pass<LOG2M, THREADS, true>(X, tid);
     __syncthreads();
-    for (int log2s = 4; log2s <= LOG2M - (ODD ? 3 : 2); log2s += 2) {
-        radix4_pass<LOG2M, THREADS, true>(X, tw, log2s, tid);
+#pragma unroll
+    for (int p = F::NLOW - 1; p >= 0; --p) {
+        radix4_pass<LOG2M, THREADS, true, false>(X, tw, W.wlow[p], F::TOP - 2 * (p + 1), tid);
         __syncthreads();
     }
-    if (ODD) {
+    radix4_pass<LOG2M, THREADS, true, true>(X, tw, make_float2(0.f, 0.f), F::TOP, tid);
+    __syncthreads();
+    if (F::ODD) {
         radix2_top_pass<LOG2M, THREADS, true>(X, tw, tid);
         __syncthreads();
     }
@@ -184,7 +216,9 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
                                                 const float2* __restrict__ kfa, const float2* __restrict__ kfb,
                                                 const float2* __restrict__ kfs, int tid) {
     constexpr int M = 1 << LOG2M;
-    for (int q = tid; q < M / 2; q += THREADS) {
+#pragma unroll 1
+    for (int it = 0; it < M / 2 / THREADS; ++it) {
+        const int q = tid + it * THREADS;
         const int p = 2 * q;
         if (q == 0) {
             // k = 0 (self-paired, carries DC and Nyquist) and k = M/2 (position 1, self-paired)
@@ -225,13 +259,15 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     const int h = row / a.B, b = row % a.B;
     const int L = a.L, Lc = L / 2;  // L even
     const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
+    FftTw<LOG2M, THREADS> W;
+    W.load(a.tw, tid);
     for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
     __syncthreads();
-    fft_forward<LOG2M, THREADS>(X, a.tw, tid);
+    fft_forward<LOG2M, THREADS>(X, a.tw, W, tid);
     pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
                                     a.kfs + (size_t)h * 3, tid);
     __syncthreads();
-    fft_inverse<LOG2M, THREADS>(X, a.tw, tid);
+    fft_inverse<LOG2M, THREADS>(X, a.tw, W, tid);
     const float scale = 1.f / (float)M, Dh = a.D[h];
     float2* __restrict__ g2 = reinterpret_cast<float2*>(a.g + ((size_t)b * a.H + h) * L);
     for (int j = tid; j < Lc; j += THREADS) {
@@ -250,9 +286,11 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float2 X[];
     const int tid = threadIdx.x, h = blockIdx.x;
     const float2* __restrict__ r2 = reinterpret_cast<const float2*>(in + (size_t)h * 2 * M);
+    FftTw<LOG2M, THREADS> W;
+    W.load(tw, tid);
     for (int j = tid; j < M; j += THREADS) X[pidx(j)] = r2[j];
     __syncthreads();
-    fft_forward<LOG2M, THREADS>(X, tw, tid);
+    fft_forward<LOG2M, THREADS>(X, tw, W, tid);
     float2* __restrict__ o = out + (size_t)h * (M + 1);
     for (int k = tid; k <= M / 2; k += THREADS) {
         if (k == 0) {
@@ -305,7 +343,7 @@ __global__ void kf_permute_kernel(const float2* __restrict__ kf, float2* __restr
 template <int LOG2M>
 struct FcCfg {
     static constexpr int M = 1 << LOG2M;
-    static constexpr int THREADS = (M / 16 > 1024) ? 1024 : (M / 16 < 64 ? 64 : M / 16);
+    static constexpr int THREADS = M / 16;   // one 16-point group / four radix-4 butterflies per thread
     static constexpr size_t LDS = (size_t)(M + M / 16) * 8;
 };
 
@@ -313,7 +351,8 @@ bool fftconv_supported(int L, int* log2m) {
     if (L < 16 || (L & 1)) return false;
     int lg = 4;
     while ((1 << lg) < L) ++lg;  // M = Nf/2 >= L  <=>  Nf >= 2L
-    if (lg < 6 || lg > 14) return false;
+    if (lg < 10) lg = 10;               // smaller rows still use M = 1024 (one wave); the padding is zeros
+    if (lg > 14) return false;
     if (log2m) *log2m = lg;
     return true;
 }
@@ -347,10 +386,6 @@ static int launch_rf(const float* in, float* out, const float* tw, const float* 
 
 #define DWS_FC_DISPATCH(FN, ...)                                                        \
     switch (log2m) {                                                                    \
-        case 6: return FN<6>(__VA_ARGS__);                                              \
-        case 7: return FN<7>(__VA_ARGS__);                                              \
-        case 8: return FN<8>(__VA_ARGS__);                                              \
-        case 9: return FN<9>(__VA_ARGS__);                                              \
         case 10: return FN<10>(__VA_ARGS__);                                            \
         case 11: return FN<11>(__VA_ARGS__);                                            \
         case 12: return FN<12>(__VA_ARGS__);                                            \
