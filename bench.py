@@ -51,6 +51,13 @@ CONFIGS = {
                    diffusion_step_embed_dim_out=512, unet=True, d_model=64, n_layers=6, pool=[4, 4],
                    expand=2, ff=2, L=16000),
         diffusion=dict(T=200, beta_0=1e-4, beta_T=0.02), B=16, L=16000),
+    # sampling with the architecture of BASELINE.json configs[4] (unet_d128_n6; README.md:215 samples it at B=128/GPU)
+    "unet_d128_n6_T200": dict(
+        model=dict(_name_="sashimi", unconditional=True, in_channels=1, out_channels=1,
+                   diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512,
+                   diffusion_step_embed_dim_out=512, unet=True, d_model=128, n_layers=6, pool=[4, 4],
+                   expand=2, ff=2, L=16000),
+        diffusion=dict(T=200, beta_0=1e-4, beta_T=0.02), B=16, L=16000),
     # BASELINE.json configs[3] (mel conditioner installed once per utterance)
     "unet_d32_n6_T50_cond": dict(
         model=dict(_name_="sashimi", unconditional=False, in_channels=1, out_channels=1,

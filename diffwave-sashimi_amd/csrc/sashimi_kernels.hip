@@ -140,7 +140,8 @@ __global__ void ln_kernel(const float* __restrict__ x, const float* __restrict__
 }
 
 // Same op, one HBM pass: a block owns 64 positions x all H channels; thread (col, part) keeps
-// its H/4 values of column `col` in registers (H <= 256), partial sums meet in LDS.
+// its H/4 values of column `col` in registers (H <= 512), partial sums meet in LDS.
+template <int RPT>   // rows (channels) held per thread: H <= 4 * RPT
 __global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ m_p,
                                                       const float* __restrict__ s_p, const float* __restrict__ part_t,
                                                       int pt_bstride, float* __restrict__ out, int H, int L,
@@ -150,10 +151,10 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ 
     const int l = blockIdx.x * 64 + col;
     const bool ok = l < L;
     const float* __restrict__ xb = x + (size_t)b * H * L + (ok ? l : 0);
-    float v[64];
+    float v[RPT];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < RPT; ++i) {
         const int h = i * 4 + part;
         v[i] = (h < H) ? xb[(size_t)h * L] : 0.f;
         sum += v[i];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ 
     const float mean = (red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]) / (float)H;
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < RPT; ++i) {
         const int h = i * 4 + part;
         const float d = (h < H) ? v[i] - mean : 0.f;
         var = fmaf(d, d, var);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ 
     const float shift = m_p[0] - mean;
     float* __restrict__ ob = out + (size_t)b * H * ostride + l;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < RPT; ++i) {
         const int h = i * 4 + part;
         if (h < H && ok) {
             float y = scale * (v[i] + shift);
@@ -188,9 +189,15 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ 
 int launch_ln(const float* x, const float* m_p, const float* s_p, const float* part_t, int pt_bstride, float* out,
               int B, int H, int L, size_t ostride, hipStream_t s) {
     ProfileScope ps("ln_kernel", s);
-    if (H <= 256)
-        hipLaunchKernelGGL(ln_tile_kernel, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, m_p, s_p, part_t, pt_bstride,
-                           out, H, L, ostride);
+    if (H <= 128)
+        hipLaunchKernelGGL(ln_tile_kernel<32>, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, m_p, s_p, part_t,
+                           pt_bstride, out, H, L, ostride);
+    else if (H <= 256)
+        hipLaunchKernelGGL(ln_tile_kernel<64>, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, m_p, s_p, part_t,
+                           pt_bstride, out, H, L, ostride);
+    else if (H <= 512)
+        hipLaunchKernelGGL(ln_tile_kernel<128>, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, m_p, s_p, part_t,
+                           pt_bstride, out, H, L, ostride);
     else
         hipLaunchKernelGGL(ln_kernel, dim3(ceil_div(L, 64), B), dim3(64), 0, s, x, m_p, s_p, part_t, pt_bstride, out,
                            H, L, ostride);

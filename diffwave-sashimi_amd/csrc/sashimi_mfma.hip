@@ -266,7 +266,9 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     return DWS_OK;
 }
 
-bool s4_tail_mfma_supported(int H, int ff) { return ff == 2 && (H == 32 || H == 64 || H == 128 || H == 256); }
+bool s4_tail_mfma_supported(int H, int ff) {
+    return ff == 2 && (H == 32 || H == 64 || H == 128 || H == 256 || H == 512);
+}
 
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     switch (H) {
@@ -274,6 +276,7 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
         case 64: return launch_tail_t<64, 2, 2, 2>(a, s);
         case 128: return launch_tail_t<128, 4, 1, 2>(a, s);
         case 256: return launch_tail_t<256, 8, 1, 2>(a, s);
+        case 512: return launch_tail_t<512, 16, 1, 1>(a, s);  // 32 positions x 16 waves: the tiles fill 139 KB of LDS
     }
     return set_error(DWS_ERR_UNSUPPORTED, "s4_tail_mfma: H=%d not instantiated", H);
 }
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     int mt[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) mt[m] = wave * MT + m;
+    for (int m = 0; m < MT; ++m) mt[m] = blockIdx.y * (4 * MT) + wave * MT + m;   // grid.y walks 128*MT-row blocks of M
     const float4* A = reinterpret_cast<const float4*>(a.A);
 
     stage_load(0);
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
 }
 
 bool pw_mfma_supported(int mode, int K, int M, int p) {
-    if (K % 64 != 0 || (M != 128 && M != 256 && M != 512)) return false;
+    if (K % 64 != 0 || (M != 128 && M != 256 && M % 512 != 0)) return false;
     if (mode == 0) return p >= 1 && 64 % p == 0;
     return p == 4;
 }
@@ -415,7 +418,7 @@ static int launch_pw_mode(const PwMfmaArgs& a, hipStream_t s) {
     const int grid = a.B * ceil_div(a.L, 64);
     if (a.M == 128) hipLaunchKernelGGL((pw_mfma_kernel<1, MODE>), dim3(grid), dim3(256), 0, s, a);
     else if (a.M == 256) hipLaunchKernelGGL((pw_mfma_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((pw_mfma_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pw_mfma_kernel<4, MODE>), dim3(grid, a.M / 512), dim3(256), 0, s, a);
     return DWS_OK;
 }
 

@@ -59,6 +59,8 @@ SASHIMI_CASES = {
     "ss_knobs": (ss_cfg(d_model=6, n_layers=1, L=250, pool=[2], expand=3, ff=1, diffusion_step_embed_dim_mid=64), 3, 131, 132, True),
     # channel counts of BASELINE config 3 (H = 64/128/256), shortened
     "ss_d64_short": (ss_cfg(d_model=64, n_layers=2, L=1024), 2, 141, 142, False),
+    # channel counts of BASELINE config 5 (unet_d128: H = 128/256/512), shortened
+    "ss_d128_short": (ss_cfg(d_model=128, n_layers=1, L=1024), 1, 181, 182, False),
     # BASELINE config 3 architecture: unet_d64_n6 pool[4,4] ff2, L=16000, at B=1
     "ss_unet_d64": (ss_cfg(d_model=64, n_layers=6, L=16000), 1, 151, 152, False),
 }
