@@ -1,0 +1,166 @@
+"""Data-parallel gradient exchange with the reference's surface
+(``distributed_util.py:44-48,50-60,97-149``): ``init_distributed``,
+``apply_gradient_allreduce(module)``, ``reduce_tensor``.
+
+Re-designed for one process per MI355X over RCCL/xGMI instead of translating
+the reference's pattern:
+
+* initial weight sync is ONE flattened broadcast per dtype (the reference issues
+  one broadcast per state_dict tensor: 686 for SaShiMi, ``distributed_util.py:107-110``);
+* gradients are averaged in fixed-size flat buckets filled in reverse
+  registration order, each all-reduced asynchronously the moment its last
+  gradient has been accumulated, i.e. overlapped with the rest of backward
+  (the reference flattens everything and does one blocking all-reduce after
+  backward, ``:112-142``).  xGMI is point-to-point (7 links x ~153 GB/s), so a
+  ring all-reduce is per-link bound: several ~25 MB buckets in flight keep all
+  links busy while backward still runs; a single 94 MB buffer cannot overlap at all.
+* the end-of-backward callback only waits for the outstanding buckets, divides
+  by the world size and hands the views back.
+
+Backend "nccl" is RCCL on ROCm; the CPU tests use "gloo".
+"""
+import torch
+import torch.distributed as dist
+from torch.autograd import Variable
+
+DEFAULT_BUCKET_BYTES = 25 * 1024 * 1024
+
+
+def reduce_tensor(tensor, num_gpus):
+    """Mean over ranks (``distributed_util.py:44-48``); used for loss logging (``train.py:135``)."""
+    rt = tensor.clone()
+    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    rt /= num_gpus
+    return rt
+
+
+def init_distributed(rank, num_gpus, group_name, dist_backend, dist_url):
+    """``distributed_util.py:50-60`` (``group_name`` is accepted and ignored: current
+    torch has no such argument).  Pins the process to its GPU when there is one."""
+    if torch.cuda.is_available():
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+    dist.init_process_group(dist_backend, init_method=dist_url, world_size=num_gpus, rank=rank)
+
+
+def _real_view(t):
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
+def broadcast_state(module, src=0):
+    """One flattened broadcast per dtype of every tensor in ``state_dict()``."""
+    groups = {}
+    for t in module.state_dict().values():
+        if torch.is_tensor(t):
+            groups.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), tensors in groups.items():
+        views = [_real_view(t.data) for t in tensors]
+        flat = torch.cat([v.reshape(-1) for v in views]) if len(views) > 1 else views[0].reshape(-1).clone()
+        dist.broadcast(flat, src)
+        off = 0
+        for v in views:
+            n = v.numel()
+            v.copy_(flat[off:off + n].view_as(v))
+            off += n
+
+
+class _Bucket:
+    def __init__(self, params, device, dtype):
+        self.params = params
+        self.numel = sum(_real_view(p).numel() for p in params)
+        self.flat = torch.zeros(self.numel, device=device, dtype=dtype)
+        self.offsets = []
+        off = 0
+        for p in params:
+            n = _real_view(p).numel()
+            self.offsets.append((off, n))
+            off += n
+        self.pending = len(params)
+        self.ready = set()
+        self.work = None
+
+
+class GradientAllReducer:
+    """Bucketed, backward-overlapped gradient averaging for data-parallel training."""
+
+    def __init__(self, module, bucket_bytes=DEFAULT_BUCKET_BYTES, sync_state=True):
+        self.module = module
+        self.world = dist.get_world_size()
+        if sync_state:
+            broadcast_state(module, 0)
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.buckets, self.where = [], {}
+        cur, cur_bytes, cur_key = [], 0, None
+        # reverse registration order ~ the order gradients become available in backward
+        for p in reversed(params):
+            key = (_real_view(p).dtype, p.device)
+            nbytes = _real_view(p).numel() * _real_view(p).element_size()
+            if cur and (key != cur_key or cur_bytes + nbytes > bucket_bytes):
+                self._close(cur, cur_key)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+            cur_key = key
+        if cur:
+            self._close(cur, cur_key)
+        self._callback_queued = False
+        self._handles = []
+        for p in params:
+            self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _close(self, params, key):
+        b = _Bucket(list(params), key[1], key[0])
+        for i, p in enumerate(params):
+            self.where[p] = (len(self.buckets), i)
+        self.buckets.append(b)
+
+    def _launch(self, b):
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._callback_queued:
+            self._callback_queued = True
+            Variable._execution_engine.queue_callback(self._finalize)
+        bi, pi = self.where[p]
+        b = self.buckets[bi]
+        if pi in b.ready:       # gradient accumulated twice in one backward: re-copy, do not recount
+            pass
+        off, n = b.offsets[pi]
+        b.flat[off:off + n].copy_(_real_view(p.grad).reshape(-1))
+        if pi not in b.ready:
+            b.ready.add(pi)
+            b.pending -= 1
+            if b.pending == 0:
+                self._launch(b)
+
+    def _finalize(self):
+        # Buckets with parameters that got no gradient this backward: every rank has the same graph,
+        # so every rank reaches this point with the same set; missing slots contribute zeros.
+        for b in self.buckets:
+            if b.work is None and b.ready:
+                for pi, p in enumerate(b.params):
+                    if pi not in b.ready:
+                        off, n = b.offsets[pi]
+                        b.flat[off:off + n].zero_()
+                self._launch(b)
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.flat /= self.world
+                for pi, p in enumerate(b.params):
+                    if pi in b.ready and p.grad is not None:
+                        off, n = b.offsets[pi]
+                        _real_view(p.grad).copy_(b.flat[off:off + n].view_as(_real_view(p.grad)))
+            b.work, b.pending, b.ready = None, len(b.params), set()
+        self._callback_queued = False
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def apply_gradient_allreduce(module, bucket_bytes=DEFAULT_BUCKET_BYTES):
+    """``distributed_util.py:97-149``: returns the SAME module, now averaging its gradients over
+    the process group during ``backward()``."""
+    module._dws_grad_reducer = GradientAllReducer(module, bucket_bytes=bucket_bytes)
+    return module
