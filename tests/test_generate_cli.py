@@ -1,0 +1,139 @@
+"""The generate.py-compatible driver: config composition, run-directory naming (CPU) and an
+end-to-end run through the HIP sampler (GPU)."""
+import os
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+
+def _tree(tmp_path):
+    """A config tree with the Hydra features the reference's configs/ uses
+    (`configs/config.yaml:1-31`, `experiment/*.yaml`, `model/sashimi.yaml:14`)."""
+    w = lambda rel, txt: (os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True),
+                          (tmp_path / rel).write_text(textwrap.dedent(txt)))
+    w("config.yaml", """\
+        defaults:
+          - _self_
+          - experiment: sc09
+        generate:
+          ckpt_iter: max
+          n_samples: 16
+          batch_size: null
+          mel_name: null
+        """)
+    w("experiment/sc09.yaml", """\
+        # @package _global_
+        defaults:
+          - /model: sashimi
+          - /dataset: sc09
+        diffusion:
+          T: 200
+          beta_0: 0.0001
+          beta_T: 0.02
+          beta: null
+        """)
+    w("experiment/lj.yaml", """\
+        # @package _global_
+        defaults:
+          - /model: sashimi
+          - /dataset: lj
+        diffusion: {T: 50, beta_0: 0.0001, beta_T: 0.05, beta: null}
+        generate: {mel_name: LJ001-0001, n_samples: 2}
+        model: {unconditional: false, mel_upsample: [16, 16]}
+        """)
+    w("model/sashimi.yaml", """\
+        _name_: sashimi
+        unconditional: true
+        unet: true
+        d_model: 64
+        n_layers: 6
+        pool: [4, 4]
+        expand: 2
+        ff: 2
+        L: ${dataset.segment_length}
+        """)
+    w("model/wavenet.yaml", """\
+        _name_: wavenet
+        unconditional: true
+        res_channels: 128
+        skip_channels: 256
+        num_res_layers: 30
+        dilation_cycle: 10
+        """)
+    w("dataset/sc09.yaml", "_name_: sc09\nsegment_length: 16000\nsampling_rate: 16000\n")
+    w("dataset/lj.yaml", "_name_: ljspeech\nsegment_length: 16000\nsampling_rate: 22050\nhop_length: 256\n")
+    return str(tmp_path)
+
+
+def test_config_composition_like_hydra(tmp_path):
+    from diffwave_sashimi_amd.generate import load_config
+    d = _tree(tmp_path)
+    cfg = load_config(d)
+    assert cfg["model"]["_name_"] == "sashimi" and cfg["model"]["L"] == 16000     # ${dataset.segment_length}
+    assert cfg["diffusion"]["T"] == 200 and cfg["generate"]["n_samples"] == 16
+    cfg = load_config(d, ["model=wavenet", "generate.n_samples=4", "generate.ckpt_iter=500000"])
+    assert cfg["model"]["_name_"] == "wavenet" and cfg["model"]["res_channels"] == 128
+    assert cfg["generate"]["n_samples"] == 4 and cfg["generate"]["ckpt_iter"] == 500000
+    cfg = load_config(d, ["experiment=lj"])
+    assert cfg["model"]["unconditional"] is False and cfg["model"]["mel_upsample"] == [16, 16]
+    assert cfg["dataset"]["hop_length"] == 256 and cfg["diffusion"]["T"] == 50
+    assert cfg["generate"]["mel_name"] == "LJ001-0001" and cfg["generate"]["n_samples"] == 2
+    assert cfg["generate"]["ckpt_iter"] == "max"                                 # untouched root key survives
+    cfg = load_config(d, ["experiment=lj", "model=wavenet"])
+    assert cfg["model"]["_name_"] == "wavenet" and cfg["model"]["unconditional"] is False
+
+
+def test_run_directory_names_match_the_reference_layout():
+    """Names of the reference's shipped run dirs (`exp/`): wnet_h128_d30_T200_betaT0.02_uncond,
+    unet_d64_n6_pool_2_expand2_ff2_T200_betaT0.02_uncond, ..._L16000_hop256_cond (`utils.py:96-108`)."""
+    from diffwave_sashimi_amd.generate import find_max_epoch, local_path_name
+    wn = dict(cases.WN_BASE, res_channels=128, skip_channels=256, num_res_layers=30, dilation_cycle=10)
+    diff = dict(T=200, beta_0=1e-4, beta_T=0.02)
+    assert local_path_name(None, wn, diff, {}) == "wnet_h128_d30_T200_betaT0.02_uncond"
+    ss = cases.ss_cfg(d_model=64, n_layers=6, L=16000)
+    assert local_path_name("", ss, diff, {}) == "unet_d64_n6_pool_2_expand2_ff2_T200_betaT0.02_uncond"
+    ssc = cases.ss_cfg(d_model=32, n_layers=6, L=16000, unconditional=False)
+    lj = dict(segment_length=16000, hop_length=256)
+    assert (local_path_name("run1", ssc, dict(T=50, beta_T=0.05), lj)
+            == "run1_unet_d32_n6_pool_2_expand2_ff2_T50_betaT0.05_L16000_hop256_cond")
+
+
+def test_find_max_epoch(tmp_path):
+    from diffwave_sashimi_amd.generate import find_max_epoch
+    for f in ("1000.pkl", "250000.pkl", "notes.txt", "x.pkl", "30.pkl"):
+        (tmp_path / f).write_text("")
+    assert find_max_epoch(str(tmp_path)) == 250000
+    os.makedirs(tmp_path / "empty")
+    assert find_max_epoch(str(tmp_path / "empty")) == -1
+
+
+@pytest.mark.gpu
+def test_generate_end_to_end_from_a_checkpoint(tmp_path, gpu):
+    """Checkpoint ingest (`generate.py:105-112`) -> hipGraph sampler -> float32 wavs named like the reference."""
+    from scipy.io import wavfile
+    from diffwave_sashimi_amd.generate import generate, local_path_name
+    cfg, B, L, wseed, iseed, _ = cases.WAVENET_CASES["wn_c64"]
+    diff = dict(T=5, beta_0=1e-4, beta_T=0.05, beta=None)
+    ds = dict(_name_="sc09", segment_length=640, sampling_rate=16000)
+    root = str(tmp_path / "exp")
+    run = local_path_name(None, cfg, diff, ds)
+    os.makedirs(os.path.join(root, run, "checkpoint"))
+    src = cases.build_ours(cfg, wseed)
+    torch.save({"model_state_dict": src.state_dict()}, os.path.join(root, run, "checkpoint", "2000.pkl"))
+    torch.save({"model_state_dict": src.state_dict()}, os.path.join(root, run, "checkpoint", "1000.pkl"))
+    audio = generate(1, diff, dict(cfg), ds, ckpt_iter="max", n_samples=4, batch_size=2, exp_root=root, seed=11)
+    assert audio.shape == (4, 1, 640) and torch.isfinite(audio).all()
+    outdir = os.path.join(root, run, "waveforms", "2000")
+    files = sorted(os.listdir(outdir))
+    assert files == ["2k_4.wav", "2k_5.wav", "2k_6.wav", "2k_7.wav"]              # n_samples*rank + i, rank 1
+    sr, w = wavfile.read(os.path.join(outdir, "2k_4.wav"))
+    assert sr == 16000 and w.dtype == np.float32 and w.shape == (640,)
+    assert np.array_equal(w, audio[0, 0].cpu().numpy())
+    again = generate(1, diff, dict(cfg), ds, ckpt_iter=2000, n_samples=4, batch_size=2, exp_root=root, seed=11)
+    assert torch.equal(audio, again)                                               # seeded -> reproducible
+    with pytest.raises(Exception, match="No valid model found"):
+        generate(0, diff, dict(cfg), ds, ckpt_iter=3000, n_samples=2, exp_root=root)
