@@ -32,6 +32,25 @@ dws::ParamSpec* dws_model::add_param(const std::string& name, std::vector<int64_
     return p;
 }
 
+int dws_model::forward_train(const float*, const float*, float*, hipStream_t) {
+    return dws::set_error(DWS_ERR_UNSUPPORTED, "the training forward/backward of this backbone is not built yet");
+}
+
+int dws_model::backward(const float*, hipStream_t) {
+    return dws::set_error(DWS_ERR_UNSUPPORTED, "the training forward/backward of this backbone is not built yet");
+}
+
+float* dws_model::G(const std::string& name) {
+    auto it = index.find(name);
+    if (it == index.end()) return nullptr;
+    dws::ParamSpec* p = params[it->second];
+    if (!p->grad.p) {
+        if (p->grad.ensure(p->nbytes()) != DWS_OK) return nullptr;
+        hipMemset(p->grad.p, 0, p->nbytes());
+    }
+    return p->grad.f();
+}
+
 int dws_model::set_option(const std::string& key, const std::string& value) {
     return dws::set_error(DWS_ERR_INVALID, "unknown option %s=%s for this model", key.c_str(), value.c_str());
 }
@@ -149,6 +168,29 @@ int dws_model_set_condition(dws_model* m, const float* mel, int64_t Bm, int64_t 
 int dws_model_forward(dws_model* m, const float* audio, const float* steps, float* out, void* stream) {
     DWS_CHECK(m && audio && steps && out, DWS_ERR_INVALID, "dws_model_forward: null argument");
     return m->forward(audio, steps, out, (hipStream_t)stream);
+}
+
+int dws_model_forward_train(dws_model* m, const float* audio, const float* steps, float* out, void* stream) {
+    DWS_CHECK(m && audio && steps && out, DWS_ERR_INVALID, "dws_model_forward_train: null argument");
+    return m->forward_train(audio, steps, out, (hipStream_t)stream);
+}
+
+int dws_model_backward(dws_model* m, const float* dout, void* stream) {
+    DWS_CHECK(m && dout, DWS_ERR_INVALID, "dws_model_backward: null argument");
+    return m->backward(dout, (hipStream_t)stream);
+}
+
+int dws_model_get_grad(dws_model* m, const char* name, float* dst, int64_t numel, void* stream) {
+    DWS_CHECK(m && name && dst, DWS_ERR_INVALID, "dws_model_get_grad: null argument");
+    auto it = m->index.find(name);
+    DWS_CHECK(it != m->index.end(), DWS_ERR_INVALID, "unknown parameter '%s'", name);
+    dws::ParamSpec* p = m->params[it->second];
+    DWS_CHECK(p->dtype == 0 && (int64_t)p->numel() == numel, DWS_ERR_INVALID, "'%s': grad has %zu elements, got %lld", name,
+              p->numel(), (long long)numel);
+    float* g = m->G(name);
+    DWS_CHECK(g, DWS_ERR_HIP, "could not allocate the gradient of '%s'", name);
+    DWS_HIP(hipMemcpyAsync(dst, g, p->nbytes(), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DWS_OK;
 }
 
 int dws_model_read_tap(dws_model* m, const char* tap, float* dst, int64_t capacity, void* stream) {

@@ -39,6 +39,7 @@ struct ParamSpec {
     std::vector<int64_t> shape;
     int dtype = 0;  // 0 float32, 1 int64
     DevBuf buf;     // raw copy of the state-dict tensor
+    DevBuf grad;    // gradient w.r.t. the raw tensor (training path; allocated on first backward)
     size_t numel() const {
         size_t n = 1;
         for (auto s : shape) n *= (size_t)s;
@@ -84,6 +85,10 @@ struct dws_model {
     virtual int set_condition(const float* mel, int64_t Bm, int64_t Tmel, hipStream_t s) = 0;
     virtual int forward(const float* audio, const float* steps, float* out, hipStream_t s) = 0;
     virtual int read_tap(const char* tap, float* dst, int64_t capacity, hipStream_t s) = 0;
+    // training path: forward that keeps what backward needs; backward fills ParamSpec::grad of every parameter
+    virtual int forward_train(const float* audio, const float* steps, float* out, hipStream_t s);
+    virtual int backward(const float* dout, hipStream_t s);
+    float* G(const std::string& name);  // gradient buffer of a parameter (allocated, zeroed on first use)
 };
 
 namespace dws {

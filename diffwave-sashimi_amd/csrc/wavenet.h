@@ -23,6 +23,7 @@ struct WnLayerArgs {
     const float* melc;     // nullable: conditioner term [Bm, 2C, L] of this layer
     int mel_bstride;       // 0: broadcast batch-1 mel, 1: per-batch
     float* gate_ws;        // generic path scratch [B, C, L]
+    float* hsave;          // nullable (training): pre-gate activations H of this layer [B, 2C, L]
     int B, L, dilation, first_layer, last_layer;
 };
 
@@ -44,7 +45,7 @@ int launch_permute_dconv(const float* w, float* out, int C, int KC, hipStream_t 
 int launch_pack_a_frag(const float* w, float* out, int M, int K, hipStream_t s);
 int launch_step_embed(const float* steps, const float* freq, float* emb, int B, int half, hipStream_t s);
 int launch_linear_rows(const float* in, const float* W, const float* bias, float* out, int B, int K, int O,
-                       int act, hipStream_t s);
+                       int act, hipStream_t s, float* pre_out = nullptr);
 int launch_init_conv(const float* audio, const float* W, const float* bias, float* x, int B, int Cin, int C, int L,
                      hipStream_t s);
 int launch_wn_bias_tap(const float* Wd_all, const float* part_t, float* Abt, int NL, int B, int C, hipStream_t s);

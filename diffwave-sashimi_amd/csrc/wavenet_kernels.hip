@@ -109,7 +109,8 @@ int launch_step_embed(const float* steps, const float* freq, float* emb, int B, 
 // act: 0 = identity, 1 = swish (`wavenet.py:10-11`).
 template <int ACT>
 __global__ void linear_rows_kernel(const float* __restrict__ in, const float* __restrict__ W,
-                                   const float* __restrict__ bias, float* __restrict__ out, int B, int K, int O) {
+                                   const float* __restrict__ bias, float* __restrict__ out, int B, int K, int O,
+                                   float* __restrict__ pre_out) {
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (o >= O) return;
@@ -132,6 +133,7 @@ __global__ void linear_rows_kernel(const float* __restrict__ in, const float* __
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         if (lane == 0) {
             float y = acc + bo;
+            if (pre_out) pre_out[(size_t)b * O + o] = y;   // training: pre-activation for the swish adjoint
             if (ACT == 1) y = y / (1.f + expf(-y));
             out[(size_t)b * O + o] = y;
         }
@@ -139,13 +141,13 @@ __global__ void linear_rows_kernel(const float* __restrict__ in, const float* __
 }
 
 int launch_linear_rows(const float* in, const float* W, const float* bias, float* out, int B, int K, int O,
-                       int act, hipStream_t s) {
+                       int act, hipStream_t s, float* pre_out) {
     DWS_CHECK(K <= 1024, DWS_ERR_UNSUPPORTED, "linear_rows: K=%d > 1024 not supported", K);
     dim3 grid(ceil_div(O, 4)), block(256);
     if (act == 1)
-        hipLaunchKernelGGL(linear_rows_kernel<1>, grid, block, 0, s, in, W, bias, out, B, K, O);
+        hipLaunchKernelGGL(linear_rows_kernel<1>, grid, block, 0, s, in, W, bias, out, B, K, O, pre_out);
     else
-        hipLaunchKernelGGL(linear_rows_kernel<0>, grid, block, 0, s, in, W, bias, out, B, K, O);
+        hipLaunchKernelGGL(linear_rows_kernel<0>, grid, block, 0, s, in, W, bias, out, B, K, O, pre_out);
     return DWS_OK;
 }
 
@@ -352,6 +354,13 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
                         hs += melb[(size_t)(C + ch) * L + pos];
                     }
                 }
+                if (a.hsave) {  // training: keep the pre-activations for the gate adjoint
+                    const int pos = l0 + col;
+                    if (pos < L) {
+                        a.hsave[((size_t)b * 2 * C + ch) * L + pos] = ht;
+                        a.hsave[((size_t)b * 2 * C + C + ch) * L + pos] = hs;
+                    }
+                }
                 gt[ch * P + col] = fast_tanh(ht) * fast_sigmoid(hs);
             }
         }
@@ -544,6 +553,10 @@ __global__ void wn_gate_generic_kernel(WnLayerArgs a, int C) {
         if (melb) {
             ht += melb[(size_t)c * L + l];
             hs += melb[(size_t)(C + c) * L + l];
+        }
+        if (a.hsave) {
+            a.hsave[((size_t)b * 2 * C + c) * L + l] = ht;
+            a.hsave[((size_t)b * 2 * C + C + c) * L + l] = hs;
         }
         a.gate_ws[((size_t)b * C + c) * L + l] = tanhf(ht) * sigmoidf_(hs);
     }

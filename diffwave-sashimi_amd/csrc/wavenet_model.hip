@@ -6,6 +6,7 @@
 #include "conditioner.h"
 #include "model.h"
 #include "wavenet.h"
+#include "wavenet_backward.h"
 
 namespace dws {
 
@@ -30,6 +31,11 @@ struct WaveNetModel : dws_model {
     int64_t melBm = 0;               // 0 = no condition installed
     // workspace
     DevBuf x0, x1, skip, gate, emb, h1, h2, part_t, scratch_out;
+    // training workspace: per-layer inputs and pre-gate activations, saved pre-activations of the
+    // embedding MLP, gradient scratch
+    std::vector<DevBuf> tx, tH;
+    DevBuf ty, ta1, ta2, dxa, dxb, dskip, dgb, dHb, dresb, dyb, dWfold, dpt, dh2, dh1, demb, dWt_all, dbt_all;
+    bool trained_fwd = false;
 
     explicit WaveNetModel(const dws_model_desc& dd) {
         d = dd;
@@ -219,22 +225,48 @@ struct WaveNetModel : dws_model {
     }
 
     int forward(const float* audio, const float* steps, float* out, hipStream_t s) override {
+        trained_fwd = false;
+        return run_forward(audio, steps, out, false, s);
+    }
+
+    int forward_train(const float* audio, const float* steps, float* out, hipStream_t s) override {
+        DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
+        DWS_CHECK(!bf16x3, DWS_ERR_UNSUPPORTED, "training runs with precision=f32 (bf16x3 backward is not built)");
+        DWS_CHECK(melBm == 0, DWS_ERR_UNSUPPORTED, "training of the mel-conditional path is not built yet");
+        const size_t act = (size_t)B * C * L * 4;
+        tx.resize(NL + 1); tH.resize(NL);
+        for (int n = 0; n <= NL; ++n) DWS_TRY(tx[n].ensure(act));
+        for (int n = 0; n < NL; ++n) DWS_TRY(tH[n].ensure(2 * act));
+        DWS_TRY(ty.ensure((size_t)B * S * L * 4));
+        DWS_TRY(ta1.ensure((size_t)B * Emid * 4));
+        DWS_TRY(ta2.ensure((size_t)B * Eout * 4));
+        DWS_TRY(run_forward(audio, steps, out, true, s));
+        train_audio = audio;
+        trained_fwd = true;
+        return DWS_OK;
+    }
+
+    const float* train_audio = nullptr;
+
+    int run_forward(const float* audio, const float* steps, float* out, bool train, hipStream_t s) {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
         if (dirty) DWS_TRY(commit(s));
-        DWS_TRY(launch_init_conv(audio, Wi.f(), P("init_conv.0.conv.bias"), x0.f(), (int)B, Cin, C, (int)L, s));
+        float* xfirst = train ? tx[0].f() : x0.f();
+        DWS_TRY(launch_init_conv(audio, Wi.f(), P("init_conv.0.conv.bias"), xfirst, (int)B, Cin, C, (int)L, s));
         DWS_TRY(launch_step_embed(steps, freq.f(), emb.f(), (int)B, Ein / 2, s));
         DWS_TRY(launch_linear_rows(emb.f(), P("residual_layer.fc_t1.weight"), P("residual_layer.fc_t1.bias"), h1.f(),
-                                   (int)B, Ein, Emid, 1, s));
+                                   (int)B, Ein, Emid, 1, s, train ? ta1.f() : nullptr));
         DWS_TRY(launch_linear_rows(h1.f(), P("residual_layer.fc_t2.weight"), P("residual_layer.fc_t2.bias"), h2.f(),
-                                   (int)B, Emid, Eout, 1, s));
+                                   (int)B, Emid, Eout, 1, s, train ? ta2.f() : nullptr));
         DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), (int)B, Eout, NL * C, 0, s));
         if (mfma_layer && bf16x3) DWS_TRY(launch_wn_bias_tap_bf16(Wd_all.f(), part_t.f(), Abt.p, NL, (int)B, C, s));
         else if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
             WnLayerArgs a{};
-            a.x_in = (n & 1) ? x1.f() : x0.f();
-            a.x_out = (n & 1) ? x0.f() : x1.f();
+            a.x_in = train ? tx[n].f() : ((n & 1) ? x1.f() : x0.f());
+            a.x_out = train ? tx[n + 1].f() : ((n & 1) ? x0.f() : x1.f());
+            a.hsave = train ? tH[n].f() : nullptr;
             a.skip = skip.f();
             a.part_t = part_t.f() + (size_t)n * C;
             a.part_t_bstride = NL * C;
@@ -253,7 +285,101 @@ struct WaveNetModel : dws_model {
             else if (mfma_layer) DWS_TRY(launch_wn_layer_mfma(C, S, a, s));
             else DWS_TRY(launch_wn_layer_generic(C, S, a, s));
         }
-        DWS_TRY(final_stage(out, nullptr, s));
+        DWS_TRY(final_stage(out, train ? ty.f() : nullptr, s));
+        DWS_HIP(hipGetLastError());
+        return DWS_OK;
+    }
+
+    // weight-norm adjoint of one folded weight into the raw (weight_g, weight_v) gradients
+    int wn_bwd(const std::string& p, const float* dWf, int O, int inner, hipStream_t s) {
+        return launch_weight_norm_bwd(dWf, P(p + ".weight_v"), P(p + ".weight_g"), G(p + ".weight_v"), G(p + ".weight_g"), O,
+                                      inner, s);
+    }
+
+    // Adjoint of run_forward (`models/wavenet.py:82-121,149-165,202-210`), layer by layer in reverse.
+    int backward(const float* dout, hipStream_t s) override {
+        DWS_CHECK(trained_fwd, DWS_ERR_STATE, "backward without a preceding forward_train");
+        const int nB = (int)B, nL = (int)L;
+        const size_t act = (size_t)B * C * L * 4, nact = (size_t)B * C * L;
+        DWS_TRY(dxa.ensure(act)); DWS_TRY(dxb.ensure(act)); DWS_TRY(dgb.ensure(act)); DWS_TRY(dresb.ensure(act));
+        DWS_TRY(gate.ensure(act));
+        DWS_TRY(dHb.ensure(2 * act));
+        DWS_TRY(dskip.ensure((size_t)B * S * L * 4)); DWS_TRY(dyb.ensure((size_t)B * S * L * 4));
+        DWS_TRY(dWfold.ensure((size_t)std::max(2 * C * C * 3, std::max((C + S) * C, S * S)) * 4));
+        DWS_TRY(dpt.ensure((size_t)B * NL * C * 4));
+        DWS_TRY(dh2.ensure((size_t)B * Eout * 4)); DWS_TRY(dh1.ensure((size_t)B * Emid * 4));
+        DWS_TRY(dWt_all.ensure((size_t)NL * C * Eout * 4)); DWS_TRY(dbt_all.ensure((size_t)NL * C * 4));
+        const float scale = (float)std::sqrt(1.0 / NL);
+
+        // ---- final_conv: out = Wz y + bz, y = relu(Wf (skip * scale) + bf)
+        DWS_TRY(launch_wgrad(dout, ty.f(), nullptr, 0, G("final_conv.2.conv.weight"), nB, Cout, S, nL, 1, 1, 1.f, s));
+        DWS_TRY(launch_rowsum(dout, G("final_conv.2.conv.bias"), nB, Cout, nL, 1.f, 0, s));
+        DWS_TRY(launch_final_dy(dout, P("final_conv.2.conv.weight"), ty.f(), dyb.f(), nB, S, Cout, nL, s));
+        DWS_TRY(launch_wgrad(dyb.f(), skip.f(), nullptr, 0, dWfold.f(), nB, S, S, nL, 1, 1, scale, s));
+        DWS_TRY(wn_bwd("final_conv.0.conv", dWfold.f(), S, S, s));
+        DWS_TRY(launch_rowsum(dyb.f(), G("final_conv.0.conv.bias"), nB, S, nL, 1.f, 0, s));
+        DWS_TRY(launch_conv_t(dyb.f(), Wf.f(), dskip.f(), nB, S, S, nL, 1, 1, scale, 0, s));  // same for every layer
+
+        // ---- residual layers, last to first
+        float* dx_out = nullptr;  // gradient w.r.t. the layer's x output (none for the last layer)
+        for (int n = NL - 1; n >= 0; --n) {
+            const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
+            const int dil = 1 << (n % cycle);
+            const float* Wr = Wrs[n].f();
+            const float* Ws = Wrs[n].f() + (size_t)C * C;
+            // dg = Wr^T dres + Ws^T dskip
+            if (dx_out) {
+                DWS_TRY(launch_scale(dx_out, dresb.f(), 0.70710678118654752440f, nact, s));
+                DWS_TRY(launch_conv_t(dresb.f(), Wr, dgb.f(), nB, C, C, nL, 1, 1, 1.f, 0, s));
+                DWS_TRY(launch_conv_t(dskip.f(), Ws, dgb.f(), nB, S, C, nL, 1, 1, 1.f, 1, s));
+            } else {
+                DWS_TRY(launch_conv_t(dskip.f(), Ws, dgb.f(), nB, S, C, nL, 1, 1, 1.f, 0, s));
+            }
+            DWS_TRY(launch_gate_bwd(dgb.f(), tH[n].f(), dHb.f(), gate.f(), nB, C, nL, s));
+            // res / skip 1x1 weights (folded: [Wr; Ws]) and biases
+            if (dx_out) {
+                DWS_TRY(launch_wgrad(dresb.f(), gate.f(), nullptr, 0, dWfold.f(), nB, C, C, nL, 1, 1, 1.f, s));
+                DWS_TRY(wn_bwd(p + ".res_conv", dWfold.f(), C, C, s));
+                DWS_TRY(launch_rowsum(dresb.f(), G(p + ".res_conv.bias"), nB, C, nL, 1.f, 0, s));
+            } else {  // the last layer's residual branch feeds nothing (`wavenet.py:165` uses only the skips)
+                DWS_HIP(hipMemsetAsync(G(p + ".res_conv.weight_v"), 0, (size_t)C * C * 4, s));
+                DWS_HIP(hipMemsetAsync(G(p + ".res_conv.weight_g"), 0, (size_t)C * 4, s));
+                DWS_HIP(hipMemsetAsync(G(p + ".res_conv.bias"), 0, (size_t)C * 4, s));
+            }
+            DWS_TRY(launch_wgrad(dskip.f(), gate.f(), nullptr, 0, dWfold.f(), nB, S, C, nL, 1, 1, 1.f, s));
+            DWS_TRY(wn_bwd(p + ".skip_conv", dWfold.f(), S, C, s));
+            DWS_TRY(launch_rowsum(dskip.f(), G(p + ".skip_conv.bias"), nB, S, nL, 1.f, 0, s));
+            // dilated conv: weights see h = x + pt (zero padded), input gets the transposed conv
+            DWS_TRY(launch_wgrad(dHb.f(), tx[n].f(), part_t.f() + (size_t)n * C, NL * C, dWfold.f(), nB, 2 * C, C, nL, 3,
+                                 dil, 1.f, s));
+            DWS_TRY(wn_bwd(p + ".dilated_conv_layer.conv", dWfold.f(), 2 * C, C * 3, s));
+            DWS_TRY(launch_rowsum(dHb.f(), G(p + ".dilated_conv_layer.conv.bias"), nB, 2 * C, nL, 1.f, 0, s));
+            float* dh = (dx_out == dxa.f()) ? dxb.f() : dxa.f();
+            DWS_TRY(launch_conv_t(dHb.f(), Wd(n), dh, nB, 2 * C, C, nL, 3, dil, 1.f, 0, s));
+            DWS_TRY(launch_rowsum_bc(dh, dpt.f() + (size_t)n * C, NL * C, nB, C, nL, s));  // d fc_t(e)[b, n, c]
+            if (dx_out) DWS_TRY(launch_dx_combine(dh, dx_out, nact, s));                   // + dx' * sqrt(.5)
+            dx_out = dh;
+        }
+        // ---- init_conv: x0 = relu(Wi audio + bi)
+        DWS_TRY(launch_relu_bwd(dx_out, tx[0].f(), nact, s));
+        DWS_TRY(launch_wgrad(dx_out, train_audio, nullptr, 0, dWfold.f(), nB, C, Cin, nL, 1, 1, 1.f, s));
+        DWS_TRY(wn_bwd("init_conv.0.conv", dWfold.f(), C, Cin, s));
+        DWS_TRY(launch_rowsum(dx_out, G("init_conv.0.conv.bias"), nB, C, nL, 1.f, 0, s));
+
+        // ---- step embedding: per-layer fc_t (stacked), then the shared swish MLP
+        DWS_TRY(launch_lin_bwd_w(dpt.f(), h2.f(), dWt_all.f(), dbt_all.f(), nB, Eout, NL * C, s));
+        for (int n = 0; n < NL; ++n) {
+            const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
+            DWS_HIP(hipMemcpyAsync(G(p + ".fc_t.weight"), dWt_all.f() + (size_t)n * C * Eout, (size_t)C * Eout * 4,
+                                   hipMemcpyDeviceToDevice, s));
+            DWS_HIP(hipMemcpyAsync(G(p + ".fc_t.bias"), dbt_all.f() + (size_t)n * C, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+        }
+        DWS_TRY(launch_lin_bwd_x(dpt.f(), Wt_all.f(), ta2.f(), dh2.f(), nB, Eout, NL * C, s));   // d(pre-activation 2)
+        DWS_TRY(launch_lin_bwd_w(dh2.f(), h1.f(), G("residual_layer.fc_t2.weight"), G("residual_layer.fc_t2.bias"), nB, Emid,
+                                 Eout, s));
+        DWS_TRY(launch_lin_bwd_x(dh2.f(), P("residual_layer.fc_t2.weight"), ta1.f(), dh1.f(), nB, Emid, Eout, s));
+        DWS_TRY(launch_lin_bwd_w(dh1.f(), emb.f(), G("residual_layer.fc_t1.weight"), G("residual_layer.fc_t1.bias"), nB, Ein,
+                                 Emid, s));
         DWS_HIP(hipGetLastError());
         return DWS_OK;
     }

@@ -8,6 +8,41 @@ import torch.nn as nn
 from .. import _lib
 
 
+class _EngineTrainFn(torch.autograd.Function):
+    """Differentiable call of the engine (`train.py:221`): forward_train keeps the activations inside
+    the dws_model, backward fills the gradient of every raw state-dict tensor, which are handed to
+    autograd as the gradients of the module's parameters (so optimizers and the DP all-reduce of
+    ``distributed_util.apply_gradient_allreduce`` work unchanged)."""
+
+    @staticmethod
+    def forward(ctx, module, audio, steps, *params):
+        lib = _lib.load()
+        B, _, L = audio.shape
+        module._sync_params()
+        module._prepare(B, L)
+        module._set_condition(None)
+        x = audio.detach().to(torch.float32).contiguous()
+        out = torch.empty((B, module.out_channels, L), device=audio.device, dtype=torch.float32)
+        _lib.check(lib.dws_model_forward_train(module._handle, x.data_ptr(), steps.data_ptr(), out.data_ptr(),
+                                               _lib.current_stream()))
+        ctx.module, ctx.x, ctx.steps = module, x, steps      # x must stay alive until backward (init_conv adjoint)
+        ctx.meta = [(n, tuple(p.shape), p.dtype) for n, p in module.named_parameters()]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        m = ctx.module
+        d = dout.detach().to(torch.float32).contiguous()
+        _lib.check(lib.dws_model_backward(m._handle, d.data_ptr(), _lib.current_stream()))
+        grads = []
+        for name, shape, dtype in ctx.meta:
+            g = torch.empty(shape, device=d.device, dtype=torch.float32)
+            _lib.check(lib.dws_model_get_grad(m._handle, name.encode(), g.data_ptr(), g.numel(), _lib.current_stream()))
+            grads.append(g.to(dtype))
+        return (None, None, None, *grads)
+
+
 class EngineModule(nn.Module):
     """Base of :class:`WaveNet` and :class:`Sashimi`.
 
@@ -100,16 +135,20 @@ class EngineModule(nn.Module):
     # -- reference surface -----------------------------------------------------
     def forward(self, input_data, mel_spec=None):
         audio, diffusion_steps = input_data
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "the backward/training path (SURVEY.md 8a rows a19-a20) is not built yet; "
-                "call under torch.no_grad() or .eval()")
         if audio.device.type != "cuda":
             raise RuntimeError("libdws runs on the GPU only: move the model and inputs to cuda "
                                "(there is no CPU fallback)")
         if audio.dim() != 3:
             raise RuntimeError("audio must be [B, in_channels, L]")
         B, Cin, L = audio.shape
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            # training call (`train.py:221`): differentiable w.r.t. the parameters
+            if mel_spec is not None:
+                raise NotImplementedError("training of the mel-conditional path is not built yet")
+            steps = diffusion_steps.detach().to(device=audio.device, dtype=torch.float32).reshape(-1).contiguous()
+            if steps.numel() != B:
+                raise RuntimeError(f"diffusion_steps must hold B={B} entries, got {tuple(diffusion_steps.shape)}")
+            return _EngineTrainFn.apply(self, audio, steps, *self.parameters())
         with torch.no_grad():
             self._sync_params()
             self._prepare(B, L)

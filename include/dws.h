@@ -146,6 +146,16 @@ int dws_model_set_condition(dws_model* m, const float* mel, int64_t Bm, int64_t 
  * (`generate.py:50`; the int64 steps of `train.py:218` are converted by the host side). */
 int dws_model_forward(dws_model* m, const float* audio, const float* steps, float* out, void* stream);
 
+/* Training path (`train.py:198-222`; WaveNet backbone, fp32 precision, unconditional -- the rest
+ * returns DWS_ERR_UNSUPPORTED for now).  forward_train == forward but keeps the activations backward
+ * needs; backward takes dLoss/d(eps)[B, out_channels, L] and produces the gradient of every RAW
+ * state-dict tensor (weight_g / weight_v / bias ...), fetched with get_grad (device copy).  The
+ * data-parallel exchange of those gradients is the host side's job (RCCL all-reduce,
+ * `distributed_util.py:97-149`). */
+int dws_model_forward_train(dws_model* m, const float* audio, const float* steps, float* out, void* stream);
+int dws_model_backward(dws_model* m, const float* dout, void* stream);
+int dws_model_get_grad(dws_model* m, const char* name, float* dst, int64_t numel, void* stream);
+
 /* Debug/parity tap: copy an internal activation into `dst` (device pointer,
  * `capacity` floats).  WaveNet: "pre_final" = ReLU(final_conv[0](skip)) [B,S,L],
  * "skip" [B,S,L], "x" (last residual output) [B,C,L]. */
