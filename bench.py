@@ -145,6 +145,53 @@ def cpu_baseline(cfg, seconds_budget=25.0):
             "ms_per_step_b1": per_step * 1e3}
 
 
+def train_bench(args, cfg, world, rank, dev, ddist):
+    """One data-parallel training step (`train.py:118-143`): q-sample + forward_train + MSE + backward through the
+    HIP engine, bucketed RCCL all-reduce of the gradients overlapped with backward, Adam.  Synthetic audio
+    U(-0.3, 0.3) (SURVEY.md 8d).  Not the headline metric; reported as training audio samples/s."""
+    import torch.nn as nn
+    from diffwave_sashimi_amd.distributed_util import apply_gradient_allreduce
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from diffwave_sashimi_amd.training import training_loss
+    assert cfg["model"]["_name_"] == "wavenet", "the SaShiMi backward is not built yet"
+    B, L = (args.batch or 4), cfg["L"]          # `configs/config.yaml:12`: batch_size_per_gpu = 4
+    net = build_model(cfg, dev).train()
+    if world > 1:
+        net = apply_gradient_allreduce(net)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4)     # `train.py:91`
+    dh = calc_diffusion_hyperparams(**cfg["diffusion"])
+    g = torch.Generator().manual_seed(99 + rank)
+    audio = ((torch.rand(B, 1, L, generator=g) * 2 - 1) * 0.3).to(dev)
+    loss_fn = nn.MSELoss()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = training_loss(net, loss_fn, audio, dh, generator=g)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    ddist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    ddist.barrier()
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+    ms = elapsed / args.steps * 1e3
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training audio samples/sec (train.py-style DP step: fwd + bwd + grad all-reduce + Adam)",
+            "value": ddist.aggregate_throughput(B * L, world, ms * 1e-3), "unit": "audio samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic U(-0.3,0.3) audio",
+            "config": {"workload": args.config + " training", "batch_per_gpu": B, "L": L,
+                       "parallelism": "dp%d, bucketed RCCL all-reduce overlapped with backward" % world},
+            "final_loss": float(loss)}))
+    ddist.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +201,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="WaveNet matrix arithmetic: exact-f32 MFMA (default) or the 3-term bf16 split")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+                    help="sample: the headline reverse-diffusion step; train: one DP training step "
+                         "(forward_train + backward + RCCL gradient all-reduce + Adam), WaveNet only for now")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -177,6 +227,8 @@ def main():
     B, L = cfg["B"], cfg["L"]
     dcfg = cfg["diffusion"]
     T = dcfg["T"]
+    if args.mode == "train":
+        return train_bench(args, cfg, world, rank, dev, ddist)
     net = build_model(cfg, dev)
     if args.precision != "f32":
         net.set_option("precision", args.precision)
