@@ -21,4 +21,32 @@ int launch_weight_norm_bwd(const float* dW, const float* v, const float* g, floa
                            hipStream_t s);
 int launch_lin_bwd_w(const float* dy, const float* x, float* dW, float* db, int B, int K, int O, hipStream_t s);
 int launch_lin_bwd_x(const float* dy, const float* W, const float* pre, float* dx, int B, int K, int O, hipStream_t s);
+
+// ---- MFMA adjoints (wavenet_backward_mfma.hip)
+struct TapConvArgs {
+    const float* src0; int K0;   // [B][K0][L]   first K0 contraction channels
+    const float* src1; int K1;   // [B][K1][L]   next K1 (may be 0)
+    const float* A;              // A fragments of the [M][nkg_total*8] transposed weight (pack_a_frag order)
+    int nkg_total;               // k-groups per fragment row in A (the launch may use a prefix of them)
+    int M, T, dil, sign;         // tap t reads position l + sign * (t - T/2) * dil
+    int epi;                     // 0: out = acc + addin * addscale;  1: gate adjoint (dH, g from H)
+    float* out;
+    const float* addin; float addscale;
+    const float* H; float* dH; float* g;
+    int B, L;
+};
+bool tapconv_mfma_supported(int M, int K0, int K1, int T);
+int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s);
+int launch_tapconv_pack_transposed(const float* W, float* out, int O, int C, int T, int ldo, int coff, float scale,
+                                   hipStream_t s);
+
+struct WgradArgs {
+    const float* dY;             // [B][O][L]
+    const float* X;              // [B][C][L]
+    const float* addc; int addc_bstride;   // optional per-(b, c) constant added to in-range X
+    float* partial;              // [nsplit][O][C][T] scratch
+    int B, O, C, L, dil, nsplit;
+};
+int wgrad_mfma_nsplit(int B, int O, int C, int L, int T);
+int launch_wgrad_mfma(const WgradArgs& a, int T, float scale, float* dW, hipStream_t s);
 }  // namespace dws

@@ -1,0 +1,308 @@
+// MFMA (exact-f32) versions of the two heavy adjoints of the WaveNet residual layer.
+//
+// tapconv_mfma_kernel: position-tile GEMM with shifted taps, the data-gradient workhorse
+//     out[m, l] = sum_{k < K} sum_{t < T} A[m, (k, t)] * src[k, l + sign * (t - T/2) * dil]      (0 outside [0, L))
+//   * adjoint of the dilated conv w.r.t. its input (`wavenet.py:95`): M = C, K = 2C, T = 3, sign = -1,
+//     A[c, (o, t)] = Wd[o, c, t]; epilogue adds dx' * sqrt(.5) (the residual path, `wavenet.py:121`)
+//   * adjoint of the res/skip 1x1 convs (`wavenet.py:117-119`): M = C, K = S (+ C), T = 1 over the
+//     concatenated inputs [dskip; dx'] with A = [Ws^T, sqrt(.5) Wr^T]; epilogue = gate adjoint
+//     (dHt, dHs, g from the saved pre-activations, `wavenet.py:114`)
+//   Same structure as the forward kernel: LDS-DMA staging through per-row descriptors (hardware zero
+//   padding), A fragments streamed from L2 with a pinned one-group-ahead prefetch.
+//
+// wgrad_mfma_kernel: weight gradients, a GEMM whose contraction runs over POSITIONS
+//     dW[o, c, t] = sum_{b, l} dY[b, o, l] * Xh[b, c, l + (t - T/2) * dil],   Xh = X (+ addc[b, c]) in range
+//   128 x 128 output tile per block and tap, the (b, l) range split over blocks; partial tiles go to a
+//   scratch buffer and are summed in a fixed order by wgrad_reduce_kernel (deterministic, no atomics).
+#include "wavenet_backward.h"
+
+namespace dws {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float sigm_b(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int MT, int T>
+__global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
+    constexpr int P = 64, NT = 2, KC = 32;
+    constexpr int ROWS = T * KC, RPW = ROWS / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * P];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int L = a.L;
+    const int ntl = (L + P - 1) / P;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = tile / ntl, l0 = (tile % ntl) * P;
+    const int K = a.K0 + a.K1;
+    const int ncb = K / KC;
+
+    auto stage_dma = [&](int cb, int buf) {
+        float* xs = lds + buf * (ROWS * P);
+        const int k0 = cb * KC;
+        const float* base = (k0 < a.K0) ? a.src0 + ((size_t)b * a.K0 + k0) * L
+                                        : a.src1 + ((size_t)b * a.K1 + (k0 - a.K0)) * L;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + 4 * i;
+            const int tap = row / KC, cc = row % KC;
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)cc * L), 0, L * 4, 0x00020000);
+            const int voff = (l0 + lane + a.sign * (tap - T / 2) * a.dil) * 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 4, voff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.M * a.nkg_total * 8 * 4, 0x00020000);
+    const int lane16 = lane * 16;
+    int mt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mt[m] = wave * MT + m;
+
+    stage_dma(0, 0);
+    f32x4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_cur[m] = buf_load4(rA, lane16, (mt[m] * a.nkg_total) * 1024);
+    __syncthreads();
+    const int nkg = ncb * (ROWS / 8);
+    for (int cb = 0; cb < ncb; ++cb) {
+        if (cb + 1 < ncb) stage_dma(cb + 1, (cb + 1) & 1);
+        const float* xs = lds + (cb & 1) * (ROWS * P);
+#pragma unroll
+        for (int it = 0; it < ROWS / 8; ++it) {
+            const int kg = cb * (ROWS / 8) + it;
+            const int kgn = (kg + 1 < nkg) ? kg + 1 : kg;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a_nxt[m] = buf_load4(rA, lane16, (mt[m] * a.nkg_total + kgn) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int krow = it * 8 + j * 2 + lhi;
+                float bf[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bf[n] = xs[krow * P + n * 32 + l31];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j], bf[n], acc[m][n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+        }
+        __syncthreads();
+    }
+
+    const int M = a.M;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int pos = l0 + n * 32 + l31;
+        const bool ok = pos < L;
+        const int posc = ok ? pos : 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (a.epi == 0) {
+                float ad[16];
+                if (a.addin) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        ad[r] = a.addin[((size_t)b * M + row) * L + posc] * a.addscale;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ad[r] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (ok) a.out[((size_t)b * M + row) * L + pos] = acc[m][n][r] + ad[r];
+                }
+            } else {  // gate adjoint: M == C, H / dH are [B, 2C, L]
+                float ht[16], hs[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    ht[r] = a.H[((size_t)b * 2 * M + c) * L + posc];
+                    hs[r] = a.H[((size_t)b * 2 * M + M + c) * L + posc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float th = tanhf(ht[r]), sg = sigm_b(hs[r]), d = acc[m][n][r];
+                    if (ok) {
+                        a.g[((size_t)b * M + c) * L + pos] = th * sg;
+                        a.dH[((size_t)b * 2 * M + c) * L + pos] = d * sg * (1.f - th * th);
+                        a.dH[((size_t)b * 2 * M + M + c) * L + pos] = d * th * sg * (1.f - sg);
+                    }
+                }
+            }
+        }
+    }
+}
+
+bool tapconv_mfma_supported(int M, int K0, int K1, int T) {
+    return (M == 128 || M == 256) && K0 % 32 == 0 && K1 % 32 == 0 && (K0 + K1) > 0 && (T == 1 || T == 3);
+}
+
+template <int T>
+static int launch_tc(const TapConvArgs& a, hipStream_t s) {
+    const dim3 grid(a.B * ceil_div(a.L, 64));
+    switch (a.M) {
+        case 128: hipLaunchKernelGGL((tapconv_mfma_kernel<1, T>), grid, dim3(256), 0, s, a); break;
+        case 256: hipLaunchKernelGGL((tapconv_mfma_kernel<2, T>), grid, dim3(256), 0, s, a); break;
+        default: return set_error(DWS_ERR_UNSUPPORTED, "tapconv_mfma: M=%d", a.M);
+    }
+    return DWS_OK;
+}
+
+int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s) {
+    ProfileScope ps("tapconv_mfma", s);
+    DWS_CHECK(tapconv_mfma_supported(a.M, a.K0, a.K1, a.T), DWS_ERR_UNSUPPORTED, "tapconv_mfma: M=%d K=%d+%d T=%d", a.M,
+              a.K0, a.K1, a.T);
+    return a.T == 3 ? launch_tc<3>(a, s) : launch_tc<1>(a, s);
+}
+
+// Row-major block of A in the kernel's K order k' = ((cb*T + tap)*KC + cc), o = cb*KC + cc, from a conv
+// weight W[o][c][t] (o is the contraction index of the adjoint):
+//     out[m = c][coff + k'] = scale * W[o][c][t]          (row stride ldo; pack_a_frag makes the fragments)
+__global__ void tapconv_pack_transposed_kernel(const float* __restrict__ W, float* __restrict__ out, int O, int C,
+                                               int T, int KC, int ldo, int coff, float scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * O * T) return;
+    const int m = (int)(i / ((size_t)O * T)), kp = (int)(i % ((size_t)O * T));
+    const int cb = kp / (T * KC), rem = kp % (T * KC), tap = rem / KC, cc = rem % KC;
+    const int o = cb * KC + cc;
+    out[(size_t)m * ldo + coff + kp] = W[((size_t)o * C + m) * T + tap] * scale;
+}
+
+int launch_tapconv_pack_transposed(const float* W, float* out, int O, int C, int T, int ldo, int coff, float scale,
+                                   hipStream_t s) {
+    const size_t n = (size_t)C * O * T;
+    hipLaunchKernelGGL(tapconv_pack_transposed_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, W, out, O, C, T, 32, ldo,
+                       coff, scale);
+    return DWS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// weight gradients
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
+    constexpr int PC = 64, LD = PC + 1;   // +1: lanes walk channels, so rows must not share a bank
+    __shared__ float sdy[128 * LD];
+    __shared__ float sx[128 * LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wo = wave & 1, wc = wave >> 1;                 // 2 x 2 waves over the 128 x 128 tile
+    const int o0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+    const int tap = blockIdx.z % T, split = blockIdx.z / T;
+    const int L = a.L, shift = (tap - T / 2) * a.dil;
+    const int chunks_per_b = (L + PC - 1) / PC;
+    const int total_chunks = a.B * chunks_per_b;
+    const int per = (total_chunks + a.nsplit - 1) / a.nsplit;
+    const int ch_begin = split * per, ch_end = min(total_chunks, ch_begin + per);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int b = ch / chunks_per_b, l0 = (ch % chunks_per_b) * PC;
+        __syncthreads();
+        // stage dY[o0..+128][l0..+64] and Xh[c0..+128][l0+shift..+64]: a wave loads whole rows (coalesced)
+        for (int row = wave; row < 128; row += 4) {
+            const int pos = l0 + lane;
+            const int o = o0 + row, c = c0 + row;
+            float dv = 0.f, xv = 0.f;
+            {
+                const bool ok = pos < L && o < a.O;
+                const float v = a.dY[((size_t)b * a.O + (o < a.O ? o : 0)) * L + (pos < L ? pos : 0)];
+                dv = v * (ok ? 1.f : 0.f);
+            }
+            {
+                const int ps = pos + shift;
+                const bool ok = (unsigned)ps < (unsigned)L && pos < L && c < a.C;
+                const int cc = c < a.C ? c : 0;
+                const float v = a.X[((size_t)b * a.C + cc) * L + (((unsigned)ps < (unsigned)L) ? ps : 0)];
+                const float ad = a.addc ? a.addc[(size_t)b * a.addc_bstride + cc] : 0.f;
+                xv = (v + ad) * (ok ? 1.f : 0.f);
+            }
+            sdy[row * LD + lane] = dv;
+            sx[row * LD + lane] = xv;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int ks = 0; ks < PC / 2; ++ks) {
+            const int pp = ks * 2 + lhi;
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = sdy[(wo * 64 + i * 32 + l31) * LD + pp];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = sx[(wc * 64 + j * 32 + l31) * LD + pp];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // partial[split][o][c][t]
+    float* part = a.partial + (size_t)split * a.O * a.C * T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int c = c0 + wc * 64 + j * 32 + l31;
+                if (o < a.O && c < a.C) part[((size_t)o * a.C + c) * T + tap] = acc[i][j][r];
+            }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, size_t n, int nsplit,
+                                    float scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + i];
+    dW[i] = s * scale;
+}
+
+int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
+    const int tiles = ceil_div(O, 128) * ceil_div(C, 128) * T;
+    const int chunks = B * ceil_div(L, 64);
+    int ns = std::max(1, 1024 / tiles);
+    return std::min(ns, chunks);
+}
+
+int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipStream_t s) {
+    ProfileScope ps("wgrad_mfma", s);
+    WgradArgs a = a_in;
+    const dim3 grid(ceil_div(a.O, 128), ceil_div(a.C, 128), T * a.nsplit);
+    if (T == 3) hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, s, a);
+    const size_t n = (size_t)a.O * a.C * T;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, a.partial, dW, n, a.nsplit, scale);
+    return DWS_OK;
+}
+
+}  // namespace dws

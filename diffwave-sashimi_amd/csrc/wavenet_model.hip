@@ -34,6 +34,10 @@ struct WaveNetModel : dws_model {
     // training workspace: per-layer inputs and pre-gate activations, saved pre-activations of the
     // embedding MLP, gradient scratch
     std::vector<DevBuf> tx, tH;
+    std::vector<DevBuf> ATd, ATg;    // transposed-weight A fragments of the adjoint GEMMs (training only)
+    DevBuf ATf, wpart;               // same for final_conv[0]; split-N partials of the weight gradients
+    bool mfma_bwd = false;
+    uint64_t commit_version = 0, bwd_pack_version = ~0ull;
     DevBuf ty, ta1, ta2, dxa, dxb, dskip, dgb, dHb, dresb, dyb, dWfold, dpt, dh2, dh1, demb, dWt_all, dbt_all;
     bool trained_fwd = false;
 
@@ -45,6 +49,8 @@ struct WaveNetModel : dws_model {
         MB = d.mel_bands;
         cond = !d.unconditional;
         mfma_layer = wn_layer_mfma_supported(C, S);
+        mfma_bwd = tapconv_mfma_supported(C, S, C, 1) && tapconv_mfma_supported(C, 2 * C, 0, 3) &&
+                   tapconv_mfma_supported(S, S, 0, 1) && std::getenv("DWS_WAVENET_GENERIC_BWD") == nullptr;
         mfma_final = wn_final_mfma_supported(S);
         auto wn = [&](const std::string& p, std::vector<int64_t> vshape) {
             std::vector<int64_t> g(vshape.size(), 1);
@@ -164,8 +170,42 @@ struct WaveNetModel : dws_model {
         }
         if (Abt.p) DWS_HIP(hipMemsetAsync(Abt.p, 0, Abt.bytes, s));  // correction layout depends on the precision
         dirty = false;
+        ++commit_version;
         melBm = 0;  // conditioner terms depend on the weights: must be re-installed
         return DWS_OK;
+    }
+
+    // Transposed weights of the adjoint GEMMs in A-fragment order (rebuilt after every commit).
+    int pack_bwd(hipStream_t s) {
+        const float r2 = 0.70710678118654752440f;
+        ATd.resize(NL); ATg.resize(NL);
+        DWS_TRY(tmp_pack.ensure((size_t)std::max(std::max(6 * C * C, (S + C) * C), S * S) * 4));
+        for (int n = 0; n < NL; ++n) {
+            DWS_TRY(ATd[n].ensure((size_t)6 * C * C * 4));
+            DWS_TRY(launch_tapconv_pack_transposed(Wd(n), tmp_pack.f(), 2 * C, C, 3, 6 * C, 0, 1.f, s));
+            DWS_TRY(launch_pack_a_frag(tmp_pack.f(), ATd[n].f(), C, 6 * C, s));
+            DWS_TRY(ATg[n].ensure((size_t)(S + C) * C * 4));
+            DWS_TRY(launch_tapconv_pack_transposed(Wrs[n].f() + (size_t)C * C, tmp_pack.f(), S, C, 1, S + C, 0, 1.f, s));
+            DWS_TRY(launch_tapconv_pack_transposed(Wrs[n].f(), tmp_pack.f(), C, C, 1, S + C, S, r2, s));
+            DWS_TRY(launch_pack_a_frag(tmp_pack.f(), ATg[n].f(), C, S + C, s));
+        }
+        DWS_TRY(ATf.ensure((size_t)S * S * 4));
+        DWS_TRY(launch_tapconv_pack_transposed(Wf.f(), tmp_pack.f(), S, S, 1, S, 0, (float)std::sqrt(1.0 / NL), s));
+        DWS_TRY(launch_pack_a_frag(tmp_pack.f(), ATf.f(), S, S, s));
+        bwd_pack_version = commit_version;
+        return DWS_OK;
+    }
+
+    int wgrad(const float* dY, const float* X, const float* addc, int addc_bs, float* dW, int O, int Cc, int T, int dil,
+              float scale, hipStream_t s) {
+        if (!mfma_bwd) return launch_wgrad(dY, X, addc, addc_bs, dW, (int)B, O, Cc, (int)L, T, dil, scale, s);
+        WgradArgs w{};
+        w.dY = dY; w.X = X; w.addc = addc; w.addc_bstride = addc_bs;
+        w.B = (int)B; w.O = O; w.C = Cc; w.L = (int)L; w.dil = dil;
+        w.nsplit = wgrad_mfma_nsplit((int)B, O, Cc, (int)L, T);
+        DWS_TRY(wpart.ensure((size_t)w.nsplit * O * Cc * T * 4));
+        w.partial = wpart.f();
+        return launch_wgrad_mfma(w, T, scale, dW, s);
     }
 
     int prepare(int64_t nB, int64_t nL) override {
@@ -315,10 +355,18 @@ struct WaveNetModel : dws_model {
         DWS_TRY(launch_wgrad(dout, ty.f(), nullptr, 0, G("final_conv.2.conv.weight"), nB, Cout, S, nL, 1, 1, 1.f, s));
         DWS_TRY(launch_rowsum(dout, G("final_conv.2.conv.bias"), nB, Cout, nL, 1.f, 0, s));
         DWS_TRY(launch_final_dy(dout, P("final_conv.2.conv.weight"), ty.f(), dyb.f(), nB, S, Cout, nL, s));
-        DWS_TRY(launch_wgrad(dyb.f(), skip.f(), nullptr, 0, dWfold.f(), nB, S, S, nL, 1, 1, scale, s));
+        DWS_TRY(wgrad(dyb.f(), skip.f(), nullptr, 0, dWfold.f(), S, S, 1, 1, scale, s));
         DWS_TRY(wn_bwd("final_conv.0.conv", dWfold.f(), S, S, s));
         DWS_TRY(launch_rowsum(dyb.f(), G("final_conv.0.conv.bias"), nB, S, nL, 1.f, 0, s));
-        DWS_TRY(launch_conv_t(dyb.f(), Wf.f(), dskip.f(), nB, S, S, nL, 1, 1, scale, 0, s));  // same for every layer
+        if (mfma_bwd) {  // dskip = scale * Wf^T dy, the same for every layer
+            if (bwd_pack_version != commit_version) DWS_TRY(pack_bwd(s));
+            TapConvArgs f{};
+            f.src0 = dyb.f(); f.K0 = S; f.A = ATf.f(); f.nkg_total = S / 8; f.M = S; f.T = 1; f.dil = 1; f.sign = 1;
+            f.out = dskip.f(); f.B = nB; f.L = nL;
+            DWS_TRY(launch_tapconv_mfma(f, s));
+        } else {
+            DWS_TRY(launch_conv_t(dyb.f(), Wf.f(), dskip.f(), nB, S, S, nL, 1, 1, scale, 0, s));
+        }
 
         // ---- residual layers, last to first
         float* dx_out = nullptr;  // gradient w.r.t. the layer's x output (none for the last layer)
@@ -327,35 +375,50 @@ struct WaveNetModel : dws_model {
             const int dil = 1 << (n % cycle);
             const float* Wr = Wrs[n].f();
             const float* Ws = Wrs[n].f() + (size_t)C * C;
-            // dg = Wr^T dres + Ws^T dskip
-            if (dx_out) {
-                DWS_TRY(launch_scale(dx_out, dresb.f(), 0.70710678118654752440f, nact, s));
-                DWS_TRY(launch_conv_t(dresb.f(), Wr, dgb.f(), nB, C, C, nL, 1, 1, 1.f, 0, s));
-                DWS_TRY(launch_conv_t(dskip.f(), Ws, dgb.f(), nB, S, C, nL, 1, 1, 1.f, 1, s));
+            const float r2 = 0.70710678118654752440f;
+            float* dh = (dx_out == dxa.f()) ? dxb.f() : dxa.f();
+            if (mfma_bwd) {
+                // dg = Ws^T dskip + sqrt(.5) Wr^T dx', gate adjoint fused in the epilogue
+                TapConvArgs q{};
+                q.src0 = dskip.f(); q.K0 = S; q.src1 = dx_out; q.K1 = dx_out ? C : 0;
+                q.A = ATg[n].f(); q.nkg_total = (S + C) / 8; q.M = C; q.T = 1; q.dil = 1; q.sign = 1; q.epi = 1;
+                q.H = tH[n].f(); q.dH = dHb.f(); q.g = gate.f(); q.B = nB; q.L = nL;
+                DWS_TRY(launch_tapconv_mfma(q, s));
             } else {
-                DWS_TRY(launch_conv_t(dskip.f(), Ws, dgb.f(), nB, S, C, nL, 1, 1, 1.f, 0, s));
+                if (dx_out) {
+                    DWS_TRY(launch_scale(dx_out, dresb.f(), r2, nact, s));
+                    DWS_TRY(launch_conv_t(dresb.f(), Wr, dgb.f(), nB, C, C, nL, 1, 1, 1.f, 0, s));
+                    DWS_TRY(launch_conv_t(dskip.f(), Ws, dgb.f(), nB, S, C, nL, 1, 1, 1.f, 1, s));
+                } else {
+                    DWS_TRY(launch_conv_t(dskip.f(), Ws, dgb.f(), nB, S, C, nL, 1, 1, 1.f, 0, s));
+                }
+                DWS_TRY(launch_gate_bwd(dgb.f(), tH[n].f(), dHb.f(), gate.f(), nB, C, nL, s));
             }
-            DWS_TRY(launch_gate_bwd(dgb.f(), tH[n].f(), dHb.f(), gate.f(), nB, C, nL, s));
-            // res / skip 1x1 weights (folded: [Wr; Ws]) and biases
+            // res / skip 1x1 weights and biases (dres = dx' * sqrt(.5))
             if (dx_out) {
-                DWS_TRY(launch_wgrad(dresb.f(), gate.f(), nullptr, 0, dWfold.f(), nB, C, C, nL, 1, 1, 1.f, s));
+                DWS_TRY(wgrad(dx_out, gate.f(), nullptr, 0, dWfold.f(), C, C, 1, 1, r2, s));
                 DWS_TRY(wn_bwd(p + ".res_conv", dWfold.f(), C, C, s));
-                DWS_TRY(launch_rowsum(dresb.f(), G(p + ".res_conv.bias"), nB, C, nL, 1.f, 0, s));
+                DWS_TRY(launch_rowsum(dx_out, G(p + ".res_conv.bias"), nB, C, nL, r2, 0, s));
             } else {  // the last layer's residual branch feeds nothing (`wavenet.py:165` uses only the skips)
                 DWS_HIP(hipMemsetAsync(G(p + ".res_conv.weight_v"), 0, (size_t)C * C * 4, s));
                 DWS_HIP(hipMemsetAsync(G(p + ".res_conv.weight_g"), 0, (size_t)C * 4, s));
                 DWS_HIP(hipMemsetAsync(G(p + ".res_conv.bias"), 0, (size_t)C * 4, s));
             }
-            DWS_TRY(launch_wgrad(dskip.f(), gate.f(), nullptr, 0, dWfold.f(), nB, S, C, nL, 1, 1, 1.f, s));
+            DWS_TRY(wgrad(dskip.f(), gate.f(), nullptr, 0, dWfold.f(), S, C, 1, 1, 1.f, s));
             DWS_TRY(wn_bwd(p + ".skip_conv", dWfold.f(), S, C, s));
             DWS_TRY(launch_rowsum(dskip.f(), G(p + ".skip_conv.bias"), nB, S, nL, 1.f, 0, s));
             // dilated conv: weights see h = x + pt (zero padded), input gets the transposed conv
-            DWS_TRY(launch_wgrad(dHb.f(), tx[n].f(), part_t.f() + (size_t)n * C, NL * C, dWfold.f(), nB, 2 * C, C, nL, 3,
-                                 dil, 1.f, s));
+            DWS_TRY(wgrad(dHb.f(), tx[n].f(), part_t.f() + (size_t)n * C, NL * C, dWfold.f(), 2 * C, C, 3, dil, 1.f, s));
             DWS_TRY(wn_bwd(p + ".dilated_conv_layer.conv", dWfold.f(), 2 * C, C * 3, s));
             DWS_TRY(launch_rowsum(dHb.f(), G(p + ".dilated_conv_layer.conv.bias"), nB, 2 * C, nL, 1.f, 0, s));
-            float* dh = (dx_out == dxa.f()) ? dxb.f() : dxa.f();
-            DWS_TRY(launch_conv_t(dHb.f(), Wd(n), dh, nB, 2 * C, C, nL, 3, dil, 1.f, 0, s));
+            if (mfma_bwd) {
+                TapConvArgs q{};
+                q.src0 = dHb.f(); q.K0 = 2 * C; q.A = ATd[n].f(); q.nkg_total = 6 * C / 8; q.M = C; q.T = 3; q.dil = dil;
+                q.sign = -1; q.out = dh; q.B = nB; q.L = nL;
+                DWS_TRY(launch_tapconv_mfma(q, s));
+            } else {
+                DWS_TRY(launch_conv_t(dHb.f(), Wd(n), dh, nB, 2 * C, C, nL, 3, dil, 1.f, 0, s));
+            }
             DWS_TRY(launch_rowsum_bc(dh, dpt.f() + (size_t)n * C, NL * C, nB, C, nL, s));  // d fc_t(e)[b, n, c]
             if (dx_out) DWS_TRY(launch_dx_combine(dh, dx_out, nact, s));                   // + dx' * sqrt(.5)
             dx_out = dh;

@@ -16,7 +16,10 @@ TRAIN_CASES = {
     # MFMA forward (C = 64) + backward kernels, L not a multiple of the tile
     "c64": (cases.wn_cfg(res_channels=64, skip_channels=64, num_res_layers=3, dilation_cycle=3), 2, 200),
     # different res/skip widths
+    # MFMA adjoints (tapconv / wgrad kernels, 1 M-tile per wave), different res/skip widths
     "c128_s256": (cases.wn_cfg(res_channels=128, skip_channels=256, num_res_layers=2, dilation_cycle=2), 1, 130),
+    # MFMA adjoints with 2 M-tiles per wave, dilations up to 64 > tile, ragged L, B > 1
+    "c256": (cases.wn_cfg(res_channels=256, skip_channels=256, num_res_layers=7, dilation_cycle=7), 2, 333),
 }
 
 
