@@ -76,13 +76,14 @@ template <bool SYM, int NG>
 __global__ __launch_bounds__(256) void cauchy_bwd_kernel(const float2* __restrict__ v, const float2* __restrict__ z,
                                                          const float2* __restrict__ w, const float2* __restrict__ dout,
                                                          float2* __restrict__ dv, float2* __restrict__ dw, int N,
-                                                         int L) {
+                                                         int L, int wmod) {
     const int b = blockIdx.x, n0 = blockIdx.y * NG, tid = threadIdx.x;
+    const int bw = wmod ? b % wmod : b;   // w broadcast over leading dims of v; dw stays per row of v
     float wr[NG], wi[NG], svr[NG], svi[NG], swr[NG], swi[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int n = min(n0 + g, N - 1);
-        const float2 ww = w[(size_t)b * N + n];
+        const float2 ww = w[(size_t)bw * N + n];
         wr[g] = ww.x; wi[g] = ww.y;
         svr[g] = svi[g] = swr[g] = swi[g] = 0.f;
     }
@@ -171,7 +172,7 @@ static int cauchy_fwd(const float* v, const float* z, const float* w, float* out
 
 template <bool SYM>
 static int cauchy_bwd(const float* v, const float* z, const float* w, const float* dout, float* dv, float* dw,
-                      int64_t B, int64_t N, int64_t L, hipStream_t s) {
+                      int64_t B, int64_t N, int64_t L, hipStream_t s, int wmod = 0) {
     DWS_TRY(check_shapes(SYM ? "cauchy_mult_sym_bwd" : "cauchy_mult_bwd", v, z, w, dout, B, N, L));
     if (B == 0) return DWS_OK;
     DWS_CHECK(dv && dw, DWS_ERR_INVALID, "cauchy bwd: null output");
@@ -180,7 +181,7 @@ static int cauchy_bwd(const float* v, const float* z, const float* w, const floa
     constexpr int NG = 4;
     dim3 grid((unsigned)B, (unsigned)ceil_div(N, NG));
     hipLaunchKernelGGL((cauchy_bwd_kernel<SYM, NG>), grid, dim3(256), 0, s, (const float2*)v, (const float2*)z,
-                       (const float2*)w, (const float2*)dout, (float2*)dv, (float2*)dw, (int)N, (int)L);
+                       (const float2*)w, (const float2*)dout, (float2*)dv, (float2*)dw, (int)N, (int)L, wmod);
     DWS_HIP(hipGetLastError());
     return DWS_OK;
 }
@@ -189,6 +190,12 @@ static int cauchy_bwd(const float* v, const float* z, const float* w, const floa
 int launch_cauchy_sym_fwd_bcast(const float* v, const float* z, const float* w, float* out, int64_t B, int64_t N,
                                 int64_t L, int wmod, hipStream_t s) {
     return cauchy_fwd<true>(v, z, w, out, B, N, L, s, wmod);
+}
+
+// internal: symmetric backward with w[B % wmod]; dw is per row of v (the caller sums the broadcast)
+int launch_cauchy_sym_bwd_bcast(const float* v, const float* z, const float* w, const float* dout, float* dv, float* dw,
+                                int64_t B, int64_t N, int64_t L, int wmod, hipStream_t s) {
+    return cauchy_bwd<true>(v, z, w, dout, dv, dw, B, N, L, s, wmod);
 }
 
 }  // namespace dws

@@ -16,7 +16,23 @@ struct FftConvArgs {
     const float2* kfb;  // [H][M/2] K_f at M - k
     const float2* kfs;  // [H][3]   K_f at 0, M, M/2
     int B, H, L;
+    // training variants (0 / null = the sampling path)
+    float* pre;         // also store the pre-activation conv + D u
+    int conj_k;         // multiply by conj(K_f): the adjoint (correlation) of the convolution
+    int no_act;         // g = conv + D u without the GELU
 };
+
+// dK_f partials of the convolution's kernel gradient: part[bs][h][k] = sum_{b in chunk bs} conj(U_b[k]) * dA_b[k],
+// k = 0..M (natural order), U / dA the Nf-point real spectra of the zero-padded rows.
+struct FftCorrArgs {
+    const float* u;     // [B,H,L]
+    const float* da;    // [B,H,L]
+    float2* part;       // [nbs][H][M+1]
+    const float2* tw;
+    const float2* twp;
+    int B, H, L, bchunk;
+};
+int launch_fftcorr(int log2m, const FftCorrArgs& a, hipStream_t s);
 
 bool fftconv_supported(int L, int* log2m);
 int launch_fftconv(int log2m, const FftConvArgs& a, hipStream_t s);

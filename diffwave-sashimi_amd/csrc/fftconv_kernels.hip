@@ -214,7 +214,7 @@ __device__ __forceinline__ int brev(int k, int bits) { return (int)(__brev((unsi
 template <int LOG2M, int THREADS>
 __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const float2* __restrict__ twp,
                                                 const float2* __restrict__ kfa, const float2* __restrict__ kfb,
-                                                const float2* __restrict__ kfs, int tid) {
+                                                const float2* __restrict__ kfs, int tid, float csign) {
     constexpr int M = 1 << LOG2M;
 #pragma unroll 1
     for (int it = 0; it < M / 2 / THREADS; ++it) {
@@ -226,7 +226,7 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
             const float y0 = (z0.x + z0.y) * kfs[0].x;   // A[0] = Re+Im, real; irfft ignores Im of DC / Nyquist
             const float ym = (z0.x - z0.y) * kfs[1].x;   // A[M] = Re-Im
             X[pidx(0)] = make_float2(0.5f * (y0 + ym), 0.5f * (y0 - ym));
-            X[pidx(1)] = cmulc(X[pidx(1)], kfs[2]);      // Zy[M/2] = Z[M/2] * conj(Kf[M/2])
+            X[pidx(1)] = cmulc(X[pidx(1)], make_float2(kfs[2].x, csign * kfs[2].y));  // Zy[M/2] = Z[M/2] * conj(Kf[M/2])
             continue;
         }
         const int k = brev(p, LOG2M);
@@ -238,7 +238,8 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
         const float2 xo = make_float2(0.5f * d.y, -0.5f * d.x);           // -(i/2) d
         const float2 t = cmul_(wk, xo);
         const float2 ak = cadd(xe, t), am = cconj(csub(xe, t));
-        const float2 yk = cmul_(ak, kfa[q]), ym = cmul_(am, kfb[q]);
+        const float2 ka = kfa[q], kb = kfb[q];   // csign = -1: conj(K_f), the adjoint of the convolution
+        const float2 yk = cmul_(ak, make_float2(ka.x, csign * ka.y)), ym = cmul_(am, make_float2(kb.x, csign * kb.y));
         const float2 ye = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
         const float2 e = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));  // (Yk - conj Ym)/2
         const float2 yo = cmulc(e, wk);
@@ -265,14 +266,100 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     __syncthreads();
     fft_forward<LOG2M, THREADS>(X, a.tw, W, tid);
     pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
-                                    a.kfs + (size_t)h * 3, tid);
+                                    a.kfs + (size_t)h * 3, tid, a.conj_k ? -1.f : 1.f);
     __syncthreads();
     fft_inverse<LOG2M, THREADS>(X, a.tw, W, tid);
     const float scale = 1.f / (float)M, Dh = a.D[h];
     float2* __restrict__ g2 = reinterpret_cast<float2*>(a.g + ((size_t)b * a.H + h) * L);
+    float2* __restrict__ p2 = a.pre ? reinterpret_cast<float2*>(a.pre + ((size_t)b * a.H + h) * L) : nullptr;
     for (int j = tid; j < Lc; j += THREADS) {
         const float2 y = X[pidx(j)], uu = u2[j];
-        g2[j] = make_float2(gelu_f(fmaf(y.x, scale, Dh * uu.x)), gelu_f(fmaf(y.y, scale, Dh * uu.y)));
+        const float2 v = make_float2(fmaf(y.x, scale, Dh * uu.x), fmaf(y.y, scale, Dh * uu.y));
+        if (p2) p2[j] = v;
+        g2[j] = a.no_act ? v : make_float2(gelu_f(v.x), gelu_f(v.y));
+    }
+}
+
+// Kernel-gradient partials (FftCorrArgs): the block owns channel h and a chunk of the batch; per sample it
+// transforms u then dA through the same LDS FFT and accumulates conj(U) * dA for the bins its threads own.
+template <int LOG2M, int THREADS>
+__global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
+    constexpr int M = 1 << LOG2M, NP = M / 2 / THREADS;
+    extern __shared__ __attribute__((aligned(16))) float2 X[];
+    const int tid = threadIdx.x, h = blockIdx.x, bs = blockIdx.y;
+    const int L = a.L, Lc = L / 2;
+    FftTw<LOG2M, THREADS> W;
+    W.load(a.tw, tid);
+    float2 ua[NP], ub[NP], pa[NP], pb[NP];
+    float u0 = 0.f, uM = 0.f, p0 = 0.f, pM = 0.f;
+    float2 uh = make_float2(0.f, 0.f), ph = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pa[i] = pb[i] = make_float2(0.f, 0.f);
+    const int b_end = min(a.B, (bs + 1) * a.bchunk);
+    // real-FFT bins of pair q from the bit-reversed half-size spectrum (see pointwise_pairs)
+    auto bins = [&](int q, float2& ak, float2& am) {
+        const int p = 2 * q;
+        const int k = brev(p, LOG2M);
+        const int pm = brev(M - k, LOG2M);
+        const float2 zk = X[pidx(p)], zm = X[pidx(pm)];
+        const float2 wk = a.twp[q];
+        const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);
+        const float2 t = cmul_(wk, make_float2(0.5f * d.y, -0.5f * d.x));
+        ak = cadd(xe, t);
+        am = cconj(csub(xe, t));
+    };
+#pragma unroll 1
+    for (int b = bs * a.bchunk; b < b_end; ++b) {
+        const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
+        const float2* __restrict__ d2 = reinterpret_cast<const float2*>(a.da + ((size_t)b * a.H + h) * L);
+        for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
+        __syncthreads();
+        fft_forward<LOG2M, THREADS>(X, a.tw, W, tid);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int q = tid + i * THREADS;
+            if (q == 0) {
+                const float2 z0 = X[pidx(0)];
+                u0 = z0.x + z0.y; uM = z0.x - z0.y; uh = cconj(X[pidx(1)]);   // A[0], A[M], A[M/2]
+            } else {
+                bins(q, ua[i], ub[i]);
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? d2[j] : make_float2(0.f, 0.f);
+        __syncthreads();
+        fft_forward<LOG2M, THREADS>(X, a.tw, W, tid);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int q = tid + i * THREADS;
+            if (q == 0) {
+                const float2 z0 = X[pidx(0)];
+                p0 = fmaf(u0, z0.x + z0.y, p0);
+                pM = fmaf(uM, z0.x - z0.y, pM);
+                ph = cadd(ph, cmulc(cconj(X[pidx(1)]), uh));
+            } else {
+                float2 dk, dm;
+                bins(q, dk, dm);
+                pa[i] = cadd(pa[i], cmulc(dk, ua[i]));   // dA * conj(U)
+                pb[i] = cadd(pb[i], cmulc(dm, ub[i]));
+            }
+        }
+        __syncthreads();
+    }
+    float2* __restrict__ o = a.part + ((size_t)bs * a.H + h) * (M + 1);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int q = tid + i * THREADS;
+        if (q == 0) {
+            o[0] = make_float2(p0, 0.f);
+            o[M] = make_float2(pM, 0.f);
+            o[M / 2] = ph;
+        } else {
+            const int k = brev(2 * q, LOG2M);
+            o[k] = pa[i];
+            o[M - k] = pb[i];
+        }
     }
 }
 
@@ -371,6 +458,19 @@ static int launch_fc(const FftConvArgs& a, hipStream_t s) {
 }
 
 template <int LOG2M>
+static int launch_fcorr(const FftCorrArgs& a, hipStream_t s) {
+    using C = FcCfg<LOG2M>;
+    auto kern = fftcorr_kernel<LOG2M, C::THREADS>;
+    static bool attr = false;
+    if (!attr) {
+        DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.H, ceil_div(a.B, a.bchunk)), dim3(C::THREADS), C::LDS, s, a);
+    return DWS_OK;
+}
+
+template <int LOG2M>
 static int launch_rf(const float* in, float* out, const float* tw, const float* twn, int H, hipStream_t s) {
     using C = FcCfg<LOG2M>;
     auto kern = rfft_rows_kernel<LOG2M, C::THREADS>;
@@ -397,6 +497,11 @@ static int launch_rf(const float* in, float* out, const float* tw, const float* 
 int launch_fftconv(int log2m, const FftConvArgs& a, hipStream_t s) {
     ProfileScope ps("fftconv", s);
     DWS_FC_DISPATCH(launch_fc, a, s);
+}
+
+int launch_fftcorr(int log2m, const FftCorrArgs& a, hipStream_t s) {
+    ProfileScope ps("fftcorr", s);
+    DWS_FC_DISPATCH(launch_fcorr, a, s);
 }
 
 int launch_rfft_rows(int log2m, const float* in, float* out, const float* tw, const float* twn, int H,

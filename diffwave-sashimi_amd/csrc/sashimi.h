@@ -24,4 +24,6 @@ int launch_pw_uppool(const float* x, const float* W, const float* bias, const fl
                      int Hin, int p, int Hout, int Lin, hipStream_t s);
 int launch_cauchy_sym_fwd_bcast(const float* v, const float* z, const float* w, float* out, int64_t B, int64_t N,
                                 int64_t L, int wmod, hipStream_t s);
+int launch_cauchy_sym_bwd_bcast(const float* v, const float* z, const float* w, const float* dout, float* dv, float* dw,
+                                int64_t B, int64_t N, int64_t L, int wmod, hipStream_t s);
 }  // namespace dws

@@ -17,7 +17,9 @@
 #include "model.h"
 #include "sashimi.h"
 #include "sashimi_mfma.h"
+#include "sashimi_train.h"
 #include "wavenet.h"
+#include "wavenet_backward.h"
 
 namespace dws {
 
@@ -67,12 +69,21 @@ struct SLayer {
     int log2m = 0;        // > 0: fused LDS FFT convolution is used for this block
     DevBuf melW0, melW1, melWc, melc;
     DevBuf out;           // activation produced by this layer
+    // training path: saved activations, gradient w.r.t. `out`, transposed weights in A-fragment order
+    DevBuf t_u, t_a, t_o, t_x1, t_n2, t_f1, t_xr, dbuf;
+    DevBuf tAo, tA1, tA2, tAp, tAoT, tA1T, tA2T, tApT;
+};
+
+struct Exec {             // one step of Sashimi.forward: out_node = layer(in_node) (+ add_node)
+    SLayer* l;
+    int in_node, add_node;
 };
 
 struct Stage {
     int H, L;
     bool rocfft = false;  // some block of this stage needs the rocFFT path
     DevBuf U, Uf, Y, g, x1, n2, ffu, y;
+    DevBuf d2, dh, dx1, du;  // training path gradients: [B][max(2,FF) H][L], [B][H][L] x 3
 };
 
 struct FftTables {
@@ -93,6 +104,13 @@ struct SashimiModel : dws_model {
     // commit scratch
     DevBuf cv, cwdt, cdt, cr, ckf, ck, cK, cKf;
     int64_t melBm = 0;
+    // training path
+    std::vector<Exec> plan;
+    DevBuf dx_init, ty, ta1, ta2, tAfT, tmp_pack, wpart, dWfold, lnpart, pool_scr, dpt, dh2, dh1, dWt_all, dbt_all;
+    DevBuf fpart, dKf, dKt, dkt, dkf, cgr, cgv, cgw, cpdt, dyb, dnf;
+    uint64_t commit_version = 0, train_pack_version = ~0ull;
+    bool trained_fwd = false;
+    const float* train_audio = nullptr;
 
     ~SashimiModel() override {
         for (auto* l : all) delete l;
@@ -349,6 +367,7 @@ struct SashimiModel : dws_model {
             DWS_HIP(hipStreamSynchronize(s));
         }
         dirty = false;
+        ++commit_version;
         melBm = 0;
         return DWS_OK;
     }
@@ -547,6 +566,388 @@ struct SashimiModel : dws_model {
         }
         last_x = x;
         DWS_TRY(final_stage(x, out, nullptr, s));
+        DWS_HIP(hipGetLastError());
+        return DWS_OK;
+    }
+
+
+    // ------------------------------------------------------------------ training path
+    // Execution plan of Sashimi.forward (sashimi.py:293-307) as nodes: node 0 = init-conv output,
+    // node i+1 = output of plan[i].  The skip stack becomes add_node references.
+    void build_plan() {
+        if (!plan.empty()) return;
+        std::vector<int> stack;
+        int x = 0;
+        auto push = [&](SLayer* l, int add) {
+            plan.push_back({l, x, add});
+            x = (int)plan.size();
+        };
+        for (auto* l : d_layers) { stack.push_back(x); push(l, -1); }
+        stack.push_back(x);
+        for (size_t i = 0; i < c_layers.size(); ++i) {
+            int add = -1;
+            if (i + 1 == c_layers.size()) { add = stack.back(); stack.pop_back(); }
+            push(c_layers[i], add);
+        }
+        for (auto* l : u_layers) {
+            int add = -1;
+            if (l->kind == L_UP || unet) { add = stack.back(); stack.pop_back(); }
+            push(l, add);
+        }
+    }
+    float* node_act(int i) { return i == 0 ? x_init.f() : plan[i - 1].l->out.f(); }
+    float* node_grad(int i) { return i == 0 ? dx_init.f() : plan[i - 1].l->dbuf.f(); }
+    size_t node_numel(int i) {
+        if (i == 0) return (size_t)B * D * L;
+        SLayer* l = plan[i - 1].l;
+        return (l->kind == L_BLOCK) ? (size_t)B * l->H * l->L : (size_t)B * l->Hout * l->Lout;
+    }
+
+    // A-fragment pack of W [O][K] and of its transpose (the adjoint GEMM), optionally scaled
+    int pack_pair(const float* W, int O, int K, DevBuf& A, DevBuf& AT, hipStream_t s) {
+        DWS_TRY(tmp_pack.ensure((size_t)O * K * 4));
+        DWS_TRY(A.ensure((size_t)O * K * 4));
+        DWS_TRY(AT.ensure((size_t)O * K * 4));
+        DWS_TRY(launch_pack_a_frag(W, A.f(), O, K, s));
+        DWS_TRY(launch_tapconv_pack_transposed(W, tmp_pack.f(), O, K, 1, O, 0, 1.f, s));
+        DWS_TRY(launch_pack_a_frag(tmp_pack.f(), AT.f(), K, O, s));
+        return DWS_OK;
+    }
+
+    int pack_train(hipStream_t s) {
+        for (auto* l : all) {
+            if (l->kind == L_BLOCK) {
+                const int H = l->H;
+                DWS_TRY(pack_pair(P(l->prefix + ".layer.output_linear.0.weight"), 2 * H, H, l->tAo, l->tAoT, s));
+                DWS_TRY(pack_pair(l->W1.f(), FF * H, H, l->tA1, l->tA1T, s));
+                DWS_TRY(pack_pair(l->W2.f(), H, FF * H, l->tA2, l->tA2T, s));
+            } else {
+                const int O = (l->kind == L_DOWN) ? l->Hout : l->Hout * l->p;
+                const int K = (l->kind == L_DOWN) ? l->H * l->p : l->H;
+                DWS_TRY(pack_pair(l->Wp.f(), O, K, l->tAp, l->tApT, s));
+            }
+        }
+        DWS_TRY(tmp_pack.ensure((size_t)D * D * 4));
+        DWS_TRY(tAfT.ensure((size_t)D * D * 4));
+        DWS_TRY(launch_tapconv_pack_transposed(Wf.f(), tmp_pack.f(), D, D, 1, D, 0, 1.f, s));
+        DWS_TRY(launch_pack_a_frag(tmp_pack.f(), tAfT.f(), D, D, s));
+        train_pack_version = commit_version;
+        return DWS_OK;
+    }
+
+    // out[b, m, l] = epi(sum_k A[m, k] src[b, k, l])   (tapconv_mfma, T = 1)
+    int gemm(const float* A, int M, int K, const float* src, float* out, int Lx, int epi, const float* bias,
+             const float* res, const float* addend, const float* aux, float* out2, hipStream_t s) {
+        TapConvArgs q{};
+        q.src0 = src; q.K0 = K; q.A = A; q.nkg_total = K / 8; q.M = M; q.T = 1; q.dil = 1; q.sign = 1; q.epi = epi;
+        q.out = out; q.bias = bias; q.res = res; q.addend = addend; q.aux = aux; q.out2 = out2;
+        q.addin = (epi == 0) ? aux : nullptr; q.addscale = 1.f;
+        q.B = (int)B; q.L = Lx;
+        return launch_tapconv_mfma(q, s);
+    }
+
+    // dW[o, c] = scale * sum_{b, l} dY[b, o, l] * act(X[b, c, l])
+    int wgrad(const float* dY, const float* X, int O, int Cc, int Lx, int xact, float* dW, hipStream_t s) {
+        WgradArgs w{};
+        w.dY = dY; w.X = X; w.B = (int)B; w.O = O; w.C = Cc; w.L = Lx; w.dil = 1; w.xact = xact;
+        w.nsplit = wgrad_mfma_nsplit((int)B, O, Cc, Lx, 1);
+        DWS_TRY(wpart.ensure((size_t)w.nsplit * O * Cc * 4));
+        w.partial = wpart.f();
+        return launch_wgrad_mfma(w, 1, 1.f, dW, s);
+    }
+
+    int wn_bwd(const std::string& p, const float* dWf, int O, int inner, hipStream_t s) {
+        return launch_weight_norm_bwd(dWf, P(p + ".weight_v"), P(p + ".weight_g"), G(p + ".weight_v"), G(p + ".weight_g"), O,
+                                      inner, s);
+    }
+
+    int train_supported() {
+        DWS_CHECK(melBm == 0 && !cond, DWS_ERR_UNSUPPORTED, "training of the mel-conditional path is not built yet");
+        for (auto* l : all) {
+            if (l->kind == L_BLOCK) {
+                DWS_CHECK(l->log2m > 0, DWS_ERR_UNSUPPORTED,
+                          "sashimi training needs the fused FFT convolution (L even, <= 16384 per stage); stage L=%d", l->L);
+                DWS_CHECK(l->H % 32 == 0, DWS_ERR_UNSUPPORTED, "sashimi training needs channel counts that are multiples of 32 (H=%d)", l->H);
+            }
+        }
+        DWS_CHECK(D % 32 == 0, DWS_ERR_UNSUPPORTED, "sashimi training needs d_model %% 32 == 0");
+        return DWS_OK;
+    }
+
+    int ensure_train_buffers() {
+        build_plan();
+        for (auto* st : stages) {
+            const size_t rows = (size_t)B * st->H * st->L * 4;
+            DWS_TRY(st->d2.ensure(rows * std::max(2, FF)));
+            DWS_TRY(st->dh.ensure(rows));
+            DWS_TRY(st->dx1.ensure(rows));
+            DWS_TRY(st->du.ensure(rows));
+            DWS_TRY(st->y.ensure(rows));
+        }
+        size_t pool_max = 4;
+        for (auto* l : all) {
+            if (l->kind == L_BLOCK) {
+                const size_t n = (size_t)B * l->H * l->L * 4;
+                DWS_TRY(l->t_u.ensure(n)); DWS_TRY(l->t_a.ensure(n)); DWS_TRY(l->t_o.ensure(2 * n));
+                DWS_TRY(l->t_x1.ensure(n)); DWS_TRY(l->t_n2.ensure(n)); DWS_TRY(l->t_f1.ensure((size_t)FF * n));
+                DWS_TRY(l->dbuf.ensure(n));
+            } else {
+                const size_t nin = (size_t)B * l->H * l->L * 4, nout = (size_t)B * l->Hout * l->Lout * 4;
+                DWS_TRY(l->dbuf.ensure(nout));
+                if (l->kind == L_DOWN) DWS_TRY(l->t_xr.ensure(nin));
+                pool_max = std::max(pool_max, std::max(nin, nout));
+            }
+        }
+        DWS_TRY(pool_scr.ensure(pool_max));
+        DWS_TRY(dx_init.ensure((size_t)B * D * L * 4));
+        DWS_TRY(ty.ensure((size_t)B * D * L * 4));
+        DWS_TRY(dyb.ensure((size_t)B * D * L * 4));
+        DWS_TRY(dnf.ensure((size_t)B * D * L * 4));
+        DWS_TRY(ta1.ensure((size_t)B * Emid * 4));
+        DWS_TRY(ta2.ensure((size_t)B * Eout * 4));
+        DWS_TRY(lnpart.ensure((size_t)B * ceil_div(L, 64) * 2 * 4));
+        return DWS_OK;
+    }
+
+    int forward_train(const float* audio, const float* steps, float* out, hipStream_t s) override {
+        DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
+        if (dirty) DWS_TRY(commit(s));
+        DWS_TRY(train_supported());
+        DWS_TRY(ensure_train_buffers());
+        if (train_pack_version != commit_version) DWS_TRY(pack_train(s));
+        const int nB = (int)B;
+        DWS_TRY(launch_init_conv(audio, Wi.f(), P("init_conv.0.conv.bias"), x_init.f(), nB, Cin, D, (int)L, s));
+        DWS_TRY(launch_step_embed(steps, freq.f(), emb.f(), nB, Ein / 2, s));
+        DWS_TRY(launch_linear_rows(emb.f(), P("fc_t1.weight"), P("fc_t1.bias"), h1.f(), nB, Ein, Emid, 1, s, ta1.f()));
+        DWS_TRY(launch_linear_rows(h1.f(), P("fc_t2.weight"), P("fc_t2.bias"), h2.f(), nB, Emid, Eout, 1, s, ta2.f()));
+        DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), nB, Eout, pt_total, 0, s));
+        for (size_t i = 0; i < plan.size(); ++i) {
+            const Exec& e = plan[i];
+            SLayer* l = e.l;
+            const float* x = node_act(e.in_node);
+            const float* add = e.add_node >= 0 ? node_act(e.add_node) : nullptr;
+            if (l->kind == L_BLOCK) {
+                Stage* st = stages[l->stage];
+                const int H = l->H, Ls = l->L;
+                const std::string& p = l->prefix;
+                DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, l->t_u.f(), nB, H,
+                                  Ls, (size_t)Ls, s));
+                FftTables* t = tables[l->log2m];
+                FftConvArgs fa{};
+                fa.u = l->t_u.f(); fa.g = st->g.f(); fa.pre = l->t_a.f(); fa.D = P(p + ".layer.D");
+                fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
+                fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
+                fa.B = nB; fa.H = H; fa.L = Ls;
+                DWS_TRY(launch_fftconv(l->log2m, fa, s));
+                DWS_TRY(gemm(l->tAo.f(), 2 * H, H, st->g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"), nullptr,
+                             nullptr, nullptr, nullptr, s));
+                DWS_TRY(launch_glu_res(l->t_o.f(), x, l->t_x1.f(), nB, H, Ls, s));
+                DWS_TRY(launch_ln(l->t_x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, l->t_n2.f(), nB, H, Ls,
+                                  (size_t)Ls, s));
+                DWS_TRY(gemm(l->tA1.f(), FF * H, H, l->t_n2.f(), l->t_f1.f(), Ls, 3, P(p + ".ff.ff.0.conv.bias"), nullptr,
+                             nullptr, nullptr, st->ffu.f(), s));
+                DWS_TRY(gemm(l->tA2.f(), H, FF * H, st->ffu.f(), l->out.f(), Ls, 4, P(p + ".ff.ff.2.conv.bias"), l->t_x1.f(),
+                             add, nullptr, nullptr, s));
+            } else if (l->kind == L_DOWN) {
+                DWS_TRY(launch_pool_rearrange(x, l->t_xr.f(), nullptr, 0, 0, nB, l->H, l->p, l->Lout, s));
+                DWS_TRY(gemm(l->tAp.f(), l->Hout, l->H * l->p, l->t_xr.f(), l->out.f(), l->Lout, 2,
+                             P(l->prefix + ".linear.conv.bias"), nullptr, nullptr, nullptr, nullptr, s));
+            } else {
+                DWS_TRY(gemm(l->tAp.f(), l->Hout * l->p, l->H, x, pool_scr.f(), l->L, 2, P(l->prefix + ".linear.conv.bias"),
+                             nullptr, nullptr, nullptr, nullptr, s));
+                DWS_TRY(launch_pool_rearrange(pool_scr.f(), l->out.f(), add, 1, 0, nB, l->Hout, l->p, l->L, s));
+            }
+        }
+        last_x = node_act((int)plan.size());
+        DWS_TRY(final_stage(last_x, out, ty.f(), s));
+        DWS_HIP(hipGetLastError());
+        train_audio = audio;
+        trained_fwd = true;
+        return DWS_OK;
+    }
+
+    // gradient of the S4 kernel parameters of one block from u and da (s4.py:704-807 backwards)
+    int kernel_backward(SLayer* l, const float* da, hipStream_t s) {
+        const int H = l->H, Ls = l->L, Lh = Ls / 2 + 1, N = NS, nB = (int)B;
+        const int M = 1 << l->log2m, Nf = 2 * M;
+        const std::string k = l->prefix + ".layer.kernel.kernel";
+        FftTables* t = tables[l->log2m];
+        const int nbs = std::max(1, std::min(nB, ceil_div(512, H)));
+        const int bchunk = ceil_div(nB, nbs);
+        const int nchunks = ceil_div(nB, bchunk);
+        DWS_TRY(fpart.ensure((size_t)nchunks * H * (M + 1) * 8));
+        DWS_TRY(dKf.ensure((size_t)H * (M + 1) * 8));
+        DWS_TRY(dKt.ensure((size_t)H * Nf * 4));
+        DWS_TRY(dkt.ensure((size_t)2 * H * Ls * 4));
+        DWS_TRY(dkf.ensure((size_t)2 * H * Lh * 8));
+        FftCorrArgs c{};
+        c.u = l->t_u.f(); c.da = da; c.part = (float2*)fpart.p; c.tw = (const float2*)t->tw.p; c.twp = (const float2*)t->twp.p;
+        c.B = nB; c.H = H; c.L = Ls; c.bchunk = bchunk;
+        DWS_TRY(launch_fftcorr(l->log2m, c, s));
+        DWS_TRY(launch_sum_leading(fpart.f(), dKf.f(), (size_t)H * (M + 1) * 2, nchunks, 1.f, s));
+        hipfftHandle plan_;
+        DWS_TRY(fft.get(1, Nf, H, &plan_));
+        DWS_FFT(hipfftSetStream(plan_, s));
+        DWS_FFT(hipfftExecC2R(plan_, (hipfftComplex*)dKf.p, (hipfftReal*)dKt.p));
+        // dK_t = C2R / Nf; k enters K as k / L (s4_twosided_pow2); dD[h] = sum u da = dK_t[h][0]
+        DWS_TRY(launch_s4_twosided_pow2_bwd(dKt.f(), dkt.f(), G(l->prefix + ".layer.D"), H, Ls, Nf,
+                                            1.f / ((float)Nf * (float)Ls), 1.f / (float)Nf, s));
+        DWS_TRY(fft.get(0, Ls, 2 * H, &plan_));
+        DWS_FFT(hipfftSetStream(plan_, s));
+        DWS_FFT(hipfftExecR2C(plan_, (hipfftReal*)dkt.p, (hipfftComplex*)dkf.p));
+        // regenerate v, w dt, r of this block (commit shares one scratch between the blocks)
+        DWS_TRY(cv.ensure((size_t)6 * H * N * 8));
+        DWS_TRY(cwdt.ensure((size_t)H * N * 8));
+        DWS_TRY(cdt.ensure((size_t)H * 4));
+        DWS_TRY(cr.ensure((size_t)6 * H * Lh * 8));
+        DWS_TRY(cgr.ensure((size_t)6 * H * Lh * 8));
+        DWS_TRY(cgv.ensure((size_t)6 * H * N * 8));
+        DWS_TRY(cgw.ensure((size_t)6 * H * N * 8));
+        const int nparts = ceil_div(Lh, 256);
+        DWS_TRY(cpdt.ensure((size_t)H * nparts * 4));
+        const float* z = P("__z." + std::to_string(Ls));
+        DWS_TRY(launch_s4_prep(P(k + ".C"), P(k + ".B"), P(k + ".P"), P(k + ".inv_w_real"), P(k + ".w_imag"),
+                               P(k + ".log_dt"), cv.f(), cwdt.f(), cdt.f(), H, N, s));
+        DWS_TRY(launch_cauchy_sym_fwd_bcast(cv.f(), z, cwdt.f(), cr.f(), 6 * H, N, Lh, H, s));
+        DWS_TRY(launch_s4_woodbury_bwd(cr.f(), P("__omega." + std::to_string(Ls)), cdt.f(), dkf.f(), cgr.f(), cpdt.f(), H,
+                                       Lh, (Ls % 2) == 0, s));
+        DWS_TRY(launch_cauchy_sym_bwd_bcast(cv.f(), z, cwdt.f(), cgr.f(), cgv.f(), cgw.f(), 6 * H, N, Lh, H, s));
+        DWS_TRY(launch_s4_prep_bwd(P(k + ".C"), P(k + ".B"), P(k + ".P"), P(k + ".inv_w_real"), P(k + ".w_imag"),
+                                   P(k + ".log_dt"), cgv.f(), cgw.f(), cpdt.f(), nparts, G(k + ".C"), G(k + ".B"), G(k + ".P"),
+                                   G(k + ".inv_w_real"), G(k + ".w_imag"), G(k + ".log_dt"), H, N, s));
+        return DWS_OK;
+    }
+
+    int ln_scalars(const std::string& p, int nblk, hipStream_t s) {
+        // lnpart holds [2][nblk] = (dm, ds) partials
+        DWS_TRY(launch_sum_leading(lnpart.f(), G(p + ".m"), 1, nblk, 1.f, s));
+        DWS_TRY(launch_sum_leading(lnpart.f() + nblk, G(p + ".s"), 1, nblk, 1.f, s));
+        return DWS_OK;
+    }
+
+    // Adjoint of forward_train, plan steps in reverse (sashimi.py:143-184,277-313).
+    int backward(const float* dout, hipStream_t s) override {
+        DWS_CHECK(trained_fwd, DWS_ERR_STATE, "backward without a preceding forward_train");
+        const int nB = (int)B, nL = (int)L;
+        const int nnodes = (int)plan.size() + 1;
+        std::vector<char> written(nnodes, 0);
+        size_t wmax = (size_t)D * D;
+        for (auto* l : all) {
+            if (l->kind == L_BLOCK) wmax = std::max(wmax, (size_t)2 * l->H * l->H * std::max(1, FF));
+            else wmax = std::max(wmax, (size_t)l->H * l->p * l->Hout * std::max(l->p, 1));
+        }
+        DWS_TRY(dWfold.ensure(wmax * 4));
+        DWS_TRY(dpt.ensure((size_t)B * pt_total * 4));
+        DWS_TRY(dh2.ensure((size_t)B * Eout * 4)); DWS_TRY(dh1.ensure((size_t)B * Emid * 4));
+        DWS_TRY(dWt_all.ensure((size_t)pt_total * Eout * 4)); DWS_TRY(dbt_all.ensure((size_t)pt_total * 4));
+
+        // ---- final stage: out = Wz y + bz, y = relu(Wf LN(x) + bf)
+        DWS_TRY(launch_wgrad(dout, ty.f(), nullptr, 0, G("final_conv.2.conv.weight"), nB, Cout, D, nL, 1, 1, 1.f, s));
+        DWS_TRY(launch_rowsum(dout, G("final_conv.2.conv.bias"), nB, Cout, nL, 1.f, 0, s));
+        DWS_TRY(launch_final_dy(dout, P("final_conv.2.conv.weight"), ty.f(), dyb.f(), nB, D, Cout, nL, s));
+        DWS_TRY(wgrad(dyb.f(), nfin.f(), D, D, nL, 0, dWfold.f(), s));
+        DWS_TRY(wn_bwd("final_conv.0.conv", dWfold.f(), D, D, s));
+        DWS_TRY(launch_rowsum(dyb.f(), G("final_conv.0.conv.bias"), nB, D, nL, 1.f, 0, s));
+        DWS_TRY(gemm(tAfT.f(), D, D, dyb.f(), dnf.f(), nL, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+        {
+            const int last = nnodes - 1;
+            DWS_TRY(launch_ln_bwd(node_act(last), dnf.f(), P("norm.m"), P("norm.s"), nullptr, node_grad(last), 0, lnpart.f(),
+                                  nB, D, nL, s));
+            DWS_TRY(ln_scalars("norm", nB * ceil_div(nL, 64), s));
+            written[last] = 1;
+        }
+
+        for (int i = (int)plan.size() - 1; i >= 0; --i) {
+            const Exec& e = plan[i];
+            SLayer* l = e.l;
+            const float* x = node_act(e.in_node);
+            const float* dy = node_grad(i + 1);
+            float* din = node_grad(e.in_node);
+            DWS_CHECK(written[i + 1], DWS_ERR_STATE, "backward: no gradient reached node %d", i + 1);
+            const std::string& p = l->prefix;
+            if (l->kind == L_BLOCK) {
+                Stage* st = stages[l->stage];
+                const int H = l->H, Ls = l->L, nblk = nB * ceil_div(Ls, 64);
+                // ff: out = x1 + W2 gelu(f1) + b2, f1 = W1 n2 + b1
+                DWS_TRY(gemm(l->tA2T.f(), FF * H, H, dy, st->d2.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_f1.f(), nullptr, s));
+                DWS_TRY(wgrad(dy, l->t_f1.f(), H, FF * H, Ls, 1, dWfold.f(), s));
+                DWS_TRY(wn_bwd(p + ".ff.ff.2.conv", dWfold.f(), H, FF * H, s));
+                DWS_TRY(launch_rowsum(dy, G(p + ".ff.ff.2.conv.bias"), nB, H, Ls, 1.f, 0, s));
+                DWS_TRY(gemm(l->tA1T.f(), H, FF * H, st->d2.f(), st->dh.f(), Ls, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+                DWS_TRY(wgrad(st->d2.f(), l->t_n2.f(), FF * H, H, Ls, 0, dWfold.f(), s));
+                DWS_TRY(wn_bwd(p + ".ff.ff.0.conv", dWfold.f(), FF * H, H, s));
+                DWS_TRY(launch_rowsum(st->d2.f(), G(p + ".ff.ff.0.conv.bias"), nB, FF * H, Ls, 1.f, 0, s));
+                // norm2: dx1 = dy + LN'(dn2)
+                DWS_TRY(launch_ln_bwd(l->t_x1.f(), st->dh.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), dy, st->dx1.f(), 0,
+                                      lnpart.f(), nB, H, Ls, s));
+                DWS_TRY(ln_scalars(p + ".norm2", nblk, s));
+                // x1 = x + glu(o), o = Wo gelu(a) + bo
+                DWS_TRY(launch_glu_bwd(st->dx1.f(), l->t_o.f(), st->d2.f(), nB, H, Ls, s));
+                DWS_TRY(gemm(l->tAoT.f(), H, 2 * H, st->d2.f(), st->dh.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_a.f(), nullptr, s));
+                DWS_TRY(wgrad(st->d2.f(), l->t_a.f(), 2 * H, H, Ls, 1, G(p + ".layer.output_linear.0.weight"), s));
+                DWS_TRY(launch_rowsum(st->d2.f(), G(p + ".layer.output_linear.0.bias"), nB, 2 * H, Ls, 1.f, 0, s));
+                // a = conv(u, K) + D u: du = conv^T(da) + D da; kernel parameters from corr(u, da)
+                FftTables* t = tables[l->log2m];
+                FftConvArgs fa{};
+                fa.u = st->dh.f(); fa.g = st->du.f(); fa.D = P(p + ".layer.D"); fa.conj_k = 1; fa.no_act = 1;
+                fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
+                fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
+                fa.B = nB; fa.H = H; fa.L = Ls;
+                DWS_TRY(launch_fftconv(l->log2m, fa, s));
+                DWS_TRY(kernel_backward(l, st->dh.f(), s));
+                // u = LN1(x) + fc_t(e): dx = dx1 + LN'(du)
+                DWS_TRY(launch_rowsum_bc(st->du.f(), dpt.f() + l->pt_off, pt_total, nB, H, Ls, s));
+                DWS_TRY(launch_ln_bwd(x, st->du.f(), P(p + ".norm1.m"), P(p + ".norm1.s"), st->dx1.f(), din, written[e.in_node],
+                                      lnpart.f(), nB, H, Ls, s));
+                DWS_TRY(ln_scalars(p + ".norm1", nblk, s));
+                written[e.in_node] = 1;
+            } else if (l->kind == L_DOWN) {
+                const int K = l->H * l->p, O = l->Hout;
+                DWS_TRY(wgrad(dy, l->t_xr.f(), O, K, l->Lout, 0, dWfold.f(), s));
+                DWS_TRY(wn_bwd(p + ".linear.conv", dWfold.f(), O, K, s));
+                DWS_TRY(launch_rowsum(dy, G(p + ".linear.conv.bias"), nB, O, l->Lout, 1.f, 0, s));
+                DWS_TRY(gemm(l->tApT.f(), K, O, dy, pool_scr.f(), l->Lout, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+                DWS_TRY(launch_pool_rearrange(pool_scr.f(), din, nullptr, 1, written[e.in_node], nB, l->H, l->p, l->Lout, s));
+                written[e.in_node] = 1;
+            } else {
+                const int K = l->H, O = l->Hout * l->p;   // xl = Wp x + b, [B][O][L_in]
+                DWS_TRY(launch_pool_rearrange(dy, pool_scr.f(), nullptr, 0, 0, nB, l->Hout, l->p, l->L, s));
+                DWS_TRY(wgrad(pool_scr.f(), x, O, K, l->L, 0, dWfold.f(), s));
+                DWS_TRY(wn_bwd(p + ".linear.conv", dWfold.f(), O, K, s));
+                DWS_TRY(launch_rowsum(pool_scr.f(), G(p + ".linear.conv.bias"), nB, O, l->L, 1.f, 0, s));
+                if (written[e.in_node])
+                    DWS_TRY(gemm(l->tApT.f(), K, O, pool_scr.f(), din, l->L, 0, nullptr, nullptr, nullptr, din, nullptr, s));
+                else
+                    DWS_TRY(gemm(l->tApT.f(), K, O, pool_scr.f(), din, l->L, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+                written[e.in_node] = 1;
+            }
+            if (e.add_node >= 0) {  // the skip connection receives the same gradient
+                DWS_TRY(launch_add_into(dy, node_grad(e.add_node), written[e.add_node], node_numel(e.add_node), s));
+                written[e.add_node] = 1;
+            }
+        }
+
+        // ---- init_conv: x0 = relu(Wi audio + bi)
+        const size_t nact = (size_t)B * D * L;
+        DWS_CHECK(written[0], DWS_ERR_STATE, "backward: no gradient reached the init conv");
+        DWS_TRY(launch_relu_bwd(dx_init.f(), x_init.f(), nact, s));
+        DWS_TRY(launch_wgrad(dx_init.f(), train_audio, nullptr, 0, dWfold.f(), nB, D, Cin, nL, 1, 1, 1.f, s));
+        DWS_TRY(wn_bwd("init_conv.0.conv", dWfold.f(), D, Cin, s));
+        DWS_TRY(launch_rowsum(dx_init.f(), G("init_conv.0.conv.bias"), nB, D, nL, 1.f, 0, s));
+
+        // ---- step embedding: per-block fc_t (stacked), then the shared swish MLP
+        DWS_TRY(launch_lin_bwd_w(dpt.f(), h2.f(), dWt_all.f(), dbt_all.f(), nB, Eout, pt_total, s));
+        for (auto* l : all) {
+            if (l->kind != L_BLOCK) continue;
+            DWS_HIP(hipMemcpyAsync(G(l->prefix + ".fc_t.weight"), dWt_all.f() + (size_t)l->pt_off * Eout,
+                                   (size_t)l->H * Eout * 4, hipMemcpyDeviceToDevice, s));
+            DWS_HIP(hipMemcpyAsync(G(l->prefix + ".fc_t.bias"), dbt_all.f() + l->pt_off, (size_t)l->H * 4,
+                                   hipMemcpyDeviceToDevice, s));
+        }
+        DWS_TRY(launch_lin_bwd_x(dpt.f(), Wt_all.f(), ta2.f(), dh2.f(), nB, Eout, pt_total, s));
+        DWS_TRY(launch_lin_bwd_w(dh2.f(), h1.f(), G("fc_t2.weight"), G("fc_t2.bias"), nB, Emid, Eout, s));
+        DWS_TRY(launch_lin_bwd_x(dh2.f(), P("fc_t2.weight"), ta1.f(), dh1.f(), nB, Emid, Eout, s));
+        DWS_TRY(launch_lin_bwd_w(dh1.f(), emb.f(), G("fc_t1.weight"), G("fc_t1.bias"), nB, Ein, Emid, s));
         DWS_HIP(hipGetLastError());
         return DWS_OK;
     }

@@ -1,0 +1,21 @@
+// Launch interface of sashimi_train.hip (internal to libdws.so).
+#pragma once
+#include "dws_common.h"
+
+namespace dws {
+int launch_ln_bwd(const float* x, const float* dy, const float* m_p, const float* s_p, const float* base, float* out,
+                  int accumulate, float* partial, int B, int H, int L, hipStream_t s);
+int launch_sum_leading(const float* partial, float* out, size_t n, int k, float scale, hipStream_t s);
+int launch_glu_res(const float* o, const float* x, float* x1, int B, int H, int L, hipStream_t s);
+int launch_glu_bwd(const float* dx1, const float* o, float* dout, int B, int H, int L, hipStream_t s);
+int launch_pool_rearrange(const float* in, float* out, const float* addend, int dir, int accumulate, int B, int H,
+                          int p, int Lp, hipStream_t s);
+int launch_add_into(const float* a, float* out, int accumulate, size_t n, hipStream_t s);
+int launch_s4_twosided_pow2_bwd(const float* dK, float* dkt, float* dD, int H, int L, int Nf, float sc, float scD,
+                                hipStream_t s);
+int launch_s4_woodbury_bwd(const float* r, const float* omega, const float* dt, const float* dkf, float* gr,
+                           float* part_dt, int H, int Lh, int n_even, hipStream_t s);
+int launch_s4_prep_bwd(const float* C, const float* Bp, const float* P, const float* iwr, const float* wim,
+                       const float* log_dt, const float* gv, const float* gw6, const float* part_dt, int nparts, float* gC,
+                       float* gB, float* gP, float* giwr, float* gwim, float* glogdt, int H, int N, hipStream_t s);
+}  // namespace dws

@@ -29,10 +29,11 @@ struct TapConvArgs {
     const float* A;              // A fragments of the [M][nkg_total*8] transposed weight (pack_a_frag order)
     int nkg_total;               // k-groups per fragment row in A (the launch may use a prefix of them)
     int M, T, dil, sign;         // tap t reads position l + sign * (t - T/2) * dil
-    int epi;                     // 0: out = acc + addin * addscale;  1: gate adjoint (dH, g from H)
+    int epi;                     // see the kernel: 0 add, 1 gate adjoint, 2 bias, 3 bias+gelu (pre and act), 4 bias+res, 5 gelu'
     float* out;
     const float* addin; float addscale;
     const float* H; float* dH; float* g;
+    const float* bias; const float* res; const float* addend; const float* aux; float* out2;
     int B, L;
 };
 bool tapconv_mfma_supported(int M, int K0, int K1, int T);
@@ -46,6 +47,7 @@ struct WgradArgs {
     const float* addc; int addc_bstride;   // optional per-(b, c) constant added to in-range X
     float* partial;              // [nsplit][O][C][T] scratch
     int B, O, C, L, dil, nsplit;
+    int xact;                    // 1: the X operand is gelu(X) (recomputed from the saved pre-activation)
 };
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T);
 int launch_wgrad_mfma(const WgradArgs& a, int T, float scale, float* dW, hipStream_t s);

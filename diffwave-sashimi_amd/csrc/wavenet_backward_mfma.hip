@@ -26,7 +26,16 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, i
 }
 __device__ __forceinline__ float sigm_b(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int MT, int T>
+__device__ __forceinline__ float gelu_b(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_b(float x) {  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+// EPI (all rows m of an M-block, positions of the tile):
+//   0  out = acc (+ addin * addscale)                       1  gate adjoint (WaveNet)
+//   2  out = acc + bias[m]                                   3  out = acc + bias (pre-activation), out2 = gelu(out)
+//   4  out = acc + bias + res (+ addend)                     5  out = acc * gelu'(aux)
+template <int MT, int T, int EPI>
 __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
     constexpr int P = 64, NT = 2, KC = 32;
     constexpr int ROWS = T * KC, RPW = ROWS / 4;
@@ -39,6 +48,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
     const int ntl = (L + P - 1) / P;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int b = tile / ntl, l0 = (tile % ntl) * P;
+    const int mt0 = blockIdx.y * (4 * MT);   // first 32-row tile of this M-block
     const int K = a.K0 + a.K1;
     const int ncb = K / KC;
 
@@ -69,7 +79,9 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
     const int lane16 = lane * 16;
     int mt[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) mt[m] = wave * MT + m;
+    for (int m = 0; m < MT; ++m) mt[m] = mt0 + wave * MT + m;
+    // rows beyond M (M not a multiple of the M-block): the wave only helps staging; A loads are OOB -> 0
+    const bool wave_live = mt[0] * 32 < a.M;
 
     stage_dma(0, 0);
     f32x4 a_cur[MT], a_nxt[MT];
@@ -106,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
     }
 
     const int M = a.M;
+    if (!wave_live) return;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int pos = l0 + n * 32 + l31;
@@ -113,24 +126,8 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
         const int posc = ok ? pos : 0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if (a.epi == 0) {
-                float ad[16];
-                if (a.addin) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        ad[r] = a.addin[((size_t)b * M + row) * L + posc] * a.addscale;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ad[r] = 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (ok) a.out[((size_t)b * M + row) * L + pos] = acc[m][n][r] + ad[r];
-                }
-            } else {  // gate adjoint: M == C, H / dH are [B, 2C, L]
+            if (mt[m] * 32 >= M) continue;
+            if (EPI == 1) {  // gate adjoint: M == C, H / dH are [B, 2C, L]
                 float ht[16], hs[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -148,23 +145,46 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
                         a.dH[((size_t)b * 2 * M + M + c) * L + pos] = d * th * sg * (1.f - sg);
                     }
                 }
+            } else {
+                float ad[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const size_t idx = ((size_t)b * M + row) * L + posc;
+                    if (EPI == 0) ad[r] = a.addin ? a.addin[idx] * a.addscale : 0.f;
+                    else if (EPI == 2 || EPI == 3) ad[r] = a.bias ? a.bias[row] : 0.f;
+                    else if (EPI == 4) ad[r] = a.bias[row] + a.res[idx] + (a.addend ? a.addend[idx] : 0.f);
+                    else ad[r] = a.aux[idx];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const size_t idx = ((size_t)b * M + row) * L + pos;
+                    if (!ok) continue;
+                    if (EPI == 5) {
+                        a.out[idx] = acc[m][n][r] * gelu_grad_b(ad[r]);
+                    } else {
+                        const float v = acc[m][n][r] + ad[r];
+                        a.out[idx] = v;
+                        if (EPI == 3) a.out2[idx] = gelu_b(v);
+                    }
+                }
             }
         }
     }
 }
 
 bool tapconv_mfma_supported(int M, int K0, int K1, int T) {
-    return (M == 128 || M == 256) && K0 % 32 == 0 && K1 % 32 == 0 && (K0 + K1) > 0 && (T == 1 || T == 3);
+    return M % 32 == 0 && M > 0 && K0 % 32 == 0 && K1 % 32 == 0 && (K0 + K1) > 0 && (T == 1 || T == 3);
 }
 
-template <int T>
+template <int T, int EPI>
 static int launch_tc(const TapConvArgs& a, hipStream_t s) {
-    const dim3 grid(a.B * ceil_div(a.L, 64));
-    switch (a.M) {
-        case 128: hipLaunchKernelGGL((tapconv_mfma_kernel<1, T>), grid, dim3(256), 0, s, a); break;
-        case 256: hipLaunchKernelGGL((tapconv_mfma_kernel<2, T>), grid, dim3(256), 0, s, a); break;
-        default: return set_error(DWS_ERR_UNSUPPORTED, "tapconv_mfma: M=%d", a.M);
-    }
+    const int nt = a.B * ceil_div(a.L, 64);
+    if (a.M % 256 == 0 || a.M > 512)
+        hipLaunchKernelGGL((tapconv_mfma_kernel<2, T, EPI>), dim3(nt, ceil_div(a.M, 256)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((tapconv_mfma_kernel<1, T, EPI>), dim3(nt, ceil_div(a.M, 128)), dim3(256), 0, s, a);
     return DWS_OK;
 }
 
@@ -172,7 +192,19 @@ int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s) {
     ProfileScope ps("tapconv_mfma", s);
     DWS_CHECK(tapconv_mfma_supported(a.M, a.K0, a.K1, a.T), DWS_ERR_UNSUPPORTED, "tapconv_mfma: M=%d K=%d+%d T=%d", a.M,
               a.K0, a.K1, a.T);
-    return a.T == 3 ? launch_tc<3>(a, s) : launch_tc<1>(a, s);
+    if (a.T == 3) {
+        DWS_CHECK(a.epi == 0, DWS_ERR_UNSUPPORTED, "tapconv_mfma: T=3 has epilogue 0 only");
+        return launch_tc<3, 0>(a, s);
+    }
+    switch (a.epi) {
+        case 0: return launch_tc<1, 0>(a, s);
+        case 1: return launch_tc<1, 1>(a, s);
+        case 2: return launch_tc<1, 2>(a, s);
+        case 3: return launch_tc<1, 3>(a, s);
+        case 4: return launch_tc<1, 4>(a, s);
+        case 5: return launch_tc<1, 5>(a, s);
+    }
+    return set_error(DWS_ERR_INVALID, "tapconv_mfma: epilogue %d", a.epi);
 }
 
 // Row-major block of A in the kernel's K order k' = ((cb*T + tap)*KC + cc), o = cb*KC + cc, from a conv
@@ -243,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
                 const int cc = c < a.C ? c : 0;
                 const float v = a.X[((size_t)b * a.C + cc) * L + (((unsigned)ps < (unsigned)L) ? ps : 0)];
                 const float ad = a.addc ? a.addc[(size_t)b * a.addc_bstride + cc] : 0.f;
-                xv = (v + ad) * (ok ? 1.f : 0.f);
+                xv = ((a.xact ? gelu_b(v) : v) + ad) * (ok ? 1.f : 0.f);
             }
             sdy[row * LD + lane] = dv;
             sx[row * LD + lane] = xv;
