@@ -107,7 +107,7 @@ struct SashimiModel : dws_model {
     // training path
     std::vector<Exec> plan;
     DevBuf dx_init, ty, ta1, ta2, tAfT, tmp_pack, wpart, dWfold, lnpart, pool_scr, dpt, dh2, dh1, dWt_all, dbt_all;
-    DevBuf fpart, dKf, dKt, dkt, dkf, cgr, cgv, cgw, cpdt, dyb, dnf;
+    DevBuf bpart, fpart, dKf, dKt, dkt, dkf, cgr, cgv, cgw, cpdt, dyb, dnf;
     uint64_t commit_version = 0, train_pack_version = ~0ull;
     bool trained_fwd = false;
     const float* train_audio = nullptr;
@@ -646,13 +646,17 @@ struct SashimiModel : dws_model {
         return launch_tapconv_mfma(q, s);
     }
 
-    // dW[o, c] = scale * sum_{b, l} dY[b, o, l] * act(X[b, c, l])
-    int wgrad(const float* dY, const float* X, int O, int Cc, int Lx, int xact, float* dW, hipStream_t s) {
+    // dW[o, c] = sum_{b, l} dY[b, o, l] * act(X[b, c, l]);  db[o] = sum_{b, l} dY[b, o, l] (optional, same pass)
+    int wgrad(const float* dY, const float* X, int O, int Cc, int Lx, int xact, float* dW, float* db, hipStream_t s) {
         WgradArgs w{};
         w.dY = dY; w.X = X; w.B = (int)B; w.O = O; w.C = Cc; w.L = Lx; w.dil = 1; w.xact = xact;
         w.nsplit = wgrad_mfma_nsplit((int)B, O, Cc, Lx, 1);
         DWS_TRY(wpart.ensure((size_t)w.nsplit * O * Cc * 4));
         w.partial = wpart.f();
+        if (db) {
+            DWS_TRY(bpart.ensure((size_t)w.nsplit * O * 4));
+            w.bias_part = bpart.f(); w.dbias = db; w.bias_scale = 1.f;
+        }
         return launch_wgrad_mfma(w, 1, 1.f, dW, s);
     }
 
@@ -845,9 +849,8 @@ struct SashimiModel : dws_model {
         DWS_TRY(launch_wgrad(dout, ty.f(), nullptr, 0, G("final_conv.2.conv.weight"), nB, Cout, D, nL, 1, 1, 1.f, s));
         DWS_TRY(launch_rowsum(dout, G("final_conv.2.conv.bias"), nB, Cout, nL, 1.f, 0, s));
         DWS_TRY(launch_final_dy(dout, P("final_conv.2.conv.weight"), ty.f(), dyb.f(), nB, D, Cout, nL, s));
-        DWS_TRY(wgrad(dyb.f(), nfin.f(), D, D, nL, 0, dWfold.f(), s));
+        DWS_TRY(wgrad(dyb.f(), nfin.f(), D, D, nL, 0, dWfold.f(), G("final_conv.0.conv.bias"), s));
         DWS_TRY(wn_bwd("final_conv.0.conv", dWfold.f(), D, D, s));
-        DWS_TRY(launch_rowsum(dyb.f(), G("final_conv.0.conv.bias"), nB, D, nL, 1.f, 0, s));
         DWS_TRY(gemm(tAfT.f(), D, D, dyb.f(), dnf.f(), nL, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
         {
             const int last = nnodes - 1;
@@ -870,13 +873,11 @@ struct SashimiModel : dws_model {
                 const int H = l->H, Ls = l->L, nblk = nB * ceil_div(Ls, 64);
                 // ff: out = x1 + W2 gelu(f1) + b2, f1 = W1 n2 + b1
                 DWS_TRY(gemm(l->tA2T.f(), FF * H, H, dy, st->d2.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_f1.f(), nullptr, s));
-                DWS_TRY(wgrad(dy, l->t_f1.f(), H, FF * H, Ls, 1, dWfold.f(), s));
+                DWS_TRY(wgrad(dy, l->t_f1.f(), H, FF * H, Ls, 1, dWfold.f(), G(p + ".ff.ff.2.conv.bias"), s));
                 DWS_TRY(wn_bwd(p + ".ff.ff.2.conv", dWfold.f(), H, FF * H, s));
-                DWS_TRY(launch_rowsum(dy, G(p + ".ff.ff.2.conv.bias"), nB, H, Ls, 1.f, 0, s));
                 DWS_TRY(gemm(l->tA1T.f(), H, FF * H, st->d2.f(), st->dh.f(), Ls, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
-                DWS_TRY(wgrad(st->d2.f(), l->t_n2.f(), FF * H, H, Ls, 0, dWfold.f(), s));
+                DWS_TRY(wgrad(st->d2.f(), l->t_n2.f(), FF * H, H, Ls, 0, dWfold.f(), G(p + ".ff.ff.0.conv.bias"), s));
                 DWS_TRY(wn_bwd(p + ".ff.ff.0.conv", dWfold.f(), FF * H, H, s));
-                DWS_TRY(launch_rowsum(st->d2.f(), G(p + ".ff.ff.0.conv.bias"), nB, FF * H, Ls, 1.f, 0, s));
                 // norm2: dx1 = dy + LN'(dn2)
                 DWS_TRY(launch_ln_bwd(l->t_x1.f(), st->dh.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), dy, st->dx1.f(), 0,
                                       lnpart.f(), nB, H, Ls, s));
@@ -884,8 +885,8 @@ struct SashimiModel : dws_model {
                 // x1 = x + glu(o), o = Wo gelu(a) + bo
                 DWS_TRY(launch_glu_bwd(st->dx1.f(), l->t_o.f(), st->d2.f(), nB, H, Ls, s));
                 DWS_TRY(gemm(l->tAoT.f(), H, 2 * H, st->d2.f(), st->dh.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_a.f(), nullptr, s));
-                DWS_TRY(wgrad(st->d2.f(), l->t_a.f(), 2 * H, H, Ls, 1, G(p + ".layer.output_linear.0.weight"), s));
-                DWS_TRY(launch_rowsum(st->d2.f(), G(p + ".layer.output_linear.0.bias"), nB, 2 * H, Ls, 1.f, 0, s));
+                DWS_TRY(wgrad(st->d2.f(), l->t_a.f(), 2 * H, H, Ls, 1, G(p + ".layer.output_linear.0.weight"),
+                              G(p + ".layer.output_linear.0.bias"), s));
                 // a = conv(u, K) + D u: du = conv^T(da) + D da; kernel parameters from corr(u, da)
                 FftTables* t = tables[l->log2m];
                 FftConvArgs fa{};
@@ -903,18 +904,16 @@ struct SashimiModel : dws_model {
                 written[e.in_node] = 1;
             } else if (l->kind == L_DOWN) {
                 const int K = l->H * l->p, O = l->Hout;
-                DWS_TRY(wgrad(dy, l->t_xr.f(), O, K, l->Lout, 0, dWfold.f(), s));
+                DWS_TRY(wgrad(dy, l->t_xr.f(), O, K, l->Lout, 0, dWfold.f(), G(p + ".linear.conv.bias"), s));
                 DWS_TRY(wn_bwd(p + ".linear.conv", dWfold.f(), O, K, s));
-                DWS_TRY(launch_rowsum(dy, G(p + ".linear.conv.bias"), nB, O, l->Lout, 1.f, 0, s));
                 DWS_TRY(gemm(l->tApT.f(), K, O, dy, pool_scr.f(), l->Lout, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
                 DWS_TRY(launch_pool_rearrange(pool_scr.f(), din, nullptr, 1, written[e.in_node], nB, l->H, l->p, l->Lout, s));
                 written[e.in_node] = 1;
             } else {
                 const int K = l->H, O = l->Hout * l->p;   // xl = Wp x + b, [B][O][L_in]
                 DWS_TRY(launch_pool_rearrange(dy, pool_scr.f(), nullptr, 0, 0, nB, l->Hout, l->p, l->L, s));
-                DWS_TRY(wgrad(pool_scr.f(), x, O, K, l->L, 0, dWfold.f(), s));
+                DWS_TRY(wgrad(pool_scr.f(), x, O, K, l->L, 0, dWfold.f(), G(p + ".linear.conv.bias"), s));
                 DWS_TRY(wn_bwd(p + ".linear.conv", dWfold.f(), O, K, s));
-                DWS_TRY(launch_rowsum(pool_scr.f(), G(p + ".linear.conv.bias"), nB, O, l->L, 1.f, 0, s));
                 if (written[e.in_node])
                     DWS_TRY(gemm(l->tApT.f(), K, O, pool_scr.f(), din, l->L, 0, nullptr, nullptr, nullptr, din, nullptr, s));
                 else

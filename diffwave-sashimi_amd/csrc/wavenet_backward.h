@@ -48,6 +48,8 @@ struct WgradArgs {
     float* partial;              // [nsplit][O][C][T] scratch
     int B, O, C, L, dil, nsplit;
     int xact;                    // 1: the X operand is gelu(X) (recomputed from the saved pre-activation)
+    float* bias_part;            // optional [nsplit][O] scratch: also produce dbias[o] = bias_scale * sum_{b,l} dY[b,o,l]
+    float* dbias; float bias_scale;
 };
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T);
 int launch_wgrad_mfma(const WgradArgs& a, int T, float scale, float* dW, hipStream_t s);

@@ -231,9 +231,13 @@ int launch_tapconv_pack_transposed(const float* W, float* out, int O, int C, int
 // ---------------------------------------------------------------------------
 // weight gradients
 // ---------------------------------------------------------------------------
+// Chunk i+1 is fetched into registers while the MFMAs of chunk i run from LDS (software pipeline; the
+// activation / addc / range masks are applied when the registers are written to LDS).  Blocks of the
+// first c-tile and tap also accumulate sum_pos dY[o] (the conv's bias gradient) from the staged tile.
 template <int T>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     constexpr int PC = 64, LD = PC + 1;   // +1: lanes walk channels, so rows must not share a bank
+    constexpr int RPW = 32;               // rows of each operand a wave stages per chunk
     __shared__ float sdy[128 * LD];
     __shared__ float sx[128 * LD];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     const int total_chunks = a.B * chunks_per_b;
     const int per = (total_chunks + a.nsplit - 1) / a.nsplit;
     const int ch_begin = split * per, ch_end = min(total_chunks, ch_begin + per);
+    const bool do_bias = a.bias_part != nullptr && blockIdx.y == 0 && tap == 0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -255,32 +260,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum = 0.f;
 
-    for (int ch = ch_begin; ch < ch_end; ++ch) {
+    // one descriptor per operand; the wave-uniform row offset rides in the scalar offset of the load
+    __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)((size_t)a.B * a.O * L * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)((size_t)a.B * a.C * L * 4), 0x00020000);
+    float rdy[RPW], rx[RPW];
+    float mdy = 0.f, mx = 0.f;   // range masks of this lane's position in the fetched chunk
+    int fb = 0;                  // batch index of the fetched chunk
+    auto fetch = [&](int ch) {
         const int b = ch / chunks_per_b, l0 = (ch % chunks_per_b) * PC;
-        __syncthreads();
-        // stage dY[o0..+128][l0..+64] and Xh[c0..+128][l0+shift..+64]: a wave loads whole rows (coalesced)
-        for (int row = wave; row < 128; row += 4) {
-            const int pos = l0 + lane;
-            const int o = o0 + row, c = c0 + row;
-            float dv = 0.f, xv = 0.f;
-            {
-                const bool ok = pos < L && o < a.O;
-                const float v = a.dY[((size_t)b * a.O + (o < a.O ? o : 0)) * L + (pos < L ? pos : 0)];
-                dv = v * (ok ? 1.f : 0.f);
-            }
-            {
-                const int ps = pos + shift;
-                const bool ok = (unsigned)ps < (unsigned)L && pos < L && c < a.C;
-                const int cc = c < a.C ? c : 0;
-                const float v = a.X[((size_t)b * a.C + cc) * L + (((unsigned)ps < (unsigned)L) ? ps : 0)];
-                const float ad = a.addc ? a.addc[(size_t)b * a.addc_bstride + cc] : 0.f;
-                xv = ((a.xact ? gelu_b(v) : v) + ad) * (ok ? 1.f : 0.f);
-            }
-            sdy[row * LD + lane] = dv;
-            sx[row * LD + lane] = xv;
+        const int pos = l0 + lane, ps = pos + shift;
+        const bool pin = pos < L, sin = (unsigned)ps < (unsigned)L && pin;
+        mdy = pin ? 1.f : 0.f;
+        mx = sin ? 1.f : 0.f;
+        fb = b;
+        const int vy = (pin ? pos : 0) * 4, vx = (((unsigned)ps < (unsigned)L) ? ps : 0) * 4;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + 4 * i;
+            const int o = min(o0 + row, a.O - 1), c = min(c0 + row, a.C - 1);
+            rdy[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, vy, (b * a.O + o) * L * 4, 0));
+            rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, vx, (b * a.C + c) * L * 4, 0));
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + 4 * i;
+            const float rm = (o0 + row < a.O) ? mdy : 0.f, cm = (c0 + row < a.C) ? mx : 0.f;
+            const float ad = a.addc ? a.addc[(size_t)fb * a.addc_bstride + min(c0 + row, a.C - 1)] : 0.f;
+            sdy[row * LD + lane] = rdy[i] * rm;
+            sx[row * LD + lane] = ((a.xact ? gelu_b(rx[i]) : rx[i]) + ad) * cm;
+        }
+    };
+
+    if (ch_begin < ch_end) fetch(ch_begin);
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        __syncthreads();           // the previous chunk's MFMAs are done with LDS
+        commit();
         __syncthreads();
+        if (ch + 1 < ch_end) fetch(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the global loads ahead of the MFMA loop
+        if (do_bias && tid < 128) {
+#pragma unroll 8
+            for (int p = 0; p < PC; ++p) bsum += sdy[tid * LD + p];
+        }
 #pragma unroll 8
         for (int ks = 0; ks < PC / 2; ++ks) {
             const int pp = ks * 2 + lhi;
@@ -308,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
                 const int c = c0 + wc * 64 + j * 32 + l31;
                 if (o < a.O && c < a.C) part[((size_t)o * a.C + c) * T + tap] = acc[i][j][r];
             }
+    if (do_bias && tid < 128 && o0 + tid < a.O) a.bias_part[(size_t)split * a.O + o0 + tid] = bsum;
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, size_t n, int nsplit,
@@ -328,12 +354,17 @@ int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
 
 int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipStream_t s) {
     ProfileScope ps("wgrad_mfma", s);
+    DWS_CHECK((size_t)a_in.B * std::max(a_in.O, a_in.C) * a_in.L * 4 < ((size_t)1 << 31), DWS_ERR_UNSUPPORTED,
+              "wgrad_mfma: operand larger than 2 GiB (B=%d rows=%d L=%d)", a_in.B, std::max(a_in.O, a_in.C), a_in.L);
     WgradArgs a = a_in;
     const dim3 grid(ceil_div(a.O, 128), ceil_div(a.C, 128), T * a.nsplit);
     if (T == 3) hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, s, a);
     const size_t n = (size_t)a.O * a.C * T;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, a.partial, dW, n, a.nsplit, scale);
+    if (a.bias_part)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(a.O, 256)), dim3(256), 0, s, a.bias_part, a.dbias,
+                           (size_t)a.O, a.nsplit, a.bias_scale);
     return DWS_OK;
 }
 

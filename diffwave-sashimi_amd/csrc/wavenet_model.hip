@@ -35,7 +35,7 @@ struct WaveNetModel : dws_model {
     // embedding MLP, gradient scratch
     std::vector<DevBuf> tx, tH;
     std::vector<DevBuf> ATd, ATg;    // transposed-weight A fragments of the adjoint GEMMs (training only)
-    DevBuf ATf, wpart;               // same for final_conv[0]; split-N partials of the weight gradients
+    DevBuf ATf, wpart, bpart;               // same for final_conv[0]; split-N partials of the weight gradients
     bool mfma_bwd = false;
     uint64_t commit_version = 0, bwd_pack_version = ~0ull;
     DevBuf ty, ta1, ta2, dxa, dxb, dskip, dgb, dHb, dresb, dyb, dWfold, dpt, dh2, dh1, demb, dWt_all, dbt_all;
@@ -196,15 +196,23 @@ struct WaveNetModel : dws_model {
         return DWS_OK;
     }
 
+    // weight gradient, and (db != null) the bias gradient db[o] = bscale * sum dY[b, o, l] in the same pass
     int wgrad(const float* dY, const float* X, const float* addc, int addc_bs, float* dW, int O, int Cc, int T, int dil,
-              float scale, hipStream_t s) {
-        if (!mfma_bwd) return launch_wgrad(dY, X, addc, addc_bs, dW, (int)B, O, Cc, (int)L, T, dil, scale, s);
+              float scale, hipStream_t s, float* db = nullptr, float bscale = 1.f) {
+        if (!mfma_bwd) {
+            if (db) DWS_TRY(launch_rowsum(dY, db, (int)B, O, (int)L, bscale, 0, s));
+            return launch_wgrad(dY, X, addc, addc_bs, dW, (int)B, O, Cc, (int)L, T, dil, scale, s);
+        }
         WgradArgs w{};
         w.dY = dY; w.X = X; w.addc = addc; w.addc_bstride = addc_bs;
         w.B = (int)B; w.O = O; w.C = Cc; w.L = (int)L; w.dil = dil;
         w.nsplit = wgrad_mfma_nsplit((int)B, O, Cc, (int)L, T);
         DWS_TRY(wpart.ensure((size_t)w.nsplit * O * Cc * T * 4));
         w.partial = wpart.f();
+        if (db) {
+            DWS_TRY(bpart.ensure((size_t)w.nsplit * O * 4));
+            w.bias_part = bpart.f(); w.dbias = db; w.bias_scale = bscale;
+        }
         return launch_wgrad_mfma(w, T, scale, dW, s);
     }
 
@@ -355,9 +363,8 @@ struct WaveNetModel : dws_model {
         DWS_TRY(launch_wgrad(dout, ty.f(), nullptr, 0, G("final_conv.2.conv.weight"), nB, Cout, S, nL, 1, 1, 1.f, s));
         DWS_TRY(launch_rowsum(dout, G("final_conv.2.conv.bias"), nB, Cout, nL, 1.f, 0, s));
         DWS_TRY(launch_final_dy(dout, P("final_conv.2.conv.weight"), ty.f(), dyb.f(), nB, S, Cout, nL, s));
-        DWS_TRY(wgrad(dyb.f(), skip.f(), nullptr, 0, dWfold.f(), S, S, 1, 1, scale, s));
+        DWS_TRY(wgrad(dyb.f(), skip.f(), nullptr, 0, dWfold.f(), S, S, 1, 1, scale, s, G("final_conv.0.conv.bias")));
         DWS_TRY(wn_bwd("final_conv.0.conv", dWfold.f(), S, S, s));
-        DWS_TRY(launch_rowsum(dyb.f(), G("final_conv.0.conv.bias"), nB, S, nL, 1.f, 0, s));
         if (mfma_bwd) {  // dskip = scale * Wf^T dy, the same for every layer
             if (bwd_pack_version != commit_version) DWS_TRY(pack_bwd(s));
             TapConvArgs f{};
@@ -396,21 +403,19 @@ struct WaveNetModel : dws_model {
             }
             // res / skip 1x1 weights and biases (dres = dx' * sqrt(.5))
             if (dx_out) {
-                DWS_TRY(wgrad(dx_out, gate.f(), nullptr, 0, dWfold.f(), C, C, 1, 1, r2, s));
+                DWS_TRY(wgrad(dx_out, gate.f(), nullptr, 0, dWfold.f(), C, C, 1, 1, r2, s, G(p + ".res_conv.bias"), r2));
                 DWS_TRY(wn_bwd(p + ".res_conv", dWfold.f(), C, C, s));
-                DWS_TRY(launch_rowsum(dx_out, G(p + ".res_conv.bias"), nB, C, nL, r2, 0, s));
             } else {  // the last layer's residual branch feeds nothing (`wavenet.py:165` uses only the skips)
                 DWS_HIP(hipMemsetAsync(G(p + ".res_conv.weight_v"), 0, (size_t)C * C * 4, s));
                 DWS_HIP(hipMemsetAsync(G(p + ".res_conv.weight_g"), 0, (size_t)C * 4, s));
                 DWS_HIP(hipMemsetAsync(G(p + ".res_conv.bias"), 0, (size_t)C * 4, s));
             }
-            DWS_TRY(wgrad(dskip.f(), gate.f(), nullptr, 0, dWfold.f(), S, C, 1, 1, 1.f, s));
+            DWS_TRY(wgrad(dskip.f(), gate.f(), nullptr, 0, dWfold.f(), S, C, 1, 1, 1.f, s, G(p + ".skip_conv.bias")));
             DWS_TRY(wn_bwd(p + ".skip_conv", dWfold.f(), S, C, s));
-            DWS_TRY(launch_rowsum(dskip.f(), G(p + ".skip_conv.bias"), nB, S, nL, 1.f, 0, s));
             // dilated conv: weights see h = x + pt (zero padded), input gets the transposed conv
-            DWS_TRY(wgrad(dHb.f(), tx[n].f(), part_t.f() + (size_t)n * C, NL * C, dWfold.f(), 2 * C, C, 3, dil, 1.f, s));
+            DWS_TRY(wgrad(dHb.f(), tx[n].f(), part_t.f() + (size_t)n * C, NL * C, dWfold.f(), 2 * C, C, 3, dil, 1.f, s,
+                          G(p + ".dilated_conv_layer.conv.bias")));
             DWS_TRY(wn_bwd(p + ".dilated_conv_layer.conv", dWfold.f(), 2 * C, C * 3, s));
-            DWS_TRY(launch_rowsum(dHb.f(), G(p + ".dilated_conv_layer.conv.bias"), nB, 2 * C, nL, 1.f, 0, s));
             if (mfma_bwd) {
                 TapConvArgs q{};
                 q.src0 = dHb.f(); q.K0 = 2 * C; q.A = ATd[n].f(); q.nkg_total = 6 * C / 8; q.M = C; q.T = 3; q.dil = dil;
