@@ -36,10 +36,13 @@ __device__ __forceinline__ float gelu_grad_b(float x) {  // d/dx [x Phi(x)] = Ph
 //   2  out = acc + bias[m]                                   3  out = acc + bias (pre-activation), out2 = gelu(out)
 //   4  out = acc + bias + res (+ addend)                     5  out = acc * gelu'(aux)
 template <int MT, int T, int EPI>
-__global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void tapconv_mfma_kernel(TapConvArgs a) {
     constexpr int P = 64, NT = 2, KC = 32;
     constexpr int ROWS = T * KC, RPW = ROWS / 4;
-    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * P];
+    // T = 3: measured faster with 2 workgroups per CU than with 3 (456 -> 384 us on the C = 256 adjoint), so the
+    // allocation is padded past a third of the 160 KB LDS
+    constexpr int LDS_PAD = (T == 3) ? 2304 : 0;
+    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * P + LDS_PAD];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,47 +129,57 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConvArgs a) {
         const int posc = ok ? pos : 0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if (mt[m] * 32 >= M) continue;
             if (EPI == 1) {  // gate adjoint: M == C, H / dH are [B, 2C, L]
-                float ht[16], hs[16];
+                const float* __restrict__ Hb = a.H + (size_t)b * 2 * M * L;
+                float* __restrict__ dHb = a.dH + (size_t)b * 2 * M * L;
+                float* __restrict__ gb = a.g + (size_t)b * M * L;
+                const int ML = M * L;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    ht[r] = a.H[((size_t)b * 2 * M + c) * L + posc];
-                    hs[r] = a.H[((size_t)b * 2 * M + M + c) * L + posc];
-                }
+                for (int r0 = 0; r0 < 16; r0 += 4) {   // four rows at a time keeps the register footprint down
+                    float ht[4], hs[4];
+                    const int i0 = (mt[m] * 32 + 8 * (r0 >> 2) + 4 * lhi) * L + posc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const float th = tanhf(ht[r]), sg = sigm_b(hs[r]), d = acc[m][n][r];
-                    if (ok) {
-                        a.g[((size_t)b * M + c) * L + pos] = th * sg;
-                        a.dH[((size_t)b * 2 * M + c) * L + pos] = d * sg * (1.f - th * th);
-                        a.dH[((size_t)b * 2 * M + M + c) * L + pos] = d * th * sg * (1.f - sg);
+                    for (int r = 0; r < 4; ++r) {
+                        ht[r] = Hb[i0 + r * L];
+                        hs[r] = Hb[i0 + r * L + ML];
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float th = tanhf(ht[r]), sg = sigm_b(hs[r]), d = acc[m][n][r0 + r];
+                        if (ok) {
+                            gb[i0 + r * L] = th * sg;
+                            dHb[i0 + r * L] = d * sg * (1.f - th * th);
+                            dHb[i0 + r * L + ML] = d * th * sg * (1.f - sg);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // do not hoist the next group's loads (they would spill)
                 }
             } else {
+                // 32-bit indices off per-batch base pointers: 64-bit address math per element costs ~2x the registers
+                const size_t boff = (size_t)b * M * L;
+                float* __restrict__ ob = a.out + boff;
                 float ad[16];
+                const int i0 = (mt[m] * 32 + 4 * lhi) * L + posc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const size_t idx = ((size_t)b * M + row) * L + posc;
-                    if (EPI == 0) ad[r] = a.addin ? a.addin[idx] * a.addscale : 0.f;
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    const int row = mt[m] * 32 + rr + 4 * lhi;
+                    const int idx = i0 + rr * L;
+                    if (EPI == 0) ad[r] = a.addin ? (a.addin + boff)[idx] * a.addscale : 0.f;
                     else if (EPI == 2 || EPI == 3) ad[r] = a.bias ? a.bias[row] : 0.f;
-                    else if (EPI == 4) ad[r] = a.bias[row] + a.res[idx] + (a.addend ? a.addend[idx] : 0.f);
-                    else ad[r] = a.aux[idx];
+                    else if (EPI == 4) ad[r] = a.bias[row] + (a.res + boff)[idx] + (a.addend ? (a.addend + boff)[idx] : 0.f);
+                    else ad[r] = (a.aux + boff)[idx];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const size_t idx = ((size_t)b * M + row) * L + pos;
+                    const int idx = i0 + ((r & 3) + 8 * (r >> 2)) * L;
                     if (!ok) continue;
                     if (EPI == 5) {
-                        a.out[idx] = acc[m][n][r] * gelu_grad_b(ad[r]);
+                        ob[idx] = acc[m][n][r] * gelu_grad_b(ad[r]);
                     } else {
                         const float v = acc[m][n][r] + ad[r];
-                        a.out[idx] = v;
-                        if (EPI == 3) a.out2[idx] = gelu_b(v);
+                        ob[idx] = v;
+                        if (EPI == 3) (a.out2 + boff)[idx] = gelu_b(v);
                     }
                 }
             }
@@ -181,7 +194,7 @@ bool tapconv_mfma_supported(int M, int K0, int K1, int T) {
 template <int T, int EPI>
 static int launch_tc(const TapConvArgs& a, hipStream_t s) {
     const int nt = a.B * ceil_div(a.L, 64);
-    if (a.M % 256 == 0 || a.M > 512)
+    if (a.M % 256 == 0)   // M-blocks are always full with MT = 2; with MT = 1 a partial block idles whole waves
         hipLaunchKernelGGL((tapconv_mfma_kernel<2, T, EPI>), dim3(nt, ceil_div(a.M, 256)), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((tapconv_mfma_kernel<1, T, EPI>), dim3(nt, ceil_div(a.M, 128)), dim3(256), 0, s, a);
@@ -348,7 +361,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
     const int tiles = ceil_div(O, 128) * ceil_div(C, 128) * T;
     const int chunks = B * ceil_div(L, 64);
-    int ns = std::max(1, 1024 / tiles);
+    int ns = std::max(1, 512 / tiles);
     return std::min(ns, chunks);
 }
 

@@ -1,0 +1,221 @@
+"""``train.py``-compatible driver on the HIP engine.
+
+Same call surface and on-disk conventions as the reference (``train.py:27-196,224-252``): Hydra-style
+config tree + ``key=value`` overrides, ``exp/<run>/checkpoint/<iter>.pkl`` holding
+``{'model_state_dict', 'optimizer_state_dict'}``, resume from ``train.ckpt_iter`` (``max`` = newest),
+Adam at ``train.learning_rate``, one process per GPU with ``apply_gradient_allreduce`` (RCCL), rank-0
+checkpoints followed by an in-loop ``generate`` call.  wandb is replaced by a JSON-lines log
+(``exp/<run>/train_log.jsonl``, same keys: ``train/loss``, ``train/log_loss``, ``train/loss_epoch``).
+
+    python -m diffwave_sashimi_amd.train --config-dir /path/to/configs experiment=sc09 model=sashimi \
+        dataset.data_path=/data/sc09 train.batch_size_per_gpu=32
+
+Datasets: ``sc09`` (a directory tree of 1 s / 16 kHz ``*_nohash_*.wav`` files, ``dataloaders/sc.py:25-64``) and
+``synthetic`` (uniform noise clips, for smoke runs).  The mel-conditional ``ljspeech`` loader is not built.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .generate import find_max_epoch, generate, load_config, local_directory
+
+HASH_DIVIDER, EXCEPT_FOLDER = "_nohash_", "_background_noise_"   # `dataloaders/sc.py:15-16`
+
+
+def fix_length(t, length):
+    """``dataloaders/sc.py:25-32``: crop or zero-pad a [1, n] waveform to ``length``."""
+    assert t.dim() == 2 and t.shape[0] == 1
+    if t.shape[1] > length:
+        return t[:, :length]
+    if t.shape[1] < length:
+        return torch.cat([t, torch.zeros(1, length - t.shape[1])], dim=1)
+    return t
+
+
+class SpeechCommands(torch.utils.data.Dataset):
+    """``dataloaders/sc.py:46-64``: items are ``(waveform[1,16000] in [-1,1), sample_rate, label)``."""
+
+    def __init__(self, path, length=16000):
+        self._path, self._length = path, length
+        walker = sorted(str(p) for p in Path(path).glob("**/*.wav"))
+        self._walker = [w for w in walker if HASH_DIVIDER in w and EXCEPT_FOLDER not in w]
+
+    def __getitem__(self, n):
+        from scipy.io import wavfile
+        f = self._walker[n]
+        label = os.path.split(os.path.relpath(f, self._path))[0]
+        sr, x = wavfile.read(f)
+        if x.dtype == np.int16:            # torchaudio.load(normalize=True) semantics
+            x = x.astype(np.float32) / 32768.0
+        elif x.dtype == np.int32:
+            x = x.astype(np.float32) / 2147483648.0
+        else:
+            x = x.astype(np.float32)
+        if x.ndim == 2:
+            x = x[:, 0]
+        return fix_length(torch.from_numpy(x).unsqueeze(0), self._length), sr, label
+
+    def __len__(self):
+        return len(self._walker)
+
+
+class SyntheticClips(torch.utils.data.Dataset):
+    """U(-0.3, 0.3) clips (SURVEY.md 8d's synthetic workload) with the sc09 item layout."""
+
+    def __init__(self, n_items, length, sampling_rate=16000, seed=0):
+        self.n, self.length, self.sr, self.seed = n_items, length, sampling_rate, seed
+
+    def __getitem__(self, n):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + n)
+        return (torch.rand(1, self.length, generator=g) * 2 - 1) * 0.3, self.sr, "synthetic"
+
+    def __len__(self):
+        return self.n
+
+
+def dataloader(dataset_cfg, batch_size, num_gpus, unconditional=True, rank=0, num_workers=4):
+    """``dataloaders/__init__.py:6-33``."""
+    name = dataset_cfg.get("_name_", "sc09")
+    if name == "sc09":
+        assert unconditional
+        dataset = SpeechCommands(dataset_cfg["data_path"], dataset_cfg.get("segment_length", 16000))
+    elif name == "synthetic":
+        dataset = SyntheticClips(dataset_cfg.get("n_items", 64), dataset_cfg.get("segment_length", 16000),
+                                 dataset_cfg.get("sampling_rate", 16000))
+    else:
+        raise NotImplementedError(f"dataset '{name}': the mel-conditional loader (`dataloaders/mel2samp.py`) and "
+                                  "mel-conditional training are not built")
+    sampler = None
+    if num_gpus > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, num_replicas=num_gpus, rank=rank)
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, shuffle=False,
+                                       num_workers=num_workers, pin_memory=False, drop_last=True)
+
+
+def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, ckpt_iter, n_iters, iters_per_ckpt,
+          iters_per_logging, learning_rate, batch_size_per_gpu, name=None, exp_root="exp", num_workers=4):
+    """``train.py:49-196``."""
+    from .distributed_util import apply_gradient_allreduce, reduce_tensor
+    from .models import construct_model
+    from .sampling import calc_diffusion_hyperparams
+    from .training import training_loss
+
+    local_path, checkpoint_directory = local_directory(name, model_cfg, diffusion_cfg, dataset_cfg, "checkpoint", exp_root)
+    log_path = os.path.join(exp_root, local_path, "train_log.jsonl")
+    dh = calc_diffusion_hyperparams(**diffusion_cfg, fast=False)
+    trainloader = dataloader(dataset_cfg, batch_size_per_gpu, num_gpus, unconditional=model_cfg["unconditional"],
+                             rank=rank, num_workers=num_workers)
+    if len(trainloader) == 0:
+        raise RuntimeError("the dataset holds fewer clips than one batch")
+    print("Data loaded")
+    net = construct_model(dict(model_cfg)).cuda().train()
+    print(f"{type(net).__name__} parameters: {sum(p.numel() for p in net.parameters()) / 1e6:.6f}M")   # `utils.py:76-88`
+    if num_gpus > 1:
+        net = apply_gradient_allreduce(net)
+    optimizer = torch.optim.Adam(net.parameters(), lr=learning_rate)
+
+    if ckpt_iter == "max":
+        ckpt_iter = find_max_epoch(checkpoint_directory)
+    ckpt_iter = int(ckpt_iter)
+    if ckpt_iter >= 0:
+        try:
+            checkpoint = torch.load(os.path.join(checkpoint_directory, f"{ckpt_iter}.pkl"), map_location="cpu")
+            net.load_state_dict(checkpoint["model_state_dict"])
+            if "optimizer_state_dict" in checkpoint:
+                optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+                optimizer.param_groups[0]["lr"] = learning_rate      # `train.py:111-112`
+            print(f"Successfully loaded model at iteration {ckpt_iter}")
+        except Exception as e:   # the reference swallows the error the same way (`train.py:115-117`)
+            print(f"Model checkpoint found at iteration {ckpt_iter}, but was not successfully loaded ({e}) - "
+                  "training from scratch.")
+            ckpt_iter = -1
+    else:
+        print("No valid checkpoint model found - training from scratch.")
+        ckpt_iter = -1
+
+    def log(record, step):
+        if rank == 0:
+            with open(log_path, "a") as f:
+                f.write(json.dumps(dict(record, step=step)) + "\n")
+
+    loss_fn = nn.MSELoss()
+    n_iter = ckpt_iter + 1
+    epoch = 0
+    while n_iter < n_iters + 1:
+        epoch_loss, n_batches = 0.0, 0
+        if getattr(trainloader, "sampler", None) is not None and hasattr(trainloader.sampler, "set_epoch"):
+            trainloader.sampler.set_epoch(epoch)
+        for data in trainloader:
+            audio = data[0].cuda()
+            optimizer.zero_grad()
+            loss = training_loss(net, loss_fn, audio, dh)
+            reduced_loss = reduce_tensor(loss.data, num_gpus).item() if num_gpus > 1 else loss.item()
+            loss.backward()
+            optimizer.step()
+            epoch_loss += reduced_loss
+            n_batches += 1
+            if n_iter % iters_per_logging == 0:
+                log({"train/loss": reduced_loss, "train/log_loss": float(np.log(reduced_loss))}, n_iter)
+            if n_iter % iters_per_ckpt == 0 and rank == 0:
+                torch.save({"model_state_dict": net.state_dict(), "optimizer_state_dict": optimizer.state_dict()},
+                           os.path.join(checkpoint_directory, f"{n_iter}.pkl"))
+                print(f"model at iteration {n_iter} is saved")
+                if generate_cfg and generate_cfg.get("n_samples", 0):
+                    gen = dict(generate_cfg, ckpt_iter=n_iter)
+                    net.eval()
+                    generate(rank, diffusion_cfg, model_cfg, dataset_cfg, name=name, exp_root=exp_root, **gen)
+                    net.train()
+            n_iter += 1
+            if n_iter >= n_iters + 1:
+                break
+        epoch += 1
+        if n_batches:
+            log({"train/loss_epoch": epoch_loss / n_batches, "train/log_loss_epoch": float(np.log(epoch_loss / n_batches))},
+                n_iter)
+    return net
+
+
+def distributed_train(rank, num_gpus, group_name, cfg, exp_root="exp"):
+    """``train.py:27-47``."""
+    from .distributed_util import init_distributed
+    dist_cfg = dict(cfg.get("distributed") or {})
+    if num_gpus > 1:
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+        init_distributed(rank, num_gpus, group_name, dist_cfg.get("dist_backend", "nccl"),
+                         dist_cfg.get("dist_url", "tcp://127.0.0.1:54321"))
+    tr = dict(cfg["train"])
+    train(rank, num_gpus, dict(cfg["diffusion"]), dict(cfg["model"]), dict(cfg["dataset"]), dict(cfg.get("generate") or {}),
+          exp_root=exp_root, **tr)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--config-dir", required=True, help="Hydra-style config tree (the reference's configs/)")
+    ap.add_argument("--exp-root", default="exp")
+    ap.add_argument("overrides", nargs="*", help="key=value overrides, e.g. experiment=sc09 model=sashimi")
+    args = ap.parse_args(argv)
+    cfg = load_config(args.config_dir, args.overrides)
+    cfg.pop("wandb", None)
+    os.makedirs(args.exp_root, mode=0o775, exist_ok=True)
+    group = time.strftime("%Y%m%d-%H%M%S")
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:      # launched by torch.distributed.run
+        distributed_train(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), group, cfg, args.exp_root)
+        return
+    num_gpus = torch.cuda.device_count()
+    if num_gpus <= 1:
+        distributed_train(0, 1, group, cfg, args.exp_root)
+    else:  # one process per GPU (`train.py:236-249`)
+        import torch.multiprocessing as mp
+        mp.spawn(distributed_train, args=(num_gpus, group, cfg, args.exp_root), nprocs=num_gpus, join=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

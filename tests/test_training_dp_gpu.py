@@ -1,5 +1,5 @@
-"""GPU: data-parallel WaveNet training through the HIP engine -- two ranks (one GPU shared, gloo for the
-exchange since one device cannot host two RCCL ranks) against one process on the global batch."""
+"""GPU: data-parallel training of both backbones through the HIP engine -- two ranks (one GPU shared, gloo for
+the exchange since one device cannot host two RCCL ranks) against one process on the global batch."""
 import json
 import os
 import socket
@@ -16,15 +16,20 @@ from tests.conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-CFG = cases.wn_cfg(res_channels=64, skip_channels=64, num_res_layers=2, dilation_cycle=2)
-L, STEPS, LR = 192, 2, 0.05
+DP_CASES = {
+    "wavenet": (cases.wn_cfg(res_channels=64, skip_channels=64, num_res_layers=2, dilation_cycle=2), 192),
+    # SaShiMi: complex S4 parameters travel as real views; _setup_C runs after the broadcast on identical weights
+    "sashimi": (cases.ss_cfg(d_model=32, n_layers=1, L=512, diffusion_step_embed_dim_mid=64), 512),
+}
+STEPS, LR = 2, 0.05
 
 WORKER = r'''
 import json, os, sys
 sys.path.insert(0, os.environ["DWS_ROOT"])
 import torch, torch.nn as nn, torch.distributed as dist
 from tests import cases
-from tests.test_wavenet_dp_gpu import CFG, L, STEPS, LR
+from tests.test_training_dp_gpu import DP_CASES, STEPS, LR
+CFG, L = DP_CASES[os.environ["DWS_DP_CASE"]]
 from diffwave_sashimi_amd.distributed_util import apply_gradient_allreduce, init_distributed, reduce_tensor
 from diffwave_sashimi_amd.training import training_loss
 from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
@@ -59,7 +64,9 @@ def _free_port():
     return p
 
 
-def test_two_rank_engine_training_matches_global_batch(tmp_path, gpu):
+@pytest.mark.parametrize("case", list(DP_CASES))
+def test_two_rank_engine_training_matches_global_batch(tmp_path, gpu, case):
+    CFG, L = DP_CASES[case]
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
     from diffwave_sashimi_amd.training import q_sample
     script = tmp_path / "worker.py"
@@ -67,7 +74,7 @@ def test_two_rank_engine_training_matches_global_batch(tmp_path, gpu):
     port = _free_port()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, WORLD_SIZE="2", RANK=str(rank), MASTER_PORT=str(port), DWS_ROOT=ROOT, OMP_NUM_THREADS="1",
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(rank), MASTER_PORT=str(port), DWS_ROOT=ROOT, OMP_NUM_THREADS="1", DWS_DP_CASE=case,
                    PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
