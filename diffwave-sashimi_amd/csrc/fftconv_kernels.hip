@@ -32,7 +32,7 @@ __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y
 __device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
 __device__ __forceinline__ float2 mul_pos_i(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
 __device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float x) { return dws_gelu(x); }
 
 // W_16^k = exp(-2 pi i k / 16), k = 0..7
 __device__ __forceinline__ float2 w16(int k) {

@@ -8,8 +8,8 @@
 
 namespace dws {
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float sigmoid_s(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return dws_gelu(x); }
+__device__ __forceinline__ float sigmoid_s(float x) { return dws_sigmoid(x); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cdiv(float2 a, float2 b) {

@@ -20,8 +20,8 @@ namespace dws {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float gelu_erf_m(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float sigmoid_m(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf_m(float x) { return dws_gelu(x); }
+__device__ __forceinline__ float sigmoid_m(float x) { return dws_sigmoid(x); }
 
 __device__ __forceinline__ float f4_get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 

@@ -6,7 +6,7 @@
 
 namespace dws {
 
-__device__ __forceinline__ float sigm_t(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigm_t(float x) { return dws_sigmoid(x); }
 __device__ __forceinline__ float2 cmul_t(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmulc_t(float2 a, float2 b) {  // conj(a) * b
     return make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);

@@ -24,12 +24,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-__device__ __forceinline__ float sigm_b(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigm_b(float x) { return dws_sigmoid(x); }
 
-__device__ __forceinline__ float gelu_b(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_b(float x) {  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
-    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_b(float x) { return dws_gelu(x); }
+__device__ __forceinline__ float gelu_grad_b(float x) { return dws_gelu_grad(x); }  // Phi(x) + x phi(x)
 
 // EPI (all rows m of an M-block, positions of the tile):
 //   0  out = acc (+ addin * addscale)                       1  gate adjoint (WaveNet)
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float th = tanhf(ht[r]), sg = sigm_b(hs[r]), d = acc[m][n][r0 + r];
+                        const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + dws_exp(2.f * ht[r])), sg = sigm_b(hs[r]), d = acc[m][n][r0 + r];
                         if (ok) {
                             gb[i0 + r * L] = th * sg;
                             dHb[i0 + r * L] = d * sg * (1.f - th * th);
