@@ -13,6 +13,8 @@
 //
 // pw_mfma_kernel: the pooling 1x1 convs (`sashimi.py:23-58`) with the index
 // maps folded into the B-operand gather (DownPool) / the float4 scatter (UpPool).
+#include <cstdlib>
+
 #include "sashimi.h"
 #include "sashimi_mfma.h"
 
@@ -42,33 +44,46 @@ template <int MT, int NT, int P>
 __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* __restrict__ A, int nkg_total,
                                           int kg0, int nkg, const int (&mt)[MT], const float* __restrict__ bt, int wn,
                                           int lane) {
+    // A fragments come from L2 (~1 us away) and one k-group feeds only 4*MT*NT MFMAs, so they are fetched through a
+    // ring of D k-groups; the sched_barrier pins each refill where it is written (hipcc otherwise sinks the load
+    // next to its use and the wave waits out the full latency every k-group: measured 43 % MFMA busy)
+    constexpr int D = 4;   // nkg is a multiple of 4 (K % 32 == 0)
     const int l31 = lane & 31, lhi = lane >> 5;
-    float4 cur[MT], nxt[MT];
+    float4 buf[D][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) cur[m] = A[((size_t)mt[m] * nkg_total + kg0) * 64 + lane];
-    for (int kg = 0; kg < nkg; ++kg) {
-        const int kgn = (kg + 1 < nkg) ? kg + 1 : kg;
+    for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) nxt[m] = A[((size_t)mt[m] * nkg_total + kg0 + kgn) * 64 + lane];
+        for (int m = 0; m < MT; ++m) buf[d][m] = A[((size_t)mt[m] * nkg_total + kg0 + d) * 64 + lane];
+    for (int kg = 0; kg < nkg; kg += D) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int krow = kg * 8 + j * 2 + lhi;
-            float bf[NT];
+        for (int d = 0; d < D; ++d) {
+            float4 cur[MT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = bt[krow * P + (wn * NT + n) * 32 + l31];
+            for (int m = 0; m < MT; ++m) cur[m] = buf[d][m];
+            const int kn = min(kg + d + D, nkg - 1);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) buf[d][m] = A[((size_t)mt[m] * nkg_total + kg0 + kn) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(cur[m], j), bf[n], acc[m][n], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const int krow = (kg + d) * 8 + j * 2 + lhi;
+                float bf[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bf[n] = bt[krow * P + (wn * NT + n) * 32 + l31];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(cur[m], j), bf[n], acc[m][n], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) cur[m] = nxt[m];
     }
 }
 
+// two waves per SIMD at least: without the bound hipcc spends > 256 registers per lane on one resident workgroup
 template <int H, int WM, int WN, int NT, int FFE>
-__global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64 * WM * WN) : 1)) void s4_tail_mfma_kernel(
+    S4TailArgs a) {
     using T = TailCfg<H, WM, WN, NT, FFE>;
     constexpr int P = T::P, MT = T::MT, THREADS = T::THREADS, PARTS = T::PARTS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -87,12 +102,24 @@ __global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a
     const int tix = xcd_remap(blockIdx.x, gridDim.x);
     const int b = tix / ntl, l0 = (tix % ntl) * P;
 
+    // ---- experiment: desynchronise the co-resident workgroups (dbg bits 4..7 = mode, 8.. = sleep units of ~8k cycles)
+    {
+        const int mode = (a.dbg >> 4) & 15, units = a.dbg >> 8;
+        bool late = false;
+        if (mode == 1) late = blockIdx.x < 512 && ((blockIdx.x >> 3) & 1);
+        if (mode == 2) late = blockIdx.x >= 256 && blockIdx.x < 512;
+        if (mode == 3) late = blockIdx.x < 512 && ((blockIdx.x >> 4) & 1);
+        if (mode == 4) late = blockIdx.x < 512 && ((blockIdx.x >> 8) & 1) == ((blockIdx.x >> 3) & 1);
+        if (late)
+            for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
     // ---- stage g tile
     const float* __restrict__ gb = a.g + (size_t)b * H * L;
     for (int i = tid; i < H * P; i += THREADS) {
         const int row = i / P, col = i % P;
         const int pos = l0 + col;
-        const float v = gb[(size_t)row * L + (pos < L ? pos : 0)];
+        const float v = (a.dbg & 2) ? 0.5f : gb[row * L + (pos < L ? pos : 0)];
         tile[i] = v * (pos < L ? 1.f : 0.f);
     }
     __syncthreads();
@@ -114,8 +141,10 @@ __global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc_a[m][n][r] = 0.f; acc_b[m][n][r] = 0.f; }
+        if (!(a.dbg & 1)) {
         gemm_slab<MT, NT, P>(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane);
         gemm_slab<MT, NT, P>(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane);
+        }
         __syncthreads();  // every wave is done reading g
         // x1 = x + GLU(o) (+ mel) -> tile
         const float* __restrict__ xb = a.x + (size_t)b * H * L;
@@ -131,8 +160,8 @@ __global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    xr[r] = xb[(size_t)h * L + posc];
-                    if (melb) xr[r] += melb[(size_t)h * L + posc];
+                    xr[r] = (a.dbg & 2) ? 0.25f : xb[h * L + posc];
+                    if (melb) xr[r] += melb[h * L + posc];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -198,7 +227,7 @@ __global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a
         int mt_q[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) mt_q[m] = q * (H / 32) + mt_h[m];
-        gemm_slab<MT, NT, P>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
+        if (!(a.dbg & 1)) gemm_slab<MT, NT, P>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
         if (q > 0) __syncthreads();  // previous chunk of u fully consumed by GEMM-2
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -215,7 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a
                 }
             }
         __syncthreads();
-        gemm_slab<MT, NT, P>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
+        if (!(a.dbg & 1)) gemm_slab<MT, NT, P>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
     }
 
     // ---- out = x1 + f (+ addend);  x1 = centred tile + mean
@@ -235,7 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    ad[r] = addb[(size_t)h * L + posc];
+                    ad[r] = addb[h * L + posc];
                 }
             } else {
 #pragma unroll
@@ -245,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN) void s4_tail_mfma_kernel(S4TailArgs a
             for (int r = 0; r < 16; ++r) {
                 const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const float v = (tile[h * P + col] + mean) + (acc2[m][n][r] + a.b2[h]) + ad[r];
-                if (ok) ob[(size_t)h * L + pos] = v;
+                if (ok && (!(a.dbg & 4) || v == 123.456f)) ob[h * L + pos] = v;
             }
         }
 }
@@ -262,7 +291,10 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+    S4TailArgs aa = a;
+    static const int dbg = getenv("DWS_TAIL_DBG") ? atoi(getenv("DWS_TAIL_DBG")) : 0;
+    aa.dbg = dbg;
+    hipLaunchKernelGGL(kern, dim3(a.B * ntl), dim3(T::THREADS), lds, s, aa);
     return DWS_OK;
 }
 
@@ -271,6 +303,10 @@ bool s4_tail_mfma_supported(int H, int ff) {
 }
 
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
+    static const int nt1 = getenv("DWS_TAIL_NT1") ? atoi(getenv("DWS_TAIL_NT1")) : 0;
+    if (nt1 & 1) { if (H == 64) return launch_tail_t<64, 2, 2, 1>(a, s); }
+    if (nt1 & 2) { if (H == 128) return launch_tail_t<128, 4, 1, 1>(a, s); }
+    if (nt1 & 4) { if (H == 256) return launch_tail_t<256, 8, 1, 1>(a, s); }
     switch (H) {
         case 32: return launch_tail_t<32, 1, 4, 1>(a, s);
         case 64: return launch_tail_t<64, 2, 2, 2>(a, s);

@@ -225,8 +225,10 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
 
     const int ntl = (a.L + P - 1) / P;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = tile / ntl;
-    const int l0 = (tile % ntl) * P;
+    // readfirstlane: the integer divisions run on the VALU, and without it hipcc treats everything derived from b
+    // (every buffer descriptor below) as possibly divergent and wraps each access in a waterfall loop
+    const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
+    const int l0 = __builtin_amdgcn_readfirstlane((tile % ntl) * P);
     const int L = a.L, dil = a.dilation;
 
     const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
@@ -337,28 +339,40 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     // ---- gate: g = tanh(H_t + b_t (+mel_t)) * sigmoid(H_s + b_s (+mel_s)) -> LDS [C][P]
     float* gt = lds;
     const float* melb = a.melc ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;
+    // biases by buffer load: lane part 16*lhi, row part in the scalar offset (no per-lane 64-bit address math)
+    __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias1, 0, 2 * C * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias2, 0, (C + S) * 4, 0x00020000);
+    const int vb = 16 * lhi;
 #pragma unroll
     for (int m = 0; m < MP; ++m) {
+        float bt_[16], bs_[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * MP + m) * 32 + (r & 3) + 8 * (r >> 2);
+            bt_[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB1, vb, row * 4, 0));
+            bs_[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB1, vb, (C + row) * 4, 0));
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int col = (wn * NT + n) * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = (wm * MP + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                float ht = acc[m][n][r] + a.bias1[ch];
-                float hs = acc[MP + m][n][r] + a.bias1[C + ch];
+                float ht = acc[m][n][r] + bt_[r];
+                float hs = acc[MP + m][n][r] + bs_[r];
                 if (melb) {
                     const int pos = l0 + col;
                     if (pos < L) {
-                        ht += melb[(size_t)ch * L + pos];
-                        hs += melb[(size_t)(C + ch) * L + pos];
+                        ht += melb[ch * L + pos];
+                        hs += melb[(C + ch) * L + pos];
                     }
                 }
                 if (a.hsave) {  // training: keep the pre-activations for the gate adjoint
                     const int pos = l0 + col;
                     if (pos < L) {
-                        a.hsave[((size_t)b * 2 * C + ch) * L + pos] = ht;
-                        a.hsave[((size_t)b * 2 * C + C + ch) * L + pos] = hs;
+                        float* __restrict__ hb = a.hsave + (size_t)b * 2 * C * L;
+                        hb[ch * L + pos] = ht;
+                        hb[(C + ch) * L + pos] = hs;
                     }
                 }
                 gt[ch * P + col] = fast_tanh(ht) * fast_sigmoid(hs);
@@ -407,48 +421,56 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     }
 
     // ---- epilogue: x' = (x + res + b_r) * sqrt(.5);  skip_acc (+)= skip + b_s
+    // Buffer loads / stores: the lane part of the address is ONE 32-bit offset per column group, the row part is
+    // wave-uniform and rides in the scalar offset, so the 128 accesses of a lane cost no address VALU at all
+    // (fp32 MFMA and VALU do not overlap on a SIMD: every VALU instruction here is MFMA time lost).  A lane whose
+    // position is past L gets an out-of-range offset: its loads return 0 and its stores are dropped.
     const float rs = 0.70710678118654752440f;
-    float* __restrict__ xo = a.x_out + (size_t)b * C * L;
-    float* __restrict__ sk = a.skip + (size_t)b * S * L;
     const bool first = a.first_layer, last = a.last_layer;
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rXo = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x_out + (size_t)b * C * L), 0, C * L * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rSk = __builtin_amdgcn_make_buffer_rsrc((void*)(a.skip + (size_t)b * S * L), 0, S * L * 4, 0x00020000);
+    const int L4 = L * 4;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int pos = l0 + (wn * NT + n) * 32 + l31;
-        const bool ok = pos < L;
-        const int posc = ok ? pos : 0;  // clamped: loads are unconditional, stores predicated
+        const int voff = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
         if (!last) {
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                float xr[16];
+                const int s0 = ((wm * MR + m) * 32) * L4;
+                float xr[16], br[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    xr[r] = xb[(size_t)ch * L + posc];
+                    xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0));
+                    br[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, vb, ((wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ch = (wm * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (ok) xo[(size_t)ch * L + pos] = (xr[r] + (acc2[m][n][r] + a.bias2[ch])) * rs;
+                    const float v = (xr[r] + (acc2[m][n][r] + br[r])) * rs;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rXo, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
                 }
             }
         }
 #pragma unroll
         for (int m = 0; m < MS; ++m) {
-            float sr[16];
+            const int s0 = ((wm * MS + m) * 32) * L4;
+            float sr[16], bq[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bq[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, vb, (C + (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
             if (!first) {  // wave-uniform: all 16 loads issue back to back
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    sr[r] = sk[(size_t)sc * L + posc];
-                }
+                for (int r = 0; r < 16; ++r)
+                    sr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rSk, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0));
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sr[r] = 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (ok) sk[(size_t)sc * L + pos] = sr[r] + (acc2[MR + m][n][r] + a.bias2[C + sc]);
+                const float v = sr[r] + (acc2[MR + m][n][r] + bq[r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
             }
         }
     }
