@@ -21,7 +21,6 @@ struct S4TailArgs {
     const float* addend;  // nullable U-Net skip [B,H,L]
     float* out;           // [B,H,L]
     int B, L;
-    int dbg;              // profiling ablations (DWS_TAIL_DBG): 1 skip MFMA slabs, 2 skip global loads, 4 skip stores
 };
 
 struct PwMfmaArgs {

@@ -100,29 +100,37 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
     const int L = a.L;
     const int ntl = (L + P - 1) / P;
     const int tix = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = tix / ntl, l0 = (tix % ntl) * P;
+    // readfirstlane: keeps every buffer descriptor below provably wave-uniform (no waterfall loops)
+    const int b = __builtin_amdgcn_readfirstlane(tix / ntl), l0 = __builtin_amdgcn_readfirstlane((tix % ntl) * P);
+    const int L4 = L * 4;
+    constexpr int OOB = 0x7ffffff0;   // lane offset past every descriptor: loads give 0, stores are dropped
 
-    // ---- experiment: desynchronise the co-resident workgroups (dbg bits 4..7 = mode, 8.. = sleep units of ~8k cycles)
+    // fp32 MFMA and VALU do not co-issue on a SIMD (tools/ubench/coexec.hip), so every VALU instruction in this
+    // kernel is MFMA time lost: all global traffic goes through buffer instructions whose row part is a scalar
+    // offset (no per-lane 64-bit address math), and the g tile is staged by LDS-DMA (no VALU, no VGPRs).
+    // ---- stage g tile: row r of the tile = P/64 DMA instructions of 64 positions
     {
-        const int mode = (a.dbg >> 4) & 15, units = a.dbg >> 8;
-        bool late = false;
-        if (mode == 1) late = blockIdx.x < 512 && ((blockIdx.x >> 3) & 1);
-        if (mode == 2) late = blockIdx.x >= 256 && blockIdx.x < 512;
-        if (mode == 3) late = blockIdx.x < 512 && ((blockIdx.x >> 4) & 1);
-        if (mode == 4) late = blockIdx.x < 512 && ((blockIdx.x >> 8) & 1) == ((blockIdx.x >> 3) & 1);
-        if (late)
-            for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+        __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        if constexpr (P >= 64) {
+            constexpr int SEG = P / 64, NI = H * SEG / (THREADS / 64);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int q = wave + (THREADS / 64) * i;     // (row, segment) index
+                const int row = q / SEG, seg = q % SEG;
+                const int pos = l0 + seg * 64 + lane;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, tile + row * P + seg * 64, 4, pos < L ? pos * 4 : OOB, row * L4, 0, 0);
+            }
+        } else {   // P == 32: one instruction moves two consecutive rows (they are contiguous in the tile)
+            constexpr int NI = H / 2 / (THREADS / 64);
+            const int pos = l0 + l31;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int q = wave + (THREADS / 64) * i;     // row pair
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, tile + 2 * q * P, 4, pos < L ? (lhi * L + pos) * 4 : OOB, 2 * q * L4, 0, 0);
+            }
+        }
     }
-
-    // ---- stage g tile
-    const float* __restrict__ gb = a.g + (size_t)b * H * L;
-    for (int i = tid; i < H * P; i += THREADS) {
-        const int row = i / P, col = i % P;
-        const int pos = l0 + col;
-        const float v = (a.dbg & 2) ? 0.5f : gb[row * L + (pos < L ? pos : 0)];
-        tile[i] = v * (pos < L ? 1.f : 0.f);
-    }
-    __syncthreads();
+    __syncthreads();   // the barrier's release waits for the DMA (vmcnt(0))
 
     // ---- GEMM-o: rows [tile m] pair with rows [H/32 + tile m] (GLU halves)
     int mt_a[MT], mt_b[MT], mt_h[MT];
@@ -141,35 +149,44 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc_a[m][n][r] = 0.f; acc_b[m][n][r] = 0.f; }
-        if (!(a.dbg & 1)) {
         gemm_slab<MT, NT, P>(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane);
         gemm_slab<MT, NT, P>(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane);
-        }
         __syncthreads();  // every wave is done reading g
         // x1 = x + GLU(o) (+ mel) -> tile
-        const float* __restrict__ xb = a.x + (size_t)b * H * L;
-        const float* __restrict__ melb = a.mel ? a.mel + (size_t)(a.mel_bstride ? b : 0) * H * L : nullptr;
+        __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.mel ? a.mel + (size_t)(a.mel_bstride ? b : 0) * H * L : a.x), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rBo = __builtin_amdgcn_make_buffer_rsrc((void*)a.bo, 0, 2 * H * 4, 0x00020000);
+        const bool has_mel = a.mel != nullptr;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            float ba[16], bb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2);
+                ba[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBo, 16 * lhi, row * 4, 0));
+                bb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBo, 16 * lhi, (H + row) * 4, 0));
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int col = (wn * NT + n) * 32 + l31;
                 const int pos = l0 + col;
-                const int posc = pos < L ? pos : 0;
+                const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
                 float xr[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    xr[r] = (a.dbg & 2) ? 0.25f : xb[h * L + posc];
-                    if (melb) xr[r] += melb[h * L + posc];
+                    const int soff = (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4;
+                    xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, soff, 0));
+                    if (has_mel) xr[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voff, soff, 0));
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const float oa = acc_a[m][n][r] + a.bo[h], ob = acc_b[m][n][r] + a.bo[H + h];
+                    const float oa = acc_a[m][n][r] + ba[r], ob = acc_b[m][n][r] + bb[r];
                     tile[h * P + col] = xr[r] + oa * sigmoid_m(ob);
                 }
             }
+        }
     }
     __syncthreads();
 
@@ -209,6 +226,8 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
     const float4* A1 = reinterpret_cast<const float4*>(a.A1);
     const float4* A2 = reinterpret_cast<const float4*>(a.A2);
     const float lnm = a.ln_m[0];
+    __amdgpu_buffer_rsrc_t rRs = __builtin_amdgcn_make_buffer_rsrc((void*)a.rs1, 0, FFE * H * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b1, 0, FFE * H * 4, 0x00020000);
     f32x16 acc2[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -227,10 +246,17 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
         int mt_q[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) mt_q[m] = q * (H / 32) + mt_h[m];
-        if (!(a.dbg & 1)) gemm_slab<MT, NT, P>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
+        gemm_slab<MT, NT, P>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
         if (q > 0) __syncthreads();  // previous chunk of u fully consumed by GEMM-2
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            float rsv[16], b1v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = q * H + mt_h[m] * 32 + (r & 3) + 8 * (r >> 2);
+                rsv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rRs, 16 * lhi, row * 4, 0)) * lnm;
+                b1v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB1, 16 * lhi, row * 4, 0));
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int col = (wn * NT + n) * 32 + l31;
@@ -238,34 +264,38 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int hr = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;  // row inside the chunk
-                    const int row = q * H + hr;
-                    const float pre = fmaf(al, acc1[m][n][r], fmaf(al * lnm, a.rs1[row], a.b1[row]));
+                    const float pre = fmaf(al, acc1[m][n][r] + rsv[r], b1v[r]);      // al * (W1 xc + m rowsum) + b1
                     ut[hr * P + col] = gelu_erf_m(pre);
                 }
             }
+        }
         __syncthreads();
-        if (!(a.dbg & 1)) gemm_slab<MT, NT, P>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
+        gemm_slab<MT, NT, P>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
     }
 
     // ---- out = x1 + f (+ addend);  x1 = centred tile + mean
-    float* __restrict__ ob = a.out + (size_t)b * H * L;
-    const float* __restrict__ addb = a.addend ? a.addend + (size_t)b * H * L : nullptr;
+    __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.addend ? a.addend + (size_t)b * H * L : a.out), 0, H * L4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, H * 4, 0x00020000);
+    const bool has_add = a.addend != nullptr;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+        float b2v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            b2v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int col = (wn * NT + n) * 32 + l31;
             const int pos = l0 + col;
-            const bool ok = pos < L;
-            const int posc = ok ? pos : 0;
+            const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
             const float mean = colmean[col];
             float ad[16];
-            if (addb) {
+            if (has_add) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    ad[r] = addb[h * L + posc];
-                }
+                for (int r = 0; r < 16; ++r)
+                    ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ad[r] = 0.f;
@@ -273,10 +303,11 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const float v = (tile[h * P + col] + mean) + (acc2[m][n][r] + a.b2[h]) + ad[r];
-                if (ok && (!(a.dbg & 4) || v == 123.456f)) ob[h * L + pos] = v;
+                const float v = (tile[h * P + col] + mean) + (acc2[m][n][r] + b2v[r]) + ad[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0);
             }
         }
+    }
 }
 
 template <int H, int WM, int WN, int NT>
@@ -291,10 +322,7 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    S4TailArgs aa = a;
-    static const int dbg = getenv("DWS_TAIL_DBG") ? atoi(getenv("DWS_TAIL_DBG")) : 0;
-    aa.dbg = dbg;
-    hipLaunchKernelGGL(kern, dim3(a.B * ntl), dim3(T::THREADS), lds, s, aa);
+    hipLaunchKernelGGL(kern, dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
     return DWS_OK;
 }
 
@@ -303,10 +331,6 @@ bool s4_tail_mfma_supported(int H, int ff) {
 }
 
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
-    static const int nt1 = getenv("DWS_TAIL_NT1") ? atoi(getenv("DWS_TAIL_NT1")) : 0;
-    if (nt1 & 1) { if (H == 64) return launch_tail_t<64, 2, 2, 1>(a, s); }
-    if (nt1 & 2) { if (H == 128) return launch_tail_t<128, 4, 1, 1>(a, s); }
-    if (nt1 & 4) { if (H == 256) return launch_tail_t<256, 8, 1, 1>(a, s); }
     switch (H) {
         case 32: return launch_tail_t<32, 1, 4, 1>(a, s);
         case 64: return launch_tail_t<64, 2, 2, 2>(a, s);
