@@ -67,6 +67,8 @@ _SIGS = {
                                          ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64,
                                          ctypes.c_int32, ctypes.c_void_p]),
+    "dws_mel_spectrogram": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int64, c_f32p, c_f32p, ctypes.c_int32,
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p, ctypes.c_void_p]),
     "dws_profile_enable": (ctypes.c_int, [ctypes.c_char_p]),
     "dws_profile_query": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     "dws_profile_disable": (ctypes.c_int, []),

@@ -183,10 +183,17 @@ def generate(rank, diffusion_cfg, model_cfg, dataset_cfg, ckpt_iter="max", n_sam
         batch_size = n_samples
     assert n_samples % batch_size == 0
     if mel_name is not None:
-        if mel_path is None:
-            raise NotImplementedError("computing the mel spectrogram from a .wav (`dataloaders/mel2samp.py`) is not "
-                                      "built; pass mel_path=<dir of *.wav.pt>")
-        mel = torch.load(os.path.join(mel_path, f"{mel_name}.wav.pt")).unsqueeze(0).cuda()
+        if mel_path is not None:      # pre-generated spectrogram (`generate.py:135-141`)
+            try:
+                mel = torch.load(os.path.join(mel_path, f"{mel_name}.wav.pt")).unsqueeze(0).cuda()
+            except Exception:
+                raise Exception("No ground truth mel spectrogram found")
+        else:                         # from the waveform (`generate.py:142-153`)
+            from .mel import Mel2Samp, load_wav_to_torch
+            keys = ("filter_length", "hop_length", "win_length", "sampling_rate", "mel_fmin", "mel_fmax")
+            _mel = Mel2Samp(**{k: dataset_cfg[k] for k in keys if k in dataset_cfg})
+            audio, sr = load_wav_to_torch(os.path.join(str(dataset_cfg["data_path"]), f"{mel_name}.wav"))
+            mel = _mel.get_mel(audio).unsqueeze(0)
         audio_length = mel.shape[-1] * dataset_cfg["hop_length"]
     else:
         audio_length, mel = dataset_cfg["segment_length"], None

@@ -185,6 +185,14 @@ int dws_sampler_steps(dws_model* m, float* x, const float* alpha, const float* a
                       const float* sigma, int32_t T, int32_t t_start, int32_t n_steps,
                       uint64_t seed, int32_t use_graph, void* stream);
 
+/* Mel-spectrogram front-end of the vocoding path: TacotronSTFT.mel_spectrogram
+ * (`dataloaders/stft.py:196-244`) as called by Mel2Samp.get_mel (`dataloaders/mel2samp.py:76-82`) and
+ * generate.py:147-153.  audio [B][T] in [-1, 1]; window [n_fft] (the Hann window, centre-padded to
+ * filter_length, `stft.py:122-129`); mel_basis [n_mels][n_fft/2+1] (`stft.py:203-210`); out
+ * [B][n_mels][T/hop + 1] = log(max(mel_basis . |STFT|, clip)).  All pointers are device pointers. */
+int dws_mel_spectrogram(const float* audio, int64_t B, int64_t T, const float* window, const float* mel_basis,
+                        int32_t n_fft, int32_t hop, int32_t n_mels, float clip, float* out, void* stream);
+
 /* Timing of the dominant kernel, measured with HIP events on the stream the
  * kernel was launched on (bench.py roofline leg).  Enables per-launch event
  * recording for kernels whose name contains `substr`; query returns the number

@@ -260,7 +260,51 @@ def g_s4_parts():
     save("s4_parts", **out)
 
 
-GROUPS = {"sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
+def g_mel():
+    """`dataloaders/stft.py` (TacotronSTFT) imported from the reference.  `librosa` is absent from this image, so
+    a stand-in module supplies the two functions stft.py takes from it: `librosa.util.pad_center` (zero padding,
+    trivial) and `librosa.filters.mel`, for which OUR restatement of the published Slaney filterbank is used --
+    i.e. these vectors pin the STFT / magnitude / matmul / log chain, NOT the filterbank (recorded as `mel_basis`
+    and flagged `filterbank_pinned = 0`)."""
+    import types
+    from diffwave_sashimi_amd.mel import mel_filterbank
+    lib = types.ModuleType("librosa")
+    lib.util = types.ModuleType("librosa.util")
+    lib.filters = types.ModuleType("librosa.filters")
+
+    def pad_center(data, size, axis=-1):
+        n = data.shape[axis]
+        lpad = (size - n) // 2
+        return np.pad(data, (lpad, size - n - lpad))
+    lib.util.pad_center = pad_center
+    lib.util.tiny = lambda x: np.finfo(np.float32).tiny
+    lib.filters.mel = lambda sr, n_fft, n_mels=128, fmin=0.0, fmax=None: mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    sys.modules["librosa"], sys.modules["librosa.util"], sys.modules["librosa.filters"] = lib, lib.util, lib.filters
+    import importlib.util                      # the package __init__ pulls in torchvision / torchaudio: load the file itself
+    spec = importlib.util.spec_from_file_location("ref_stft", os.path.join(_refimport.REF, "dataloaders", "stft.py"))
+    ref_stft = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_stft)
+    TacotronSTFT = ref_stft.TacotronSTFT
+    out = {"filterbank_pinned": np.zeros(1)}
+    g = torch.Generator().manual_seed(77)
+    cases_ = {"lj": dict(filter_length=1024, hop_length=256, win_length=1024, sampling_rate=22050, mel_fmin=0.0, mel_fmax=8000.0),
+              "small": dict(filter_length=256, hop_length=64, win_length=200, sampling_rate=16000, mel_fmin=50.0, mel_fmax=7000.0)}
+    for name, kw in cases_.items():
+        st = TacotronSTFT(**kw)
+        T = 16000 if name == "lj" else 3001
+        t = torch.arange(T) / kw["sampling_rate"]
+        y = 0.5 * torch.sin(2 * np.pi * 440.0 * t) * torch.linspace(0, 1, T) + 0.1 * torch.randn(2, T, generator=g)
+        y = y.clamp(-1, 1)
+        y[1, T // 2:] = 0.0                                   # silence: exercises the clamp at 1e-5
+        mag, _ = st.stft_fn.transform(y)
+        out[f"{name}/y"], out[f"{name}/mel"], out[f"{name}/mag"] = y, st.mel_spectrogram(y), mag
+        out[f"{name}/mel_basis"] = st.mel_basis
+        out[f"{name}/cfg"] = np.array([kw["filter_length"], kw["hop_length"], kw["win_length"], kw["sampling_rate"],
+                                       kw["mel_fmin"], kw["mel_fmax"]], dtype=np.float64)
+    save("mel", **out)
+
+
+GROUPS = {"mel": g_mel, "sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
           "wavenet_cond": g_wavenet_cond, "sampler": g_sampler}
 
 if __name__ == "__main__":

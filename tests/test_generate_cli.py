@@ -137,3 +137,38 @@ def test_generate_end_to_end_from_a_checkpoint(tmp_path, gpu):
     assert torch.equal(audio, again)                                               # seeded -> reproducible
     with pytest.raises(Exception, match="No valid model found"):
         generate(0, diff, dict(cfg), ds, ckpt_iter=3000, n_samples=2, exp_root=root)
+
+
+@pytest.mark.gpu
+def test_generate_vocodes_from_a_wav(tmp_path, gpu):
+    """Conditional path of `generate.py:134-153`: mel computed from `<data_path>/<mel_name>.wav` by the HIP
+    front-end, audio length = frames * hop; and the pre-generated `.wav.pt` route gives the same result."""
+    from scipy.io import wavfile
+    from diffwave_sashimi_amd.generate import generate, local_path_name
+    from oracle import mel as omel
+    from diffwave_sashimi_amd.mel import mel_filterbank
+    cfg, B, L, Tmel, wseed, iseed, _ = cases.WAVENET_COND_CASES["wn_cond_c64"]
+    diff = dict(T=4, beta_0=1e-4, beta_T=0.05, beta=None)
+    data = tmp_path / "wavs"
+    os.makedirs(data)
+    rng = np.random.default_rng(3)
+    wav = (rng.standard_normal(700) * 3000).astype(np.int16)             # 700 samples -> 700//256 + 1 = 3 frames
+    wavfile.write(str(data / "LJ001-0001.wav"), 22050, wav)
+    ds = dict(_name_="ljspeech", data_path=str(data), segment_length=768, sampling_rate=22050, filter_length=1024,
+              hop_length=256, win_length=1024, mel_fmin=0.0, mel_fmax=8000.0)
+    root = str(tmp_path / "exp")
+    run = local_path_name(None, cfg, diff, ds)
+    assert run.endswith("_L768_hop256_cond")
+    os.makedirs(os.path.join(root, run, "checkpoint"))
+    torch.save({"model_state_dict": cases.build_ours(cfg, wseed).state_dict()}, os.path.join(root, run, "checkpoint", "7.pkl"))
+    a = generate(0, diff, dict(cfg), ds, ckpt_iter="max", n_samples=2, mel_name="LJ001-0001", exp_root=root, seed=5)
+    assert a.shape == (2, 1, 3 * 256) and torch.isfinite(a).all()
+    # same utterance through the pre-generated-mel route, mel from the CPU oracle
+    y = torch.from_numpy(wav.astype(np.float32) / 32768.0).unsqueeze(0)
+    mel = omel.mel_spectrogram(y, torch.from_numpy(mel_filterbank(22050, 1024, 80, 0.0, 8000.0)))[0]
+    mdir = tmp_path / "mels"
+    os.makedirs(mdir)
+    torch.save(mel, str(mdir / "LJ001-0001.wav.pt"))
+    b = generate(0, diff, dict(cfg), ds, ckpt_iter=7, n_samples=2, mel_name="LJ001-0001", mel_path=str(mdir), exp_root=root,
+                 seed=5)
+    assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max())
