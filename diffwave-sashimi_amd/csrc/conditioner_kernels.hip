@@ -63,3 +63,85 @@ int launch_conv1x1_trunc(const float* in, const float* W, const float* bias, flo
 }
 
 }  // namespace dws
+
+// ---------------------------------------------------------------------------
+// Training: adjoint of the conditioner (`wavenet.py:98-111`, `sashimi.py:160-175`)
+// ---------------------------------------------------------------------------
+namespace dws {
+
+// gradient entering an upsampler's pre-activation: dout masked to the columns the forward kept
+// (`mel_spec[:, :, :L]`) times leaky_relu'(out) (out > 0 <=> pre-activation > 0, the slope is positive)
+__device__ __forceinline__ float dpre_at(const float* __restrict__ dout, const float* __restrict__ out, int m, int x,
+                                         int M, int Tout, int dstride, int dvalid, float slope) {
+    if (m < 0 || m >= M || x < 0 || x >= Tout || x >= dvalid) return 0.f;
+    const float d = dout[(size_t)m * dstride + x];
+    return out[(size_t)m * Tout + x] > 0.f ? d : d * slope;
+}
+
+// din[b, m, t] = sum_{ky<3} sum_{kx<2s} dpre[b, m - 1 + ky, t*s - s/2 + kx] * W[ky, kx]
+__global__ void mel_upsample_bwd_input_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                              const float* __restrict__ W, float* __restrict__ din, int M, int Tin,
+                                              int Tout, int s, int dstride, int dbstride, int dvalid, float slope) {
+    const int b = blockIdx.z, m = blockIdx.y;
+    const float* db = dout + (size_t)b * dbstride;
+    const float* ob = out + (size_t)b * M * Tout;
+    const int kw = 2 * s, pad = s / 2;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tin; t += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < kw; ++kx)
+                acc = fmaf(dpre_at(db, ob, m - 1 + ky, t * s - pad + kx, M, Tout, dstride, dvalid, slope), W[ky * kw + kx], acc);
+        din[((size_t)b * M + m) * Tin + t] = acc;
+    }
+}
+
+// dW[ky, kx] = sum_{b, m, t} in[b, m, t] * dpre[b, m - 1 + ky, t*s - s/2 + kx];  block 3*2s (the last one: dbias = sum dpre)
+__global__ __launch_bounds__(256) void mel_upsample_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                                      const float* __restrict__ out, float* __restrict__ dW,
+                                                                      float* __restrict__ dbias, int B, int M, int Tin,
+                                                                      int Tout, int s, int dstride, int dbstride,
+                                                                      int dvalid, float slope) {
+    __shared__ float red[4];
+    const int kw = 2 * s, pad = s / 2;
+    const int w = blockIdx.x;
+    float acc = 0.f;
+    if (w < 3 * kw) {
+        const int ky = w / kw, kx = w % kw;
+        const int n = B * M * Tin;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int t = i % Tin, m = (i / Tin) % M, b = i / (Tin * M);
+            acc = fmaf(in[i], dpre_at(dout + (size_t)b * dbstride, out + (size_t)b * M * Tout, m - 1 + ky, t * s - pad + kx, M,
+                                      Tout, dstride, dvalid, slope), acc);
+        }
+    } else {
+        const int n = B * M * Tout;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int x = i % Tout, m = (i / Tout) % M, b = i / (Tout * M);
+            acc += dpre_at(dout + (size_t)b * dbstride, out + (size_t)b * M * Tout, m, x, M, Tout, dstride, dvalid, slope);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = red[0] + red[1] + red[2] + red[3];
+        if (w < 3 * kw) dW[w] = v;
+        else dbias[0] = v;
+    }
+}
+
+int launch_mel_upsample_bwd(const float* in, const float* out, const float* dout, const float* W, float* din, float* dW,
+                            float* dbias, int B, int M, int Tin, int Tout, int s, int dstride, int dbstride, int dvalid,
+                            float slope, hipStream_t st) {
+    if (din) {
+        dim3 grid(min(ceil_div(Tin, 256), 1024), M, B);
+        hipLaunchKernelGGL(mel_upsample_bwd_input_kernel, grid, dim3(256), 0, st, dout, out, W, din, M, Tin, Tout, s, dstride,
+                           dbstride, dvalid, slope);
+    }
+    hipLaunchKernelGGL(mel_upsample_bwd_weight_kernel, dim3(3 * 2 * s + 1), dim3(256), 0, st, in, dout, out, dW, dbias, B, M,
+                       Tin, Tout, s, dstride, dbstride, dvalid, slope);
+    return DWS_OK;
+}
+
+}  // namespace dws

@@ -111,6 +111,10 @@ struct SashimiModel : dws_model {
     uint64_t commit_version = 0, train_pack_version = ~0ull;
     bool trained_fwd = false;
     const float* train_audio = nullptr;
+    DevBuf mel_in;                    // copy of the installed mel [Bm][MB][Tmel] (conditioner adjoint)
+    int mel_T = 0;
+    CondTrainWs cws;
+    DevBuf gW0f, gW1f, gWcf;
 
     ~SashimiModel() override {
         for (auto* l : all) delete l;
@@ -442,6 +446,9 @@ struct SashimiModel : dws_model {
                                          MB, l->H, T1, l->L, s));
         }
         DWS_HIP(hipStreamSynchronize(s));  // u0/u1 are freed on return
+        DWS_TRY(mel_in.ensure((size_t)Bm * MB * Tmel * 4));
+        DWS_HIP(hipMemcpyAsync(mel_in.p, mel, (size_t)Bm * MB * Tmel * 4, hipMemcpyDeviceToDevice, s));
+        mel_T = (int)Tmel;
         melBm = Bm;
         return DWS_OK;
     }
@@ -666,7 +673,9 @@ struct SashimiModel : dws_model {
     }
 
     int train_supported() {
-        DWS_CHECK(melBm == 0 && !cond, DWS_ERR_UNSUPPORTED, "training of the mel-conditional path is not built yet");
+        DWS_CHECK(melBm == 0 || melBm == B, DWS_ERR_UNSUPPORTED,
+                  "mel-conditional training needs one mel per clip (got %lld for B=%lld)", (long long)melBm, (long long)B);
+        DWS_CHECK(!cond || melBm > 0, DWS_ERR_STATE, "conditional model: install the mel (set_condition) before forward_train");
         for (auto* l : all) {
             if (l->kind == L_BLOCK) {
                 DWS_CHECK(l->log2m > 0, DWS_ERR_UNSUPPORTED,
@@ -745,7 +754,7 @@ struct SashimiModel : dws_model {
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
                 DWS_TRY(gemm(l->tAo.f(), 2 * H, H, st->g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"), nullptr,
                              nullptr, nullptr, nullptr, s));
-                DWS_TRY(launch_glu_res(l->t_o.f(), x, l->t_x1.f(), nB, H, Ls, s));
+                DWS_TRY(launch_glu_res(l->t_o.f(), x, melBm ? l->melc.f() : nullptr, l->t_x1.f(), nB, H, Ls, s));
                 DWS_TRY(launch_ln(l->t_x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, l->t_n2.f(), nB, H, Ls,
                                   (size_t)Ls, s));
                 DWS_TRY(gemm(l->tA1.f(), FF * H, H, l->t_n2.f(), l->t_f1.f(), Ls, 3, P(p + ".ff.ff.0.conv.bias"), nullptr,
@@ -882,6 +891,19 @@ struct SashimiModel : dws_model {
                 DWS_TRY(launch_ln_bwd(l->t_x1.f(), st->dh.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), dy, st->dx1.f(), 0,
                                       lnpart.f(), nB, H, Ls, s));
                 DWS_TRY(ln_scalars(p + ".norm2", nblk, s));
+                if (melBm) {  // x1 = ... + melc: the block's conditioner sees d x1 (`sashimi.py:160-175`)
+                    const int s0 = d.mel_upsample[0], s1 = d.mel_upsample[1];
+                    DWS_TRY(gW0f.ensure((size_t)3 * 2 * s0 * 4)); DWS_TRY(gW1f.ensure((size_t)3 * 2 * s1 * 4));
+                    DWS_TRY(gWcf.ensure((size_t)H * MB * 4));
+                    DWS_TRY(conditioner_backward(cws, mel_in.f(), nB, MB, mel_T, s0, s1, l->melW0.f(), P(p + ".upsample_conv2d.0.bias"),
+                                                 l->melW1.f(), P(p + ".upsample_conv2d.1.bias"), l->melWc.f(), H, Ls, st->dx1.f(),
+                                                 gW0f.f(), G(p + ".upsample_conv2d.0.bias"), gW1f.f(),
+                                                 G(p + ".upsample_conv2d.1.bias"), gWcf.f(), s));
+                    DWS_TRY(wn_bwd(p + ".upsample_conv2d.0", gW0f.f(), 1, 3 * 2 * s0, s));
+                    DWS_TRY(wn_bwd(p + ".upsample_conv2d.1", gW1f.f(), 1, 3 * 2 * s1, s));
+                    DWS_TRY(wn_bwd(p + ".mel_conv.conv", gWcf.f(), H, MB, s));
+                    DWS_TRY(launch_rowsum(st->dx1.f(), G(p + ".mel_conv.conv.bias"), nB, H, Ls, 1.f, 0, s));
+                }
                 // x1 = x + glu(o), o = Wo gelu(a) + bo
                 DWS_TRY(launch_glu_bwd(st->dx1.f(), l->t_o.f(), st->d2.f(), nB, H, Ls, s));
                 DWS_TRY(gemm(l->tAoT.f(), H, 2 * H, st->d2.f(), st->dh.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_a.f(), nullptr, s));

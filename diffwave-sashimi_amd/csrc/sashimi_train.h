@@ -6,7 +6,7 @@ namespace dws {
 int launch_ln_bwd(const float* x, const float* dy, const float* m_p, const float* s_p, const float* base, float* out,
                   int accumulate, float* partial, int B, int H, int L, hipStream_t s);
 int launch_sum_leading(const float* partial, float* out, size_t n, int k, float scale, hipStream_t s);
-int launch_glu_res(const float* o, const float* x, float* x1, int B, int H, int L, hipStream_t s);
+int launch_glu_res(const float* o, const float* x, const float* mel, float* x1, int B, int H, int L, hipStream_t s);
 int launch_glu_bwd(const float* dx1, const float* o, float* dout, int B, int H, int L, hipStream_t s);
 int launch_pool_rearrange(const float* in, float* out, const float* addend, int dir, int accumulate, int B, int H,
                           int p, int Lp, hipStream_t s);

@@ -136,13 +136,13 @@ int launch_sum_leading(const float* partial, float* out, size_t n, int k, float 
 // ---------------------------------------------------------------------------
 // GLU + residual (`s4.py:1435`, `sashimi.py:177`): x1 = x + o_a * sigmoid(o_b), o = [o_a; o_b] [B, 2H, L]
 // ---------------------------------------------------------------------------
-__global__ void glu_res_kernel(const float* __restrict__ o, const float* __restrict__ x, float* __restrict__ x1, int H,
-                               int L, size_t n) {
+__global__ void glu_res_kernel(const float* __restrict__ o, const float* __restrict__ x, const float* __restrict__ mel,
+                               float* __restrict__ x1, int H, int L, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t hl = (size_t)H * L, b = i / hl, r = i % hl;
     const float oa = o[b * 2 * hl + r], ob = o[b * 2 * hl + hl + r];
-    x1[i] = x[i] + oa * sigm_t(ob);
+    x1[i] = x[i] + oa * sigm_t(ob) + (mel ? mel[i] : 0.f);      // + conditioner term (`sashimi.py:160-175`)
 }
 
 __global__ void glu_bwd_kernel(const float* __restrict__ dx1, const float* __restrict__ o, float* __restrict__ dout,
@@ -156,9 +156,9 @@ __global__ void glu_bwd_kernel(const float* __restrict__ dx1, const float* __res
     dout[b * 2 * hl + hl + r] = d * oa * sg * (1.f - sg);
 }
 
-int launch_glu_res(const float* o, const float* x, float* x1, int B, int H, int L, hipStream_t s) {
+int launch_glu_res(const float* o, const float* x, const float* mel, float* x1, int B, int H, int L, hipStream_t s) {
     const size_t n = (size_t)B * H * L;
-    hipLaunchKernelGGL(glu_res_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, o, x, x1, H, L, n);
+    hipLaunchKernelGGL(glu_res_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, o, x, mel, x1, H, L, n);
     return DWS_OK;
 }
 

@@ -50,6 +50,7 @@ struct WgradArgs {
     int xact;                    // 1: the X operand is gelu(X) (recomputed from the saved pre-activation)
     float* bias_part;            // optional [nsplit][O] scratch: also produce dbias[o] = bias_scale * sum_{b,l} dY[b,o,l]
     float* dbias; float bias_scale;
+    int xL;                      // row stride of X in floats (0 = L)
 };
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T);
 int launch_wgrad_mfma(const WgradArgs& a, int T, float scale, float* dW, hipStream_t s);

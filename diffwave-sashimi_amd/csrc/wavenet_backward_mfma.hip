@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 
     // one descriptor per operand; the wave-uniform row offset rides in the scalar offset of the load
     __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)((size_t)a.B * a.O * L * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)((size_t)a.B * a.C * L * 4), 0x00020000);
+    const int xL = a.xL ? a.xL : L;   // X rows may be longer than L (the conditioner's un-truncated upsampled mel)
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)((size_t)a.B * a.C * xL * 4), 0x00020000);
     float rdy[RPW], rx[RPW];
     float mdy = 0.f, mx = 0.f;   // range masks of this lane's position in the fetched chunk
     int fb = 0;                  // batch index of the fetched chunk
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
             const int row = wave + 4 * i;
             const int o = min(o0 + row, a.O - 1), c = min(c0 + row, a.C - 1);
             rdy[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, vy, (b * a.O + o) * L * 4, 0));
-            rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, vx, (b * a.C + c) * L * 4, 0));
+            rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, vx, (b * a.C + c) * xL * 4, 0));
         }
     };
     auto commit = [&]() {
@@ -365,7 +366,7 @@ int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
 
 int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipStream_t s) {
     ProfileScope ps("wgrad_mfma", s);
-    DWS_CHECK((size_t)a_in.B * std::max(a_in.O, a_in.C) * a_in.L * 4 < ((size_t)1 << 31), DWS_ERR_UNSUPPORTED,
+    DWS_CHECK((size_t)a_in.B * std::max(a_in.O, a_in.C) * std::max(a_in.L, a_in.xL) * 4 < ((size_t)1 << 31), DWS_ERR_UNSUPPORTED,
               "wgrad_mfma: operand larger than 2 GiB (B=%d rows=%d L=%d)", a_in.B, std::max(a_in.O, a_in.C), a_in.L);
     WgradArgs a = a_in;
     const dim3 grid(ceil_div(a.O, 128), ceil_div(a.C, 128), T * a.nsplit);

@@ -29,6 +29,10 @@ struct WaveNetModel : dws_model {
     DevBuf melc;                     // [NL][Bm][2C][L]
     DevBuf mel_u0, mel_u1;           // upsample scratch
     int64_t melBm = 0;               // 0 = no condition installed
+    DevBuf mel_in;                   // copy of the installed mel [Bm][MB][Tmel] (the conditioner adjoint needs it)
+    int mel_T = 0;
+    CondTrainWs cws;
+    DevBuf gW0f, gW1f, gWcf;         // folded-weight gradients of one layer's conditioner
     // workspace
     DevBuf x0, x1, skip, gate, emb, h1, h2, part_t, scratch_out;
     // training workspace: per-layer inputs and pre-gate activations, saved pre-activations of the
@@ -259,6 +263,9 @@ struct WaveNetModel : dws_model {
             DWS_TRY(launch_conv1x1_trunc(mel_u1.f(), melWc[n].f(), P(p + ".mel_conv.conv.bias"),
                                          melc.f() + (size_t)n * Bm * 2 * C * L, (int)Bm, MB, 2 * C, T1, (int)L, s));
         }
+        DWS_TRY(mel_in.ensure((size_t)Bm * MB * Tmel * 4));
+        DWS_HIP(hipMemcpyAsync(mel_in.p, mel, (size_t)Bm * MB * Tmel * 4, hipMemcpyDeviceToDevice, s));
+        mel_T = (int)Tmel;
         melBm = Bm;
         return DWS_OK;
     }
@@ -280,7 +287,10 @@ struct WaveNetModel : dws_model {
     int forward_train(const float* audio, const float* steps, float* out, hipStream_t s) override {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
         DWS_CHECK(!bf16x3, DWS_ERR_UNSUPPORTED, "training runs with precision=f32 (bf16x3 backward is not built)");
-        DWS_CHECK(melBm == 0, DWS_ERR_UNSUPPORTED, "training of the mel-conditional path is not built yet");
+        DWS_CHECK(melBm == 0 || (melBm == B && mfma_bwd), DWS_ERR_UNSUPPORTED,
+                  "mel-conditional training needs one mel per clip (got %lld for B=%lld) and the MFMA adjoints (channels %% 32 == 0)",
+                  (long long)melBm, (long long)B);
+        DWS_CHECK(!cond || melBm > 0, DWS_ERR_STATE, "conditional model: install the mel (set_condition) before forward_train");
         const size_t act = (size_t)B * C * L * 4;
         tx.resize(NL + 1); tH.resize(NL);
         for (int n = 0; n <= NL; ++n) DWS_TRY(tx[n].ensure(act));
@@ -401,6 +411,18 @@ struct WaveNetModel : dws_model {
                 }
                 DWS_TRY(launch_gate_bwd(dgb.f(), tH[n].f(), dHb.f(), gate.f(), nB, C, nL, s));
             }
+            if (melBm) {  // conditioner of this layer: d melc = dH (`wavenet.py:98-111`)
+                const int s0 = d.mel_upsample[0], s1 = d.mel_upsample[1];
+                DWS_TRY(gW0f.ensure((size_t)3 * 2 * s0 * 4)); DWS_TRY(gW1f.ensure((size_t)3 * 2 * s1 * 4));
+                DWS_TRY(gWcf.ensure((size_t)2 * C * MB * 4));
+                DWS_TRY(conditioner_backward(cws, mel_in.f(), nB, MB, mel_T, s0, s1, melW0[n].f(), P(p + ".upsample_conv2d.0.bias"),
+                                             melW1[n].f(), P(p + ".upsample_conv2d.1.bias"), melWc[n].f(), 2 * C, nL, dHb.f(),
+                                             gW0f.f(), G(p + ".upsample_conv2d.0.bias"), gW1f.f(),
+                                             G(p + ".upsample_conv2d.1.bias"), gWcf.f(), s));
+                DWS_TRY(wn_bwd(p + ".upsample_conv2d.0", gW0f.f(), 1, 3 * 2 * s0, s));
+                DWS_TRY(wn_bwd(p + ".upsample_conv2d.1", gW1f.f(), 1, 3 * 2 * s1, s));
+                DWS_TRY(wn_bwd(p + ".mel_conv.conv", gWcf.f(), 2 * C, MB, s));
+            }
             // res / skip 1x1 weights and biases (dres = dx' * sqrt(.5))
             if (dx_out) {
                 DWS_TRY(wgrad(dx_out, gate.f(), nullptr, 0, dWfold.f(), C, C, 1, 1, r2, s, G(p + ".res_conv.bias"), r2));
@@ -416,6 +438,9 @@ struct WaveNetModel : dws_model {
             DWS_TRY(wgrad(dHb.f(), tx[n].f(), part_t.f() + (size_t)n * C, NL * C, dWfold.f(), 2 * C, C, 3, dil, 1.f, s,
                           G(p + ".dilated_conv_layer.conv.bias")));
             DWS_TRY(wn_bwd(p + ".dilated_conv_layer.conv", dWfold.f(), 2 * C, C * 3, s));
+            if (melBm)    // the conditioner's 1x1 bias enters H next to the dilated conv's: same gradient
+                DWS_HIP(hipMemcpyAsync(G(p + ".mel_conv.conv.bias"), G(p + ".dilated_conv_layer.conv.bias"), (size_t)2 * C * 4,
+                                       hipMemcpyDeviceToDevice, s));
             if (mfma_bwd) {
                 TapConvArgs q{};
                 q.src0 = dHb.f(); q.K0 = 2 * C; q.A = ATd[n].f(); q.nkg_total = 6 * C / 8; q.M = C; q.T = 3; q.dil = dil;

@@ -15,12 +15,12 @@ class _EngineTrainFn(torch.autograd.Function):
     ``distributed_util.apply_gradient_allreduce`` work unchanged)."""
 
     @staticmethod
-    def forward(ctx, module, audio, steps, *params):
+    def forward(ctx, module, audio, steps, mel_spec, *params):
         lib = _lib.load()
         B, _, L = audio.shape
         module._sync_params()
         module._prepare(B, L)
-        module._set_condition(None)
+        module._set_condition(mel_spec)      # conditional models: the conditioner's parameters get gradients too
         x = audio.detach().to(torch.float32).contiguous()
         out = torch.empty((B, module.out_channels, L), device=audio.device, dtype=torch.float32)
         _lib.check(lib.dws_model_forward_train(module._handle, x.data_ptr(), steps.data_ptr(), out.data_ptr(),
@@ -40,7 +40,7 @@ class _EngineTrainFn(torch.autograd.Function):
             g = torch.empty(shape, device=d.device, dtype=torch.float32)
             _lib.check(lib.dws_model_get_grad(m._handle, name.encode(), g.data_ptr(), g.numel(), _lib.current_stream()))
             grads.append(g.to(dtype))
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class EngineModule(nn.Module):
@@ -143,12 +143,10 @@ class EngineModule(nn.Module):
         B, Cin, L = audio.shape
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
             # training call (`train.py:221`): differentiable w.r.t. the parameters
-            if mel_spec is not None:
-                raise NotImplementedError("training of the mel-conditional path is not built yet")
             steps = diffusion_steps.detach().to(device=audio.device, dtype=torch.float32).reshape(-1).contiguous()
             if steps.numel() != B:
                 raise RuntimeError(f"diffusion_steps must hold B={B} entries, got {tuple(diffusion_steps.shape)}")
-            return _EngineTrainFn.apply(self, audio, steps, *self.parameters())
+            return _EngineTrainFn.apply(self, audio, steps, mel_spec, *self.parameters())
         with torch.no_grad():
             self._sync_params()
             self._prepare(B, L)

@@ -10,8 +10,10 @@ checkpoints followed by an in-loop ``generate`` call.  wandb is replaced by a JS
     python -m diffwave_sashimi_amd.train --config-dir /path/to/configs experiment=sc09 model=sashimi \
         dataset.data_path=/data/sc09 train.batch_size_per_gpu=32
 
-Datasets: ``sc09`` (a directory tree of 1 s / 16 kHz ``*_nohash_*.wav`` files, ``dataloaders/sc.py:25-64``) and
-``synthetic`` (uniform noise clips, for smoke runs).  The mel-conditional ``ljspeech`` loader is not built.
+Datasets: ``sc09`` (a directory tree of 1 s / 16 kHz ``*_nohash_*.wav`` files, ``dataloaders/sc.py:25-64``),
+``ljspeech`` (``dataloaders/mel2samp.py:59-113``: random ``segment_length`` crops of the wavs under ``data_path``;
+the log-mel of each batch is computed on the GPU by ``dws_mel_spectrogram`` right before the step instead of per
+item on the loader's CPU workers) and ``synthetic`` (uniform noise clips, for smoke runs).
 """
 import argparse
 import json
@@ -66,6 +68,36 @@ class SpeechCommands(torch.utils.data.Dataset):
         return len(self._walker)
 
 
+class LJSegments(torch.utils.data.Dataset):
+    """The audio half of ``Mel2Samp`` (``dataloaders/mel2samp.py:59-113``): wavs found under ``data_path``
+    (`files_to_list`, shuffled with ``random.seed(1234)``), sampling-rate check, a random ``segment_length`` crop
+    (zero-padded when shorter); items are the raw-scale float waveform ``[segment_length]``."""
+
+    def __init__(self, data_path, segment_length, sampling_rate, valid=False, **_ignored):
+        import random
+        self.audio_files = sorted(str(p) for p in Path(data_path).glob("**/*.wav"))
+        random.seed(1234)
+        random.shuffle(self.audio_files)
+        self.segment_length, self.sampling_rate, self.valid = segment_length, sampling_rate, valid
+
+    def __getitem__(self, index):
+        import random
+        from .mel import load_wav_to_torch
+        audio, sr = load_wav_to_torch(self.audio_files[index])
+        if sr != self.sampling_rate:
+            raise ValueError("{} SR doesn't match target {} SR".format(sr, self.sampling_rate))
+        if not self.valid:
+            if audio.size(0) >= self.segment_length:
+                start = random.randint(0, audio.size(0) - self.segment_length)
+                audio = audio[start:start + self.segment_length]
+            else:
+                audio = torch.nn.functional.pad(audio, (0, self.segment_length - audio.size(0)), "constant").data
+        return audio
+
+    def __len__(self):
+        return len(self.audio_files)
+
+
 class SyntheticClips(torch.utils.data.Dataset):
     """U(-0.3, 0.3) clips (SURVEY.md 8d's synthetic workload) with the sc09 item layout."""
 
@@ -89,9 +121,11 @@ def dataloader(dataset_cfg, batch_size, num_gpus, unconditional=True, rank=0, nu
     elif name == "synthetic":
         dataset = SyntheticClips(dataset_cfg.get("n_items", 64), dataset_cfg.get("segment_length", 16000),
                                  dataset_cfg.get("sampling_rate", 16000))
+    elif name == "ljspeech":
+        assert not unconditional
+        dataset = LJSegments(**{k: v for k, v in dataset_cfg.items() if k != "_name_"})
     else:
-        raise NotImplementedError(f"dataset '{name}': the mel-conditional loader (`dataloaders/mel2samp.py`) and "
-                                  "mel-conditional training are not built")
+        raise NotImplementedError(f"dataset '{name}' is not built (sc09, ljspeech, synthetic are)")
     sampler = None
     if num_gpus > 1:
         from torch.utils.data.distributed import DistributedSampler
@@ -146,6 +180,12 @@ def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, c
             with open(log_path, "a") as f:
                 f.write(json.dumps(dict(record, step=step)) + "\n")
 
+    stft = None
+    if not model_cfg["unconditional"]:
+        from .mel import MAX_WAV_VALUE, TacotronSTFT
+        keys = dict(filter_length="filter_length", hop_length="hop_length", win_length="win_length",
+                    sampling_rate="sampling_rate", mel_fmin="mel_fmin", mel_fmax="mel_fmax")
+        stft = TacotronSTFT(**{k: dataset_cfg[v] for k, v in keys.items() if v in dataset_cfg})
     loss_fn = nn.MSELoss()
     n_iter = ckpt_iter + 1
     epoch = 0
@@ -154,9 +194,13 @@ def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, c
         if getattr(trainloader, "sampler", None) is not None and hasattr(trainloader.sampler, "set_epoch"):
             trainloader.sampler.set_epoch(epoch)
         for data in trainloader:
-            audio = data[0].cuda()
+            if stft is None:
+                audio, mel = data[0].cuda(), None
+            else:   # `mel2samp.py:76-82,107-111`: mel of audio / MAX_WAV_VALUE, audio [B, 1, L] in [-1, 1]
+                audio = (data.cuda() / MAX_WAV_VALUE).unsqueeze(1)
+                mel = stft.mel_spectrogram(audio[:, 0])
             optimizer.zero_grad()
-            loss = training_loss(net, loss_fn, audio, dh)
+            loss = training_loss(net, loss_fn, audio, dh, mel_spec=mel)
             reduced_loss = reduce_tensor(loss.data, num_gpus).item() if num_gpus > 1 else loss.item()
             loss.backward()
             optimizer.step()

@@ -87,3 +87,36 @@ def test_sashimi_training_step_reduces_the_loss(gpu):
     with torch.no_grad():
         out = net((audio, torch.zeros(B, 1, device=gpu)))
     assert torch.isfinite(out).all()
+
+
+def test_conditional_sashimi_gradients_match_autograd(gpu):
+    """Mel-conditional SaShiMi training: every block's conditioner (two weight-normed ConvTranspose2d upsamplers +
+    `mel_conv`, pooled stages take the first L_stage upsampled frames, `sashimi.py:160-175`) gets gradients."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from diffwave_sashimi_amd.training import training_loss
+    cfg = cases.ss_cfg(unconditional=False, d_model=32, n_layers=1, L=1024, mel_upsample=[16, 16],
+                       diffusion_step_embed_dim_mid=64)
+    B, L, Tmel = 2, 1024, 4
+    net = cases.build_ours(cfg, 35).to(gpu).train()
+    dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
+    audio = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(39)) * 0.3
+    mel = torch.cat([cases.mel_inputs(1, Tmel, 41 + i) for i in range(B)])
+    loss = training_loss(net, nn.MSELoss(), audio.to(gpu), dh, mel_spec=mel.to(gpu), generator=torch.Generator().manual_seed(43))
+    loss.backward()
+    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    ref_loss = training_loss(lambda inp, mel_spec=None: oss.sashimi_forward(sd, cfg, inp[0], inp[1], mel_spec=mel_spec),
+                             nn.MSELoss(), audio, dh, mel_spec=mel, generator=torch.Generator().manual_seed(43))
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * max(1.0, abs(float(ref_loss)))
+    gmax = max(float(sd[k].grad.abs().max()) for k in got if sd[k].grad is not None)
+    bad, seen_cond = [], 0
+    for k, gk in got.items():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        seen_cond += ("upsample_conv2d" in k or "mel_conv" in k) and float(ref.abs().max()) > 0
+        scale = max(float(ref.abs().max()), 1e-5 * gmax)
+        err = float((gk - ref).abs().max()) / scale
+        if err >= 5e-3:
+            bad.append(f"{k}: rel err {err:.3e} (|ref|max {float(ref.abs().max()):.3e}, |got|max {float(gk.abs().max()):.3e})")
+    assert not bad, f"{len(bad)} of {len(got)} gradients off:\n" + "\n".join(bad[:30])
+    assert seen_cond >= 9 * 5          # 5 blocks x (2 upsamplers x (bias, g, v) + mel_conv (bias, g, v))

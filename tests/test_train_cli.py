@@ -53,7 +53,26 @@ def test_dataloader_shards_like_distributed_sampler():
     b = {tuple(np.round(x.flatten()[:4].numpy(), 6)) for x in seen[1]}
     assert not (a & b) and len(a | b) == 16
     with pytest.raises(NotImplementedError):
-        dataloader({"_name_": "ljspeech"}, 2, 1, unconditional=False)
+        dataloader({"_name_": "imagenet"}, 2, 1, unconditional=False)
+
+
+def test_ljspeech_segments(tmp_path):
+    """`dataloaders/mel2samp.py:84-111`: random crop of segment_length (zero pad when shorter), raw int16 scale."""
+    from diffwave_sashimi_amd.train import dataloader
+    rng = np.random.default_rng(1)
+    _write_wav(str(tmp_path / "a.wav"), (rng.integers(-3000, 3000, 5000)).astype(np.int16), 22050)
+    _write_wav(str(tmp_path / "b.wav"), (rng.integers(-3000, 3000, 900)).astype(np.int16), 22050)
+    cfg = {"_name_": "ljspeech", "data_path": str(tmp_path), "segment_length": 2048, "sampling_rate": 22050,
+           "filter_length": 1024, "hop_length": 256, "win_length": 1024, "mel_fmin": 0.0, "mel_fmax": 8000.0, "valid": False}
+    dl = dataloader(cfg, batch_size=2, num_gpus=1, unconditional=False, num_workers=0)
+    (batch,) = list(dl)
+    assert batch.shape == (2, 2048) and batch.dtype == torch.float32
+    assert float(batch.abs().max()) > 100          # raw sample values, scaled by 1/32768 only at the step
+    short = batch[[float(r[900:].abs().max()) == 0 for r in batch].index(True)]
+    assert float(short[:900].abs().max()) > 0
+    bad = dict(cfg, sampling_rate=16000)
+    with pytest.raises(ValueError):
+        list(dataloader(bad, batch_size=2, num_gpus=1, unconditional=False, num_workers=0))
 
 
 @pytest.mark.gpu
@@ -92,3 +111,29 @@ def test_train_checkpoint_generate_resume(tmp_path, gpu):
     assert sorted(os.listdir(ck)) == ["0.pkl", "3.pkl", "6.pkl"]
     resumed = torch.load(os.path.join(ck, "6.pkl"), map_location="cpu")
     assert resumed["optimizer_state_dict"]["state"][0]["step"] > saved["optimizer_state_dict"]["state"][0]["step"]
+
+
+@pytest.mark.gpu
+def test_train_conditional_from_wavs(tmp_path, gpu):
+    """The ljspeech experiment end to end on tiny data: wav crops -> HIP mel front-end -> conditional training step
+    -> checkpoint -> in-loop vocoding of `generate.mel_name` from its wav."""
+    from diffwave_sashimi_amd.generate import local_path_name
+    from diffwave_sashimi_amd.train import train
+    rng = np.random.default_rng(2)
+    data = tmp_path / "wavs"
+    for i in range(4):
+        _write_wav(str(data / f"LJ00{i}.wav"), (rng.standard_normal(3000) * 2500).astype(np.int16), 22050)
+    model = dict(_name_="wavenet", unconditional=False, in_channels=1, out_channels=1, diffusion_step_embed_dim_in=128,
+                 diffusion_step_embed_dim_mid=512, diffusion_step_embed_dim_out=512, res_channels=64, skip_channels=64,
+                 num_res_layers=2, dilation_cycle=2, mel_upsample=[16, 16])
+    ds = dict(_name_="ljspeech", data_path=str(data), segment_length=1024, sampling_rate=22050, filter_length=1024,
+              hop_length=256, win_length=1024, mel_fmin=0.0, mel_fmax=8000.0, valid=False)
+    diff = dict(T=10, beta_0=1e-4, beta_T=0.05)
+    exp = str(tmp_path / "exp")
+    train(0, 1, diff, model, ds, {"n_samples": 1, "mel_name": "LJ000"}, ckpt_iter=-1, n_iters=3, iters_per_ckpt=2,
+          iters_per_logging=1, learning_rate=1e-3, batch_size_per_gpu=2, exp_root=exp, num_workers=0)
+    run = local_path_name(None, model, diff, ds)
+    assert sorted(os.listdir(os.path.join(exp, run, "checkpoint"))) == ["0.pkl", "2.pkl"]
+    assert os.path.exists(os.path.join(exp, run, "waveforms", "2", "0k_0.wav"))
+    log = [json.loads(l) for l in open(os.path.join(exp, run, "train_log.jsonl"))]
+    assert all(np.isfinite(r["train/loss"]) for r in log if "train/loss" in r)
