@@ -125,6 +125,13 @@ int dws_model_set_param(dws_model* m, const char* name, const void* data, const 
                         void* stream) {
     DWS_CHECK(m && name && data && shape, DWS_ERR_INVALID, "dws_model_set_param: null argument");
     auto it = m->index.find(name);
+    if (it == m->index.end() && name[0] == '_' && name[1] == '_') {
+        // host-computed tables ("__omega.<L>", "__z.<L>": FFT nodes of an S4 kernel length the model was not
+        // configured with, e.g. a checkpoint trained at another l_max) are registered on first sight
+        dws::ParamSpec* np_ = m->add_param(name, std::vector<int64_t>(shape, shape + ndim), dtype);
+        DWS_TRY(np_->buf.ensure(np_->nbytes()));
+        it = m->index.find(name);
+    }
     DWS_CHECK(it != m->index.end(), DWS_ERR_INVALID, "unexpected key '%s' in state_dict", name);
     dws::ParamSpec* p = m->params[it->second];
     DWS_CHECK(dtype == p->dtype, DWS_ERR_INVALID, "'%s': dtype %d, expected %d", name, dtype, p->dtype);

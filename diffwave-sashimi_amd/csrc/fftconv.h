@@ -37,7 +37,7 @@ int launch_fftcorr(int log2m, const FftCorrArgs& a, hipStream_t s);
 bool fftconv_supported(int L, int* log2m);
 int launch_fftconv(int log2m, const FftConvArgs& a, hipStream_t s);
 int launch_rfft_rows(int log2m, const float* in, float* out, const float* tw, const float* twn, int H, hipStream_t s);
-int launch_s4_twosided_pow2(const float* k, float* K, int H, int L, int Nf, hipStream_t s);
+int launch_s4_twosided_pow2(const float* k, float* K, int H, int Lt, int Nf, int Lk, hipStream_t s);
 int launch_kf_permute(const float* kf, float* kfa, float* kfb, float* kfs, int H, int log2m, hipStream_t s);
 void build_fft_tables(int log2m, std::vector<float>& tw, std::vector<float>& twn, std::vector<float>& twp);
 

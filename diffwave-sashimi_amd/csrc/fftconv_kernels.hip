@@ -398,14 +398,16 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* __restr
 
 // Two-sided kernel re-placed for transform size Nf >= 2L (s4.py:1391-1394 generalised):
 //   K[j] = k0[j]/L (j < L);  K[Nf - m] = k1[m-1]/L (m = 1..L);  0 elsewhere.
-__global__ void s4_twosided_pow2_kernel(const float* __restrict__ k, float* __restrict__ K, int H, int L, int Nf) {
+// k rows have length Lk (the kernel's own length); the first Lt = min(run length, Lk) taps of each direction are used
+// (`L_kernel`, s4.py:1387,805); 1/Lk is the irfft normalisation the unnormalised C2R left out.
+__global__ void s4_twosided_pow2_kernel(const float* __restrict__ k, float* __restrict__ K, int H, int Lt, int Nf, int Lk) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (j >= Nf) return;
-    const float inv = 1.f / (float)L;
+    const float inv = 1.f / (float)Lk;
     float v = 0.f;
-    if (j < L) v = k[(size_t)h * L + j] * inv;
-    else if (j >= Nf - L) v = k[((size_t)H + h) * L + (Nf - j - 1)] * inv;
+    if (j < Lt) v = k[(size_t)h * Lk + j] * inv;
+    else if (j >= Nf - Lt) v = k[((size_t)H + h) * Lk + (Nf - j - 1)] * inv;
     K[(size_t)h * Nf + j] = v;
 }
 
@@ -509,8 +511,8 @@ int launch_rfft_rows(int log2m, const float* in, float* out, const float* tw, co
     DWS_FC_DISPATCH(launch_rf, in, out, tw, twn, H, s);
 }
 
-int launch_s4_twosided_pow2(const float* k, float* K, int H, int L, int Nf, hipStream_t s) {
-    hipLaunchKernelGGL(s4_twosided_pow2_kernel, dim3(ceil_div(Nf, 256), H), dim3(256), 0, s, k, K, H, L, Nf);
+int launch_s4_twosided_pow2(const float* k, float* K, int H, int Lt, int Nf, int Lk, hipStream_t s) {
+    hipLaunchKernelGGL(s4_twosided_pow2_kernel, dim3(ceil_div(Nf, 256), H), dim3(256), 0, s, k, K, H, Lt, Nf, Lk);
     return DWS_OK;
 }
 

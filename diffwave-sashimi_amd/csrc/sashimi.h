@@ -7,7 +7,7 @@ int launch_s4_prep(const float* C, const float* Bp, const float* P, const float*
                    const float* log_dt, float* v, float* wdt, float* dt, int H, int N, hipStream_t s);
 int launch_s4_woodbury(const float* r, const float* omega, const float* dt, float* kf, int H, int Lh, int n_even,
                        hipStream_t s);
-int launch_s4_twosided(const float* k, float* K, int H, int L, hipStream_t s);
+int launch_s4_twosided(const float* k, float* K, int H, int L, int Lk, int Lt, hipStream_t s);
 int launch_ln(const float* x, const float* m_p, const float* s_p, const float* part_t, int pt_bstride, float* out,
               int B, int H, int L, size_t ostride, hipStream_t s);
 int launch_spec_mul(float* uf, const float* kf, int B, int H, int Lf, hipStream_t s);

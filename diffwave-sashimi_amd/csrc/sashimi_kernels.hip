@@ -92,17 +92,19 @@ int launch_s4_woodbury(const float* r, const float* omega, const float* dt, floa
 
 // Two-sided kernel (s4.py:1391-1394): K[h][j] = k0[h][j]/L for j < L; K[h][L+i] = k1[h][L-1-i]/L.
 // (1/L is the irfft normalisation rocFFT's unnormalised C2R leaves out.)
-__global__ void s4_twosided_kernel(const float* __restrict__ k, float* __restrict__ K, int H, int L) {
+__global__ void s4_twosided_kernel(const float* __restrict__ k, float* __restrict__ K, int H, int L, int Lk, int Lt) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (j >= 2 * L) return;
-    const float inv = 1.f / (float)L;
-    const float v = (j < L) ? k[(size_t)h * L + j] : k[((size_t)H + h) * L + (2 * L - 1 - j)];
+    const float inv = 1.f / (float)Lk;   // k rows have length Lk; Lt = min(L, Lk) taps per direction (s4.py:1387)
+    float v = 0.f;
+    if (j < Lt) v = k[(size_t)h * Lk + j];
+    else if (j >= 2 * L - Lt) v = k[((size_t)H + h) * Lk + (2 * L - 1 - j)];
     K[(size_t)h * 2 * L + j] = v * inv;
 }
 
-int launch_s4_twosided(const float* k, float* K, int H, int L, hipStream_t s) {
-    hipLaunchKernelGGL(s4_twosided_kernel, dim3(ceil_div(2 * L, 256), H), dim3(256), 0, s, k, K, H, L);
+int launch_s4_twosided(const float* k, float* K, int H, int L, int Lk, int Lt, hipStream_t s) {
+    hipLaunchKernelGGL(s4_twosided_kernel, dim3(ceil_div(2 * L, 256), H), dim3(256), 0, s, k, K, H, L, Lk, Lt);
     return DWS_OK;
 }
 

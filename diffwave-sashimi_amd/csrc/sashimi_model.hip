@@ -57,7 +57,9 @@ struct FftPlans {
 enum { L_BLOCK = 0, L_DOWN = 1, L_UP = 2 };
 
 struct SLayer {
-    int kind, H, L, p = 1, Hout = 0, Lout = 0;
+    int kind, H, L, p = 1, Hout = 0, Lout = 0;   // L / Lout: lengths of the CURRENT run (prepare rescales them)
+    int L0 = 0, Lout0 = 0;                       // as configured (model L)
+    int Lk = 0;                                  // S4 kernel length = the block's `L` buffer (>= L)
     std::string prefix;
     int pt_off = 0;       // offset of this block's fc_t rows in the stacked projection
     int stage = 0;        // index into per-(H,L) workspaces
@@ -80,7 +82,7 @@ struct Exec {             // one step of Sashimi.forward: out_node = layer(in_no
 };
 
 struct Stage {
-    int H, L;
+    int H, L, L0 = 0;
     bool rocfft = false;  // some block of this stage needs the rocFFT path
     DevBuf U, Uf, Y, g, x1, n2, ffu, y;
     DevBuf d2, dh, dx1, du;  // training path gradients: [B][max(2,FF) H][L], [B][H][L] x 3
@@ -240,6 +242,8 @@ struct SashimiModel : dws_model {
             H /= E; L *= p;
             for (int i = 0; i < NL; ++i) u_layers.push_back(mk_block("u_layers." + std::to_string(idx++), H, L));
         }
+        for (auto* l : all) { l->L0 = l->L; l->Lout0 = l->Lout; }
+        for (auto* st : stages) st->L0 = st->L;
         add_param("norm.m", {1});
         add_param("norm.s", {1});
         wn("final_conv.0.conv", {D, D, 1});
@@ -253,27 +257,33 @@ struct SashimiModel : dws_model {
 
     // S4 convolution kernel of one block: parameters -> K_f   (s4.py:704-807, 1391-1403)
     int build_kernel(SLayer* l, hipStream_t s) {
-        const int H = l->H, L = l->L, Lh = L / 2 + 1, N = NS;
+        const int H = l->H, L = l->L, N = NS;
         const std::string k = l->prefix + ".layer.kernel.kernel";
         int64_t Lbuf = 0;
         DWS_HIP(hipMemcpyAsync(&Lbuf, P(k + ".L"), 8, hipMemcpyDeviceToHost, s));
         DWS_HIP(hipStreamSynchronize(s));
-        DWS_CHECK(Lbuf == L, DWS_ERR_STATE,
-                  "%s.L = %lld but the layer runs at length %d: C must have been through _setup_C(l_max) "
-                  "(s4.py:524-551) before it is handed to the engine",
-                  k.c_str(), (long long)Lbuf, L);
+        // the kernel is generated at its own length l_max; a run uses its first min(L, l_max) taps per direction
+        // (`L_kernel`, s4.py:1387,805): shorter inputs truncate it, longer inputs keep l_max taps
+        DWS_CHECK(Lbuf > 0 && Lbuf < (1 << 28), DWS_ERR_STATE,
+                  "%s.L = %lld: C must have been through _setup_C(l_max) (s4.py:524-551) before it is handed to the engine",
+                  k.c_str(), (long long)Lbuf);
+        const int Lk = (int)Lbuf, Lh = Lk / 2 + 1, Lt = std::min(L, Lk);
+        l->Lk = Lk;
+        const std::string zname = "__z." + std::to_string(Lk), oname = "__omega." + std::to_string(Lk);
+        DWS_CHECK(P(zname) && P(oname), DWS_ERR_STATE, "FFT nodes %s / %s were not handed to the engine", zname.c_str(),
+                  oname.c_str());
         DWS_TRY(cv.ensure((size_t)6 * H * N * 8));
         DWS_TRY(cwdt.ensure((size_t)H * N * 8));
         DWS_TRY(cdt.ensure((size_t)H * 4));
         DWS_TRY(cr.ensure((size_t)6 * H * Lh * 8));
         DWS_TRY(ckf.ensure((size_t)2 * H * Lh * 8));
-        DWS_TRY(ck.ensure((size_t)2 * H * L * 4));
+        DWS_TRY(ck.ensure((size_t)2 * H * Lk * 4));
         DWS_TRY(launch_s4_prep(P(k + ".C"), P(k + ".B"), P(k + ".P"), P(k + ".inv_w_real"), P(k + ".w_imag"),
                                P(k + ".log_dt"), cv.f(), cwdt.f(), cdt.f(), H, N, s));
-        DWS_TRY(launch_cauchy_sym_fwd_bcast(cv.f(), P("__z." + std::to_string(L)), cwdt.f(), cr.f(), 6 * H, N, Lh, H, s));
-        DWS_TRY(launch_s4_woodbury(cr.f(), P("__omega." + std::to_string(L)), cdt.f(), ckf.f(), H, Lh, (L % 2) == 0, s));
+        DWS_TRY(launch_cauchy_sym_fwd_bcast(cv.f(), P(zname), cwdt.f(), cr.f(), 6 * H, N, Lh, H, s));
+        DWS_TRY(launch_s4_woodbury(cr.f(), P(oname), cdt.f(), ckf.f(), H, Lh, (Lk % 2) == 0, s));
         hipfftHandle plan;
-        DWS_TRY(fft.get(1, L, 2 * H, &plan));
+        DWS_TRY(fft.get(1, Lk, 2 * H, &plan));
         DWS_FFT(hipfftSetStream(plan, s));
         DWS_FFT(hipfftExecC2R(plan, (hipfftComplex*)ckf.p, (hipfftReal*)ck.p));
         int lg = 0;
@@ -288,14 +298,14 @@ struct SashimiModel : dws_model {
             DWS_TRY(l->kfa.ensure((size_t)H * (M / 2) * 8));
             DWS_TRY(l->kfb.ensure((size_t)H * (M / 2) * 8));
             DWS_TRY(l->kfs.ensure((size_t)H * 3 * 8));
-            DWS_TRY(launch_s4_twosided_pow2(ck.f(), cK.f(), H, L, Nf, s));
+            DWS_TRY(launch_s4_twosided_pow2(ck.f(), cK.f(), H, Lt, Nf, Lk, s));
             DWS_TRY(launch_rfft_rows(lg, cK.f(), cKf.f(), t->tw.f(), t->twn.f(), H, s));
             DWS_TRY(launch_kf_permute(cKf.f(), l->kfa.f(), l->kfb.f(), l->kfs.f(), H, lg, s));
             l->log2m = lg;
         } else {
             DWS_TRY(cK.ensure((size_t)H * 2 * L * 4));
             DWS_TRY(l->Kf.ensure((size_t)H * (L + 1) * 8));
-            DWS_TRY(launch_s4_twosided(ck.f(), cK.f(), H, L, s));
+            DWS_TRY(launch_s4_twosided(ck.f(), cK.f(), H, L, Lk, Lt, s));
             DWS_TRY(fft.get(0, 2 * L, H, &plan));
             DWS_FFT(hipfftSetStream(plan, s));
             DWS_FFT(hipfftExecR2C(plan, (hipfftReal*)cK.p, (hipfftComplex*)l->Kf.p));
@@ -378,10 +388,21 @@ struct SashimiModel : dws_model {
 
     int prepare(int64_t nB, int64_t nL) override {
         DWS_CHECK(nB > 0 && nL > 0, DWS_ERR_INVALID, "prepare: B=%lld L=%lld", (long long)nB, (long long)nL);
-        DWS_CHECK(nL == d.L, DWS_ERR_UNSUPPORTED,
-                  "sashimi: input length %lld != model L=%d (variable-length generation, s4.py:1387, is not built yet)",
-                  (long long)nL, d.L);
-        if (nB != B) { drop_graph(); melBm = 0; }
+        int span = 1;
+        for (int p : pool) span *= p;
+        DWS_CHECK(nL % span == 0, DWS_ERR_INVALID, "sashimi: input length %lld is not divisible by the pooling factors (%d)",
+                  (long long)nL, span);
+        if (nB != B || nL != L) { drop_graph(); melBm = 0; }
+        if (nL != L) {
+            // variable-length run (s4.py:1387): every stage length scales with the input; the S4 kernels keep their
+            // own length (the `L` buffers) and contribute min(run, l_max) taps per direction
+            for (auto* l : all) {
+                l->L = (int)((int64_t)l->L0 * nL / d.L);
+                l->Lout = (int)((int64_t)l->Lout0 * nL / d.L);
+            }
+            for (auto* st : stages) { st->L = (int)((int64_t)st->L0 * nL / d.L); st->rocfft = false; }
+            dirty = true;   // K_f depends on the run length (two-sided assembly, transform size)
+        }
         B = nB; L = nL;
         for (auto* st : stages) {
             const size_t rows = (size_t)B * st->H, Ls = st->L;
@@ -680,6 +701,8 @@ struct SashimiModel : dws_model {
             if (l->kind == L_BLOCK) {
                 DWS_CHECK(l->log2m > 0, DWS_ERR_UNSUPPORTED,
                           "sashimi training needs the fused FFT convolution (L even, <= 16384 per stage); stage L=%d", l->L);
+                DWS_CHECK(l->Lk == l->L, DWS_ERR_UNSUPPORTED,
+                          "sashimi training runs at the kernels' own length (stage runs at %d, kernel length %d)", l->L, l->Lk);
                 DWS_CHECK(l->H % 32 == 0, DWS_ERR_UNSUPPORTED, "sashimi training needs channel counts that are multiples of 32 (H=%d)", l->H);
             }
         }
@@ -986,9 +1009,9 @@ struct SashimiModel : dws_model {
             if (dirty) DWS_TRY(commit(s));
             for (auto* l : all)
                 if (l->kind == L_BLOCK && l->prefix == t.substr(2)) {
-                    const size_t n = (size_t)2 * l->H * l->L;
-                    DWS_CHECK((size_t)capacity >= n, DWS_ERR_INVALID, "tap buffer too small");
                     DWS_TRY(build_kernel(l, s));  // regenerates the (unnormalised) time-domain kernel into scratch
+                    const size_t n = (size_t)2 * l->H * l->Lk;
+                    DWS_CHECK((size_t)capacity >= n, DWS_ERR_INVALID, "tap buffer too small");
                     DWS_HIP(hipMemcpyAsync(dst, ck.p, n * 4, hipMemcpyDeviceToDevice, s));
                     return DWS_OK;
                 }

@@ -18,7 +18,7 @@ class _EngineTrainFn(torch.autograd.Function):
     def forward(ctx, module, audio, steps, mel_spec, *params):
         lib = _lib.load()
         B, _, L = audio.shape
-        module._sync_params()
+        module._sync_params(L)
         module._prepare(B, L)
         module._set_condition(mel_spec)      # conditional models: the conditioner's parameters get gradients too
         x = audio.detach().to(torch.float32).contiguous()
@@ -88,9 +88,11 @@ class EngineModule(nn.Module):
         """(name, tensor) pairs handed to dws_model_set_param: the state_dict."""
         return self.state_dict(keep_vars=True).items()
 
-    def _sync_params(self):
+    def _sync_params(self, run_length=None):
         """Hand every changed state_dict tensor to the engine (raw: weight_g /
-        weight_v / bias ...; folding and packing happen in dws_model_commit)."""
+        weight_v / bias ...; folding and packing happen in dws_model_commit).
+        ``run_length`` is the length of the coming call (SaShiMi adapts its S4 kernels to it first)."""
+        self._run_L = run_length
         lib = _lib.load()
         h = self._ensure_handle()
         stream = _lib.current_stream()
@@ -148,7 +150,7 @@ class EngineModule(nn.Module):
                 raise RuntimeError(f"diffusion_steps must hold B={B} entries, got {tuple(diffusion_steps.shape)}")
             return _EngineTrainFn.apply(self, audio, steps, mel_spec, *self.parameters())
         with torch.no_grad():
-            self._sync_params()
+            self._sync_params(L)
             self._prepare(B, L)
             self._set_condition(mel_spec)
             x = audio.detach().to(torch.float32).contiguous()

@@ -165,27 +165,31 @@ class Sashimi(EngineModule):
     def _setup_C(self):
         """First-forward mutation of the reference (``s4.py:531-551,686-687``): a kernel
         whose ``L`` buffer is 0 gets ``C <- C (I - dA^l_max)`` in place and ``L <- l_max``,
-        so a state_dict saved afterwards stores C~ exactly like a reference checkpoint."""
+        so a state_dict saved afterwards stores C~ exactly like a reference checkpoint.
+        Other input lengths never touch the parameters: ``S4.forward`` asks the kernel for
+        ``min(L_in, l_max)`` taps (``s4.py:1387``), so the length-doubling branch is unreachable."""
         for blk in self._blocks():
             k = blk.layer.kernel.kernel
             if int(k.L) == 0:
                 Ct = s4_init.setup_C(k.C, k.P, k.inv_w_real, k.w_imag, k.log_dt, blk.L_stage)
                 k.C.copy_(Ct.to(k.C.device))
                 k.L.fill_(blk.L_stage)
-            elif int(k.L) != blk.L_stage:
-                raise NotImplementedError(
-                    f"S4 kernel was set up for length {int(k.L)} but this layer runs at {blk.L_stage} "
-                    "(length doubling, s4.py:534-551, is not built)")
 
     def _engine_state(self):
+        L_in = getattr(self, "_run_L", None) or self.L
+        span = 1
+        for p in self.pool:
+            span *= p
+        if L_in % span != 0:
+            raise RuntimeError(f"sashimi: input length {L_in} is not divisible by the pooling factors {self.pool}")
         self._setup_C()
         items = list(self.state_dict(keep_vars=True).items())
-        for Ls in sorted({blk.L_stage for blk in self._blocks()}):
-            if Ls not in self._nodes:
-                omega, z = s4_init.omega_z(Ls)
-                self._nodes[Ls] = (torch.view_as_real(omega).contiguous(), torch.view_as_real(z).contiguous())
-            items.append((f"__omega.{Ls}", self._nodes[Ls][0]))
-            items.append((f"__z.{Ls}", self._nodes[Ls][1]))
+        for Lk in sorted({int(blk.layer.kernel.kernel.L) for blk in self._blocks()}):
+            if Lk not in self._nodes:
+                omega, z = s4_init.omega_z(Lk)
+                self._nodes[Lk] = (torch.view_as_real(omega).contiguous(), torch.view_as_real(z).contiguous())
+            items.append((f"__omega.{Lk}", self._nodes[Lk][0]))
+            items.append((f"__z.{Lk}", self._nodes[Lk][1]))
         return items
 
     @classmethod

@@ -50,7 +50,7 @@ def sampling(net, size, diffusion_hyperparams, condition=None, *, x_T=None, nois
     if seed is None:
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
     with torch.no_grad():
-        net._sync_params()
+        net._sync_params(L)
         net._prepare(B, L)
         net._set_condition(condition)
         if x_T is None:

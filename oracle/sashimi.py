@@ -89,12 +89,15 @@ def ss_kernel_nplr(sd, prefix, L):
     Bp = _r2c(sd[prefix + ".B"].contiguous())
     P = _r2c(sd[prefix + ".P"].contiguous())
     inv_w_real, w_imag, log_dt = sd[prefix + ".inv_w_real"], sd[prefix + ".w_imag"], sd[prefix + ".log_dt"]
-    if int(sd[prefix + ".L"]) == 0:
+    Lk = int(sd[prefix + ".L"])          # the kernel's own length; L <= Lk is the number of taps asked for
+    if Lk == 0:
         C = setup_C(C, Bp, P, inv_w_real, w_imag, log_dt, L)
+        Lk = L
+    assert Lk >= L, "S4.forward never asks for more taps than the kernel's length (s4.py:1387)"
     dt = torch.exp(log_dt)
     Q = P.conj()
     w = -torch.exp(inv_w_real) + 1j * w_imag
-    omega, z = omega_z(L)
+    omega, z = omega_z(Lk)
     w = w * dt.unsqueeze(-1)
     Bc = torch.cat([Bp, P], dim=-3)           # (2, H, N)
     Cc = torch.cat([C, Q], dim=-3)            # (3, H, N)
@@ -105,7 +108,7 @@ def ss_kernel_nplr(sd, prefix, L):
     r = r * dt[None, None, :, None]
     k_f = r[:-1, :-1] - r[:-1, -1:] * r[-1:, :-1] / (1 + r[-1:, -1:])
     k_f = k_f * 2 / (1 + omega)
-    k = torch.fft.irfft(k_f, n=L)
+    k = torch.fft.irfft(k_f, n=Lk)[..., :L]   # generated at the kernel's length, truncated to the run (s4.py:805)
     return k[-1]                              # (2, H, L)
 
 
@@ -113,12 +116,14 @@ def s4_forward(sd, prefix, u):
     """``S4.forward`` (``s4.py:1376-1437``) as configured by ``DiffWaveBlock``
     (``sashimi.py:126``): bidirectional, channels=1, gelu, glu, transposed."""
     L = u.size(-1)
-    k = ss_kernel_nplr(sd, prefix + ".kernel.kernel", L)
+    l_max = int(sd[prefix + ".kernel.kernel.L"]) or L           # S4.L == l_max == the kernel's length after _setup_C
+    Lt = min(L, l_max)                                           # `L_kernel` (s4.py:1387): longer inputs keep l_max taps
+    k = ss_kernel_nplr(sd, prefix + ".kernel.kernel", Lt)
     k0, k1 = k[0:1], k[1:2]
-    kk = F.pad(k0, (0, L)) + F.pad(k1.flip(-1), (L, 0))           # (1, H, 2L)
-    k_f = torch.fft.rfft(kk, n=2 * L)
-    u_f = torch.fft.rfft(u, n=2 * L)
-    y = torch.fft.irfft(u_f * k_f, n=2 * L)[..., :L]
+    kk = F.pad(k0, (0, L)) + F.pad(k1.flip(-1), (L, 0))           # (1, H, Lt + L)
+    k_f = torch.fft.rfft(kk, n=Lt + L)
+    u_f = torch.fft.rfft(u, n=Lt + L)
+    y = torch.fft.irfft(u_f * k_f, n=Lt + L)[..., :L]
     y = y + u * sd[prefix + ".D"].unsqueeze(-1)                   # D: (1, H)
     y = F.gelu(y)
     y = F.conv1d(y, sd[prefix + ".output_linear.0.weight"], sd[prefix + ".output_linear.0.bias"])

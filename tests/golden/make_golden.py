@@ -238,6 +238,33 @@ def g_sashimi_cond():
     save("sashimi_cond", **out)
 
 
+def g_sashimi_varlen():
+    """Variable-length calls on ONE reference module, in sequence (`s4.py:517-522,698-702,805,1387`):
+    L (warm-up: _setup_C), L/2 (kernel truncated), 2L (double_length mutates C and L), then L again (kernel now
+    generated at 2L and truncated).  The state_dict after the doubling is recorded."""
+    cfg = cases.ss_cfg(d_model=8, n_layers=1, L=256, diffusion_step_embed_dim_mid=64)
+    ours = cases.build_ours(cfg, 211)
+    sd0 = {k: v.detach().clone() for k, v in ours.state_dict().items()}
+    net = ref_model(cfg, sd0)
+    out = {"symmetric_cauchy": np.array(1)}
+    out.update(sd_arrays(sd0, "sd0/"))
+    g = torch.Generator().manual_seed(212)
+    for i, L_in in enumerate([256, 128, 512, 256]):
+        audio = torch.randn(2, 1, L_in, generator=g)
+        steps = torch.randint(0, 200, (2, 1), generator=g).float()
+        with torch.no_grad():
+            eps = net((audio, steps))
+        out[f"call{i}/audio"], out[f"call{i}/steps"], out[f"call{i}/eps"] = audio, steps, eps
+        sd = net.state_dict()
+        out[f"call{i}/L"] = np.array([int(sd[k]) for k in sorted(sd) if k.endswith("kernel.kernel.L")])
+        if i == 2:
+            for k in sd:
+                if k.endswith("kernel.kernel.C"):
+                    out[f"after_doubling/{k}"] = sd[k].detach().clone()
+        print("varlen call", i, L_in, "eps absmax", float(eps.abs().max()), "L buffers", out[f"call{i}/L"])
+    save("sashimi_varlen", **out)
+
+
 def g_s4_parts():
     """Function-level vectors: TransposedLN, DownPool/UpPool index maps, FF, setup_C."""
     models, _, _, s4 = _refimport.load()
@@ -304,7 +331,7 @@ def g_mel():
     save("mel", **out)
 
 
-GROUPS = {"mel": g_mel, "sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
+GROUPS = {"mel": g_mel, "sashimi_varlen": g_sashimi_varlen, "sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
           "wavenet_cond": g_wavenet_cond, "sampler": g_sampler}
 
 if __name__ == "__main__":

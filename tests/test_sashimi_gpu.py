@@ -133,11 +133,41 @@ def test_sashimi_sampler_matches_oracle(gpu):
 def test_sashimi_errors_are_loud(gpu):
     cfg = cases.SASHIMI_CASES["ss_tiny"][0]
     net = cases.build_ours(cfg, 1).to(gpu)
-    with pytest.raises(NotImplementedError):   # variable-length input is not built
-        net((torch.zeros(1, 1, 512, device=gpu), torch.zeros(1, 1, device=gpu)))
+    with pytest.raises(RuntimeError):          # 1000 is not divisible by the pooling span 16
+        net((torch.zeros(1, 1, 1000, device=gpu), torch.zeros(1, 1, device=gpu)))
     from diffwave_sashimi_amd.models import construct_model
     with pytest.raises(ValueError):
         construct_model(dict(cfg, diffusion_step_embed_dim_out=64))
     with pytest.raises(RuntimeError):
         construct_model(dict(cfg, L=1000, pool=[3, 7])).to(gpu)((torch.zeros(1, 1, 1000, device=gpu),
                                                                  torch.zeros(1, 1, device=gpu)))
+
+
+def test_variable_length_calls_match_reference_sequence(gpu):
+    """One module, four calls in a row at L, L/2, 2L, L (`s4.py:1387`): truncated kernels for the short input, l_max
+    taps for the long one (fused LDS FFT at M = 1024 covers all three lengths here), parameters untouched."""
+    from tests.test_sashimi_oracle import VARLEN_CFG
+    g = load_golden("sashimi_varlen")
+    net = cases.build_ours(VARLEN_CFG, 1).to(gpu)
+    net.load_state_dict({k[len("sd0/"):]: torch.from_numpy(v).to(gpu) for k, v in g.items() if k.startswith("sd0/")})
+    for i, L_in in enumerate([256, 128, 512, 256]):
+        out = _run(net, gpu, torch.from_numpy(g[f"call{i}/audio"]), torch.from_numpy(g[f"call{i}/steps"]))
+        assert out.shape == (2, 1, L_in)
+        assert rel_err(out.cpu(), torch.from_numpy(g[f"call{i}/eps"])) < REL_TOL, (i, L_in)
+        Ls = [int(v) for k, v in sorted(net.state_dict().items()) if k.endswith("kernel.kernel.L")]
+        assert Ls == list(g[f"call{i}/L"])
+
+
+@pytest.mark.parametrize("L_in", [4000, 20000, 40000])
+def test_long_and_short_utterances_against_oracle(gpu, L_in):
+    """Vocoder-style lengths around l_max = 16000 on the config-4 channel counts: 4000 (kernel truncated), 20000 and
+    40000 (l_max taps; top stage beyond the fused FFT's 16384 -> rocFFT n = 2L path), vs the CPU oracle."""
+    cfg = cases.ss_cfg(d_model=32, n_layers=1, L=16000)
+    net = cases.build_ours(cfg, 77).to(gpu)
+    gen = torch.Generator().manual_seed(78)
+    audio, steps = torch.randn(1, 1, L_in, generator=gen), torch.tensor([[37.0]])
+    out = _run(net, gpu, audio, steps)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = osa.sashimi_forward(sd, cfg, audio, steps)
+    assert rel_err(out.cpu(), ref) < REL_TOL

@@ -160,3 +160,25 @@ def test_shim_setup_C_mutates_like_the_reference():
             assert rel_err(sd[k], v) < 1e-4
     ours._setup_C()  # idempotent
     assert torch.equal(ours.state_dict()["d_layers.0.layer.kernel.kernel.C"], sd["d_layers.0.layer.kernel.kernel.C"])
+
+
+VARLEN_CFG = cases.ss_cfg(d_model=8, n_layers=1, L=256, diffusion_step_embed_dim_mid=64)
+
+
+def test_variable_length_calls_match_reference_sequence():
+    """`s4.py:1387`: the S4 layer asks its kernel for `min(L_in, l_max)` taps, so shorter inputs truncate the kernel
+    and longer inputs convolve with an l_max-tap kernel (transform size L_in + l_max); the parameters and the `L`
+    buffers are never touched again after the first forward (the golden run confirms: no length doubling)."""
+    g = load_golden("sashimi_varlen")
+    sd = {k[len("sd0/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd0/")}
+    from diffwave_sashimi_amd.models import construct_model
+    net = construct_model(dict(VARLEN_CFG))
+    net.load_state_dict(sd)
+    net._setup_C()                                     # what the first forward does
+    sd1 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for i, L_in in enumerate([256, 128, 512, 256]):
+        audio, steps = torch.from_numpy(g[f"call{i}/audio"]), torch.from_numpy(g[f"call{i}/steps"])
+        assert audio.shape[-1] == L_in
+        assert list(g[f"call{i}/L"]) == [16, 256, 64, 64, 256]          # reference L buffers: constant
+        eps = osa.sashimi_forward(sd1, VARLEN_CFG, audio, steps)
+        assert rel_err(eps, torch.from_numpy(g[f"call{i}/eps"])) < 1e-4, (i, L_in)
