@@ -327,6 +327,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
+    ddist.barrier()   # rank 0's roofline leg is done: every rank leaves the process group together
     ddist.shutdown()
 
 
