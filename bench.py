@@ -145,7 +145,8 @@ def cpu_baseline(cfg, seconds_budget=25.0):
             "ms_per_step_b1": per_step * 1e3}
 
 
-def train_bench(args, cfg, world, rank, dev, ddist):
+def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
+    red_dev = red_dev or dev
     """One data-parallel training step (`train.py:118-143`): q-sample + forward_train + MSE + backward through the
     HIP engine, bucketed RCCL all-reduce of the gradients overlapped with backward, Adam.  Synthetic audio
     U(-0.3, 0.3) (SURVEY.md 8d).  Not the headline metric; reported as training audio samples/s."""
@@ -179,7 +180,7 @@ def train_bench(args, cfg, world, rank, dev, ddist):
     for _ in range(args.steps):
         loss = step()
     ddist.barrier()
-    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, red_dev)
     ms = elapsed / args.steps * 1e3
     if rank == 0:
         print(json.dumps({
@@ -213,11 +214,16 @@ def main():
     if args.batch:
         cfg["B"] = args.batch
     from diffwave_sashimi_amd import dist as ddist
-    world, rank, local_rank = ddist.init("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
-    if world == 1:
+    # DWS_BENCH_SHARE_GPU=1 (tests only): all ranks on cuda:0 with gloo, to exercise the N > 1 control flow on a
+    # one-GPU box (one device cannot host two RCCL ranks).  Real runs: one rank per GPU over RCCL.
+    share = os.environ.get("DWS_BENCH_SHARE_GPU") == "1"
+    world, rank, local_rank = ddist.init(("gloo" if share else "nccl") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if world == 1 or share:
         torch.cuda.set_device(0)
+        local_rank = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    red_dev = torch.device("cpu") if share else dev     # gloo reduces the timing scalar on the host
 
     from diffwave_sashimi_amd import _lib
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
@@ -229,7 +235,7 @@ def main():
     dcfg = cfg["diffusion"]
     T = dcfg["T"]
     if args.mode == "train":
-        return train_bench(args, cfg, world, rank, dev, ddist)
+        return train_bench(args, cfg, world, rank, dev, ddist, red_dev)
     net = build_model(cfg, dev)
     if args.precision != "f32":
         net.set_option("precision", args.precision)
@@ -262,7 +268,7 @@ def main():
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = ddist.max_over_ranks(elapsed, dev)
+    elapsed = ddist.max_over_ranks(elapsed, red_dev)
     ms_per_step = elapsed / args.steps * 1e3
     value = ddist.aggregate_throughput(B * L / T, world, ms_per_step * 1e-3)
 
