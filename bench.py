@@ -95,6 +95,26 @@ def layer_algorithmic_work(cfg):
     return B * L * (14 * C * C + 2 * C * S), B * L * 4 * (2 * C + 2 * S)
 
 
+def sashimi_tail_work(cfg):
+    """All S4-tail launches of one step: per block 12 H^2 flops and 12 H bytes per position
+    (read g and x, write out; the three GEMMs Wo, W1, W2), summed over the U-Net's blocks."""
+    m = cfg["model"]
+    H, L, B = m["d_model"], cfg["L"], cfg["B"]
+    flops = bytes_ = 0
+    n_down = []
+    for p in m["pool"]:
+        n_down.append((H, L))
+        L //= p
+        H *= m["expand"]
+    blocks = [(H, L)] * m["n_layers"]
+    for (h, l) in n_down:
+        blocks += [(h, l)] * (m["n_layers"] * (2 if m.get("unet", True) else 1))
+    for h, l in blocks:
+        flops += 12 * h * h * l * B
+        bytes_ += 12 * h * l * B
+    return flops, bytes_, len(blocks)
+
+
 def cpu_baseline(cfg, seconds_budget=25.0):
     """The oracle (reference-equivalent PyTorch-CPU graph: conv1d per layer, weight-norm
     per call, no hoisting) timed on this box's host cores at B=1; bounded sample.
@@ -312,6 +332,27 @@ def main():
             "hbm_achieved_GBs": bytes_ / (avg_ms * 1e-3) / 1e9,
             "hbm_frac": bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
         }
+    if rank == 0 and not args.no_roofline and cfg["model"]["_name_"] == "sashimi":
+        # dominant kernel family: the fused S4 tail (three GEMMs + GLU + LN + GELU per block), all stages together
+        flops, bytes_, nblocks = sashimi_tail_work(cfg)
+        _lib.check(lib.dws_profile_enable(b"s4_tail"))
+        nprof = 3
+        _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, nprof, seed, 0, stream))
+        torch.cuda.synchronize()
+        n_launch, tot_ms = ctypes.c_int64(), ctypes.c_double()
+        _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
+        lib.dws_profile_disable()
+        if n_launch.value == nprof * nblocks:
+            step_ms = tot_ms.value / nprof
+            ach = flops / (step_ms * 1e-3) / 1e12
+            result["roofline"] = {
+                "kernel": "s4_tail_mfma_kernel<H,...> (all %d block launches of a step)" % nblocks, "bound": "mfma",
+                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None, "ms_per_step_in_kernel": step_ms, "launches_timed": n_launch.value,
+                "algorithmic_flops_per_step": flops, "algorithmic_bytes_per_step": bytes_,
+                "hbm_achieved_GBs": bytes_ / (step_ms * 1e-3) / 1e9,
+                "note": "fp32 MFMA and VALU do not co-issue on gfx950 (DESIGN.md 6): the GELU/GLU/LN VALU work of the "
+                        "tail adds to the MFMA time"}
     if (rank == 0 and world == 1 and args.precision == "f32" and cfg["model"]["_name_"] == "wavenet"
             and not args.no_roofline):
         # Additional, clearly separate measurement (NOT `value`): the opt-in bf16x3 matrix arithmetic
