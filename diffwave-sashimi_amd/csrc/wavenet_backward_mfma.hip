@@ -348,13 +348,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     if (do_bias && tid < 128 && o0 + tid < a.O) a.bias_part[(size_t)split * a.O + o0 + tid] = bsum;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, size_t n, int nsplit,
-                                    float scale) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + i];
-    dW[i] = s * scale;
+// out[i] = scale * sum_k partial[k][i], fixed order.  Four elements per thread (float4) and the k loop unrolled by
+// four keeps 16 independent loads in flight per thread: the first version (one dependent load chain per thread)
+// ran at 0.75 TB/s.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
+                                                           size_t n, int nsplit, float scale) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 4 <= n && (n & 3) == 0) {
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(partial + (size_t)k * n + i4);
+            const float4 b = *reinterpret_cast<const float4*>(partial + (size_t)(k + 1) * n + i4);
+            const float4 c = *reinterpret_cast<const float4*>(partial + (size_t)(k + 2) * n + i4);
+            const float4 d = *reinterpret_cast<const float4*>(partial + (size_t)(k + 3) * n + i4);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+            s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+        }
+        for (; k < nsplit; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(partial + (size_t)k * n + i4);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+        float4 r;
+        r.x = ((s0.x + s1.x) + (s2.x + s3.x)) * scale;
+        r.y = ((s0.y + s1.y) + (s2.y + s3.y)) * scale;
+        r.z = ((s0.z + s1.z) + (s2.z + s3.z)) * scale;
+        r.w = ((s0.w + s1.w) + (s2.w + s3.w)) * scale;
+        *reinterpret_cast<float4*>(dW + i4) = r;
+    } else {
+        for (size_t i = i4; i < n && i < i4 + 4; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + i];
+            dW[i] = s * scale;
+        }
+    }
 }
 
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
@@ -373,9 +403,9 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
     if (T == 3) hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, s, a);
     const size_t n = (size_t)a.O * a.C * T;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, a.partial, dW, n, a.nsplit, scale);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, s, a.partial, dW, n, a.nsplit, scale);
     if (a.bias_part)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(a.O, 256)), dim3(256), 0, s, a.bias_part, a.dbias,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(a.O, 1024)), dim3(256), 0, s, a.bias_part, a.dbias,
                            (size_t)a.O, a.nsplit, a.bias_scale);
     return DWS_OK;
 }
