@@ -6,6 +6,7 @@
 // Forward of one residual layer (`models/wavenet.py:82-121`), with folded weights:
 //   h = x + pt[b,:,None] (zero padded);  H = Wd (*) h + b1;  g = tanh(H[:C]) * sigmoid(H[C:])
 //   res = Wr g + br;  skip = Ws g + bs;  x' = (x + res) * sqrt(.5);  skip_sum += skip
+#include "model.h"
 #include "wavenet_backward.h"
 
 namespace dws {
@@ -263,23 +264,45 @@ int launch_lin_bwd_w(const float* dy, const float* x, float* dW, float* db, int 
     return DWS_OK;
 }
 
-// dx[b,k] = sum_o W[o,k] dy[b,o], then optionally through swish: dx *= swish'(pre[b,k])
-__global__ void lin_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W, const float* __restrict__ pre,
-                                 float* __restrict__ dx, int K, int O) {
-    const int b = blockIdx.y;
+// dx[b,k] = sum_o W[o,k] dy[b,o], then optionally through swish: dx *= swish'(pre[b,k]).
+// O (up to n_layers * C = 9216 stacked fc_t rows) is split over grid.z; partial sums are added in a fixed order.
+__global__ void lin_bwd_x_partial_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ part,
+                                         int K, int O, int ochunk) {
+    const int b = blockIdx.y, z = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
+    const int o0 = z * ochunk, o1 = min(O, o0 + ochunk);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int o = o0;
+    for (; o + 4 <= o1; o += 4) {
+        a0 = fmaf(W[(size_t)o * K + k], dy[(size_t)b * O + o], a0);
+        a1 = fmaf(W[(size_t)(o + 1) * K + k], dy[(size_t)b * O + o + 1], a1);
+        a2 = fmaf(W[(size_t)(o + 2) * K + k], dy[(size_t)b * O + o + 2], a2);
+        a3 = fmaf(W[(size_t)(o + 3) * K + k], dy[(size_t)b * O + o + 3], a3);
+    }
+    for (; o < o1; ++o) a0 = fmaf(W[(size_t)o * K + k], dy[(size_t)b * O + o], a0);
+    part[((size_t)z * gridDim.y + b) * K + k] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ void lin_bwd_x_finish_kernel(const float* __restrict__ part, const float* __restrict__ pre, float* __restrict__ dx,
+                                        int n, int nz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
     float acc = 0.f;
-    for (int o = 0; o < O; ++o) acc = fmaf(W[(size_t)o * K + k], dy[(size_t)b * O + o], acc);
+    for (int z = 0; z < nz; ++z) acc += part[(size_t)z * n + i];
     if (pre) {
-        const float a = pre[(size_t)b * K + k], sg = sigm(a);
+        const float a = pre[i], sg = sigm(a);
         acc *= sg * (1.f + a * (1.f - sg));   // d/da [a sigmoid(a)]
     }
-    dx[(size_t)b * K + k] = acc;
+    dx[i] = acc;
 }
 
 int launch_lin_bwd_x(const float* dy, const float* W, const float* pre, float* dx, int B, int K, int O, hipStream_t s) {
-    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3(ceil_div(K, 128), B), dim3(128), 0, s, dy, W, pre, dx, K, O);
+    static DevBuf part;   // [nz][B][K] scratch, one per process (calls are stream-ordered)
+    const int ochunk = 128, nz = ceil_div(O, ochunk);
+    DWS_TRY(part.ensure((size_t)nz * B * K * 4));
+    hipLaunchKernelGGL(lin_bwd_x_partial_kernel, dim3(ceil_div(K, 128), B, nz), dim3(128), 0, s, dy, W, part.f(), K, O, ochunk);
+    hipLaunchKernelGGL(lin_bwd_x_finish_kernel, dim3(ceil_div(B * K, 256)), dim3(256), 0, s, part.f(), pre, dx, B * K, nz);
     return DWS_OK;
 }
 

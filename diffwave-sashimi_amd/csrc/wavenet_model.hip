@@ -370,8 +370,7 @@ struct WaveNetModel : dws_model {
         const float scale = (float)std::sqrt(1.0 / NL);
 
         // ---- final_conv: out = Wz y + bz, y = relu(Wf (skip * scale) + bf)
-        DWS_TRY(launch_wgrad(dout, ty.f(), nullptr, 0, G("final_conv.2.conv.weight"), nB, Cout, S, nL, 1, 1, 1.f, s));
-        DWS_TRY(launch_rowsum(dout, G("final_conv.2.conv.bias"), nB, Cout, nL, 1.f, 0, s));
+        DWS_TRY(wgrad(dout, ty.f(), nullptr, 0, G("final_conv.2.conv.weight"), Cout, S, 1, 1, 1.f, s, G("final_conv.2.conv.bias")));
         DWS_TRY(launch_final_dy(dout, P("final_conv.2.conv.weight"), ty.f(), dyb.f(), nB, S, Cout, nL, s));
         DWS_TRY(wgrad(dyb.f(), skip.f(), nullptr, 0, dWfold.f(), S, S, 1, 1, scale, s, G("final_conv.0.conv.bias")));
         DWS_TRY(wn_bwd("final_conv.0.conv", dWfold.f(), S, S, s));
@@ -455,9 +454,8 @@ struct WaveNetModel : dws_model {
         }
         // ---- init_conv: x0 = relu(Wi audio + bi)
         DWS_TRY(launch_relu_bwd(dx_out, tx[0].f(), nact, s));
-        DWS_TRY(launch_wgrad(dx_out, train_audio, nullptr, 0, dWfold.f(), nB, C, Cin, nL, 1, 1, 1.f, s));
+        DWS_TRY(wgrad(dx_out, train_audio, nullptr, 0, dWfold.f(), C, Cin, 1, 1, 1.f, s, G("init_conv.0.conv.bias")));
         DWS_TRY(wn_bwd("init_conv.0.conv", dWfold.f(), C, Cin, s));
-        DWS_TRY(launch_rowsum(dx_out, G("init_conv.0.conv.bias"), nB, C, nL, 1.f, 0, s));
 
         // ---- step embedding: per-layer fc_t (stacked), then the shared swish MLP
         DWS_TRY(launch_lin_bwd_w(dpt.f(), h2.f(), dWt_all.f(), dbt_all.f(), nB, Eout, NL * C, s));
