@@ -168,7 +168,7 @@ def cpu_baseline(cfg, seconds_budget=25.0):
 def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
     red_dev = red_dev or dev
     """One data-parallel training step (`train.py:118-143`): q-sample + forward_train + MSE + backward through the
-    HIP engine, bucketed RCCL all-reduce of the gradients overlapped with backward, Adam.  Synthetic audio
+    HIP engine, bucketed asynchronous RCCL all-reduce of the gradients, Adam.  Synthetic audio
     U(-0.3, 0.3) (SURVEY.md 8d).  Not the headline metric; reported as training audio samples/s."""
     import torch.nn as nn
     from diffwave_sashimi_amd.distributed_util import apply_gradient_allreduce
@@ -209,7 +209,7 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic U(-0.3,0.3) audio",
             "config": {"workload": args.config + " training", "batch_per_gpu": B, "L": L,
-                       "parallelism": "dp%d, bucketed RCCL all-reduce overlapped with backward" % world},
+                       "parallelism": "dp%d, bucketed asynchronous RCCL all-reduce of the gradients" % world},
             "final_loss": float(loss)}))
     ddist.shutdown()
 

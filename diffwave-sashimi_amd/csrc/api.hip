@@ -1,5 +1,6 @@
 // extern "C" surface of libdws.so for the model and sampler entry points
 // (include/dws.h); the Cauchy entry points live in cauchy_kernels.hip.
+#include <cstring>
 #include "model.h"
 
 namespace dws {
@@ -197,6 +198,53 @@ int dws_model_get_grad(dws_model* m, const char* name, float* dst, int64_t numel
     float* g = m->G(name);
     DWS_CHECK(g, DWS_ERR_HIP, "could not allocate the gradient of '%s'", name);
     DWS_HIP(hipMemcpyAsync(dst, g, p->nbytes(), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DWS_OK;
+}
+
+namespace dws {
+struct CopyJob { const float* src; float* dst; int64_t n; };
+// one launch for all parameter gradients: block (j, part) copies a slice of tensor j
+__global__ void multi_copy_kernel(const CopyJob* __restrict__ jobs, int parts) {
+    const CopyJob j = jobs[blockIdx.x];
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < j.n; i += (int64_t)parts * blockDim.x) j.dst[i] = j.src[i];
+}
+}  // namespace dws
+
+int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, float* const* dsts, const int64_t* numels,
+                        void* stream) {
+    DWS_CHECK(m && names && dsts && numels && count >= 0, DWS_ERR_INVALID, "dws_model_get_grads: null argument");
+    if (count == 0) return DWS_OK;
+    std::vector<dws::CopyJob> jobs((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        auto it = m->index.find(names[i]);
+        DWS_CHECK(it != m->index.end(), DWS_ERR_INVALID, "unknown parameter '%s'", names[i]);
+        dws::ParamSpec* p = m->params[it->second];
+        DWS_CHECK(p->dtype == 0 && (int64_t)p->numel() == numels[i], DWS_ERR_INVALID, "'%s': grad has %zu elements, got %lld",
+                  names[i], p->numel(), (long long)numels[i]);
+        float* g = m->G(names[i]);
+        DWS_CHECK(g && dsts[i], DWS_ERR_HIP, "could not allocate the gradient of '%s'", names[i]);
+        jobs[i] = {g, dsts[i], numels[i]};
+    }
+    // the job table travels through a pinned staging buffer so nothing here blocks the host; an event guards its reuse
+    static dws::DevBuf table;
+    static dws::CopyJob* pinned = nullptr;
+    static size_t pinned_cap = 0;
+    static hipEvent_t consumed = nullptr;
+    if (!consumed) DWS_HIP(hipEventCreateWithFlags(&consumed, hipEventDisableTiming));
+    else DWS_HIP(hipEventSynchronize(consumed));
+    if (pinned_cap < jobs.size()) {
+        if (pinned) hipHostFree(pinned);
+        pinned_cap = jobs.size() * 2;
+        DWS_HIP(hipHostMalloc((void**)&pinned, pinned_cap * sizeof(dws::CopyJob), hipHostMallocDefault));
+    }
+    std::memcpy(pinned, jobs.data(), jobs.size() * sizeof(dws::CopyJob));
+    DWS_TRY(table.ensure(jobs.size() * sizeof(dws::CopyJob)));
+    DWS_HIP(hipMemcpyAsync(table.p, pinned, jobs.size() * sizeof(dws::CopyJob), hipMemcpyHostToDevice, (hipStream_t)stream));
+    DWS_HIP(hipEventRecord(consumed, (hipStream_t)stream));
+    const int parts = 8;
+    hipLaunchKernelGGL(dws::multi_copy_kernel, dim3((unsigned)count, parts), dim3(256), 0, (hipStream_t)stream,
+                       (const dws::CopyJob*)table.p, parts);
+    DWS_HIP(hipGetLastError());
     return DWS_OK;
 }
 

@@ -35,11 +35,13 @@ class _EngineTrainFn(torch.autograd.Function):
         m = ctx.module
         d = dout.detach().to(torch.float32).contiguous()
         _lib.check(lib.dws_model_backward(m._handle, d.data_ptr(), _lib.current_stream()))
-        grads = []
-        for name, shape, dtype in ctx.meta:
-            g = torch.empty(shape, device=d.device, dtype=torch.float32)
-            _lib.check(lib.dws_model_get_grad(m._handle, name.encode(), g.data_ptr(), g.numel(), _lib.current_stream()))
-            grads.append(g.to(dtype))
+        n = len(ctx.meta)
+        outs = [torch.empty(shape, device=d.device, dtype=torch.float32) for _, shape, _ in ctx.meta]
+        names = (ctypes.c_char_p * n)(*[name.encode() for name, _, _ in ctx.meta])
+        dsts = (ctypes.c_void_p * n)(*[g.data_ptr() for g in outs])
+        numels = (ctypes.c_int64 * n)(*[g.numel() for g in outs])
+        _lib.check(lib.dws_model_get_grads(m._handle, n, names, dsts, numels, _lib.current_stream()))   # one launch
+        grads = [g.to(dtype) for g, (_, _, dtype) in zip(outs, ctx.meta)]
         return (None, None, None, None, *grads)
 
 

@@ -155,6 +155,9 @@ int dws_model_forward(dws_model* m, const float* audio, const float* steps, floa
 int dws_model_forward_train(dws_model* m, const float* audio, const float* steps, float* out, void* stream);
 int dws_model_backward(dws_model* m, const float* dout, void* stream);
 int dws_model_get_grad(dws_model* m, const char* name, float* dst, int64_t numel, void* stream);
+/* The same for `count` parameters in one launch (the autograd wrapper fetches every gradient after backward). */
+int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, float* const* dsts, const int64_t* numels,
+                        void* stream);
 
 /* Debug/parity tap: copy an internal activation into `dst` (device pointer,
  * `capacity` floats).  WaveNet: "pre_final" = ReLU(final_conv[0](skip)) [B,S,L],
