@@ -49,6 +49,8 @@ _SIGS = {
     "dws_model_set_param": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,
                                            ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p]),
+    "dws_model_update_params": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p),
+                                               ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "dws_model_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]),
     "dws_model_commit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "dws_model_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]),

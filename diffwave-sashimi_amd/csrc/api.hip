@@ -210,6 +210,25 @@ __global__ void multi_copy_kernel(const CopyJob* __restrict__ jobs, int parts) {
 }
 }  // namespace dws
 
+static int multi_copy(std::vector<dws::CopyJob>& jobs, hipStream_t stream);
+
+int dws_model_update_params(dws_model* m, int32_t count, const char* const* names, const float* const* srcs, void* stream) {
+    DWS_CHECK(m && names && srcs && count >= 0, DWS_ERR_INVALID, "dws_model_update_params: null argument");
+    if (count == 0) return DWS_OK;
+    std::vector<dws::CopyJob> jobs((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        auto it = m->index.find(names[i]);
+        DWS_CHECK(it != m->index.end(), DWS_ERR_INVALID, "unexpected key '%s' in state_dict", names[i]);
+        dws::ParamSpec* p = m->params[it->second];
+        DWS_CHECK(p->dtype == 0 && srcs[i], DWS_ERR_INVALID, "'%s': update_params takes float32 device tensors", names[i]);
+        jobs[i] = {srcs[i], p->buf.f(), (int64_t)p->numel()};
+    }
+    DWS_TRY(multi_copy(jobs, (hipStream_t)stream));
+    m->dirty = true;
+    m->drop_graph();
+    return DWS_OK;
+}
+
 int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, float* const* dsts, const int64_t* numels,
                         void* stream) {
     DWS_CHECK(m && names && dsts && numels && count >= 0, DWS_ERR_INVALID, "dws_model_get_grads: null argument");
@@ -225,7 +244,12 @@ int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, f
         DWS_CHECK(g && dsts[i], DWS_ERR_HIP, "could not allocate the gradient of '%s'", names[i]);
         jobs[i] = {g, dsts[i], numels[i]};
     }
-    // the job table travels through a pinned staging buffer so nothing here blocks the host; an event guards its reuse
+    return multi_copy(jobs, (hipStream_t)stream);
+}
+
+// One kernel for a list of device-to-device copies.  The job table travels through a pinned staging buffer so nothing
+// blocks the host; an event guards the buffer's reuse.
+static int multi_copy(std::vector<dws::CopyJob>& jobs, hipStream_t stream) {
     static dws::DevBuf table;
     static dws::CopyJob* pinned = nullptr;
     static size_t pinned_cap = 0;
@@ -238,11 +262,11 @@ int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, f
         DWS_HIP(hipHostMalloc((void**)&pinned, pinned_cap * sizeof(dws::CopyJob), hipHostMallocDefault));
     }
     std::memcpy(pinned, jobs.data(), jobs.size() * sizeof(dws::CopyJob));
-    DWS_TRY(table.ensure(jobs.size() * sizeof(dws::CopyJob)));
-    DWS_HIP(hipMemcpyAsync(table.p, pinned, jobs.size() * sizeof(dws::CopyJob), hipMemcpyHostToDevice, (hipStream_t)stream));
-    DWS_HIP(hipEventRecord(consumed, (hipStream_t)stream));
+    DWS_TRY(table.ensure(pinned_cap * sizeof(dws::CopyJob)));
+    DWS_HIP(hipMemcpyAsync(table.p, pinned, jobs.size() * sizeof(dws::CopyJob), hipMemcpyHostToDevice, stream));
+    DWS_HIP(hipEventRecord(consumed, stream));
     const int parts = 8;
-    hipLaunchKernelGGL(dws::multi_copy_kernel, dim3((unsigned)count, parts), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(dws::multi_copy_kernel, dim3((unsigned)jobs.size(), parts), dim3(256), 0, stream,
                        (const dws::CopyJob*)table.p, parts);
     DWS_HIP(hipGetLastError());
     return DWS_OK;

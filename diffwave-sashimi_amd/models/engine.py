@@ -98,20 +98,31 @@ class EngineModule(nn.Module):
         lib = _lib.load()
         h = self._ensure_handle()
         stream = _lib.current_stream()
+        batch = []   # (name, tensor) already known to the engine with this shape, float32 on the GPU: one launch for all
         for name, t in self._engine_state():
             key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
-            if self._versions.get(name) == key:
+            old = self._versions.get(name)
+            if old == key:
                 continue
-            if t.dtype == torch.int64:
-                src, dtype = t.detach().contiguous(), 1
+            if (old is not None and old[2] == key[2] and t.dtype == torch.float32 and t.device.type == "cuda"
+                    and t.is_contiguous()):
+                batch.append((name, t))
             else:
-                src, dtype = t.detach().to(torch.float32).contiguous(), 0
-            shape = (ctypes.c_int64 * max(src.dim(), 1))(*src.shape)
-            _lib.check(lib.dws_model_set_param(h, name.encode(), src.data_ptr(), shape, src.dim(), dtype, stream))
-            if src.device.type != "cuda":
-                torch.cuda.synchronize()
+                if t.dtype == torch.int64:
+                    src, dtype = t.detach().contiguous(), 1
+                else:
+                    src, dtype = t.detach().to(torch.float32).contiguous(), 0
+                shape = (ctypes.c_int64 * max(src.dim(), 1))(*src.shape)
+                _lib.check(lib.dws_model_set_param(h, name.encode(), src.data_ptr(), shape, src.dim(), dtype, stream))
+                if src.device.type != "cuda":
+                    torch.cuda.synchronize()
             self._versions[name] = key
             self._mel_key = None  # conditioner terms depend on the weights
+        if batch:
+            n = len(batch)
+            names = (ctypes.c_char_p * n)(*[k.encode() for k, _ in batch])
+            srcs = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t in batch])
+            _lib.check(lib.dws_model_update_params(h, n, names, srcs, stream))
 
     def _prepare(self, B, L):
         if self._shape != (B, L):

@@ -121,6 +121,10 @@ int dws_model_param_info(const dws_model* m, int index, const char** name,
 int dws_model_set_param(dws_model* m, const char* name, const void* data,
                         const int64_t* shape, int ndim, int dtype, void* stream);
 
+/* Refresh `count` float32 parameters that were set before from device tensors of the same shape, in one launch
+ * (a training loop re-sends every parameter after each optimizer step).  Marks the model dirty like set_param. */
+int dws_model_update_params(dws_model* m, int32_t count, const char* const* names, const float* const* srcs, void* stream);
+
 /* String options (unknown key/value -> DWS_ERR_INVALID):
  *   "precision" = "f32"    (default) exact-f32 MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain
  *               = "bf16x3" WaveNet residual layers on the bf16 matrix cores with a 3-term hi/lo split
