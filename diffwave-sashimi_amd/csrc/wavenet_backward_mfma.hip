@@ -14,6 +14,8 @@
 //     dW[o, c, t] = sum_{b, l} dY[b, o, l] * Xh[b, c, l + (t - T/2) * dil],   Xh = X (+ addc[b, c]) in range
 //   128 x 128 output tile per block and tap, the (b, l) range split over blocks; partial tiles go to a
 //   scratch buffer and are summed in a fixed order by wgrad_reduce_kernel (deterministic, no atomics).
+#include <cstdlib>
+
 #include "wavenet_backward.h"
 
 namespace dws {
@@ -247,7 +249,7 @@ int launch_tapconv_pack_transposed(const float* W, float* out, int O, int C, int
 // first c-tile and tap also accumulate sum_pos dY[o] (the conv's bias gradient) from the staged tile.
 template <int T>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
-    constexpr int PC = 64, LD = PC + 1;   // +1: lanes walk channels, so rows must not share a bank
+    constexpr int PC = 64, LD = PC + 2;   // +2: lanes walk channels (stride LD) and the two half-waves read adjacent positions: 66 = 2 mod 64 puts all 64 lanes on distinct banks (65 left a 2-way conflict between the halves)
     constexpr int RPW = 32;               // rows of each operand a wave stages per chunk
     __shared__ float sdy[128 * LD];
     __shared__ float sx[128 * LD];
@@ -278,32 +280,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     const int xL = a.xL ? a.xL : L;   // X rows may be longer than L (the conditioner's un-truncated upsampled mel)
     __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)((size_t)a.B * a.C * xL * 4), 0x00020000);
     float rdy[RPW], rx[RPW];
-    float mdy = 0.f, mx = 0.f;   // range masks of this lane's position in the fetched chunk
-    int fb = 0;                  // batch index of the fetched chunk
+    float mx = 0.f;              // 1 where this lane's (shifted) position of the fetched chunk is in range
+    int fb = 0, sad_b = -1;      // batch index of the fetched chunk / of the addc row staged in LDS
+    __shared__ float sad[128];
+    constexpr int OOB = 0x7ffffff0;   // lane offset past the descriptor: the load returns 0 (no mask multiply later)
     auto fetch = [&](int ch) {
         const int b = ch / chunks_per_b, l0 = (ch % chunks_per_b) * PC;
         const int pos = l0 + lane, ps = pos + shift;
         const bool pin = pos < L, sin = (unsigned)ps < (unsigned)L && pin;
-        mdy = pin ? 1.f : 0.f;
         mx = sin ? 1.f : 0.f;
         fb = b;
-        const int vy = (pin ? pos : 0) * 4, vx = (((unsigned)ps < (unsigned)L) ? ps : 0) * 4;
+        const int vy = pin ? pos * 4 : OOB, vx = sin ? ps * 4 : OOB;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int row = wave + 4 * i;
+            // rows past O / C are clamped, not masked: they only feed output elements that are never stored
             const int o = min(o0 + row, a.O - 1), c = min(c0 + row, a.C - 1);
             rdy[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, vy, (b * a.O + o) * L * 4, 0));
             rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, vx, (b * a.C + c) * xL * 4, 0));
         }
     };
     auto commit = [&]() {
+        if (a.addc && sad_b != fb) {   // block-uniform: the per-(b, c) constants of this batch element -> LDS
+            if (tid < 128) sad[tid] = a.addc[(size_t)fb * a.addc_bstride + min(c0 + tid, a.C - 1)];
+            sad_b = fb;
+            __syncthreads();
+        }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int row = wave + 4 * i;
-            const float rm = (o0 + row < a.O) ? mdy : 0.f, cm = (c0 + row < a.C) ? mx : 0.f;
-            const float ad = a.addc ? a.addc[(size_t)fb * a.addc_bstride + min(c0 + row, a.C - 1)] : 0.f;
-            sdy[row * LD + lane] = rdy[i] * rm;
-            sx[row * LD + lane] = ((a.xact ? gelu_b(rx[i]) : rx[i]) + ad) * cm;
+            sdy[row * LD + lane] = rdy[i];
+            float xv = a.xact ? gelu_b(rx[i]) : rx[i];       // gelu(0) = 0: masked lanes stay 0
+            if (a.addc) xv = fmaf(sad[row], mx, xv);
+            sx[row * LD + lane] = xv;
         }
     };
 
