@@ -357,6 +357,85 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     if (do_bias && tid < 128 && o0 + tid < a.O) a.bias_part[(size_t)split * a.O + o0 + tid] = bsum;
 }
 
+// The same weight-gradient GEMM with NO register staging: both operand tiles of a chunk go global -> LDS by LDS-DMA
+// (out-of-range positions zero-filled by the descriptor), double-buffered, so chunk i+1 lands while chunk i's MFMAs
+// run and there is no commit phase (the ablation of wgrad_mfma_kernel showed that phase and its barriers cost ~25 %).
+// For the plain case only: single tap, X used as stored (no activation, no per-(b,c) constant).  512 threads:
+// 8 waves = 2 (o) x 4 (c), a wave owns a 64 x 32 sub-tile; 135 KB of LDS -> one workgroup per CU.
+__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
+    constexpr int PC = 64, LD = PC + 2, TILE = 128 * LD;
+    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [2 buffers][dY tile | X tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wo = wave & 1, wc = wave >> 1;
+    const int o0 = blockIdx.x * 128, c0 = blockIdx.y * 128, split = blockIdx.z;
+    const int L = a.L, xL = a.xL ? a.xL : L;
+    const int chunks_per_b = (L + PC - 1) / PC;
+    const int total_chunks = a.B * chunks_per_b;
+    const int per = (total_chunks + a.nsplit - 1) / a.nsplit;
+    const int ch_begin = split * per, ch_end = min(total_chunks, ch_begin + per);
+    const bool do_bias = a.bias_part != nullptr && blockIdx.y == 0;
+    constexpr int OOB = 0x7ffffff0;
+    __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)((size_t)a.B * a.O * L * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)((size_t)a.B * a.C * xL * 4), 0x00020000);
+
+    auto stage = [&](int ch, int buf) {
+        const int b = ch / chunks_per_b, l0 = (ch % chunks_per_b) * PC;
+        const int pos = l0 + lane;
+        const int voff = pos < L ? pos * 4 : OOB;
+        float* sdy = wlds + buf * 2 * TILE;
+        float* sx = sdy + TILE;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {           // 8 waves x 16 rows of each operand
+            const int row = wave + 8 * i;
+            const int o = min(o0 + row, a.O - 1), c = min(c0 + row, a.C - 1);   // rows past O / C feed unstored outputs only
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, sdy + row * LD, 4, voff, (b * a.O + o) * L * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, sx + row * LD, 4, voff, (b * a.C + c) * xL * 4, 0, 0);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float bsum = 0.f;
+
+    if (ch_begin < ch_end) stage(ch_begin, 0);
+    __syncthreads();
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int buf = (ch - ch_begin) & 1;
+        if (ch + 1 < ch_end) stage(ch + 1, buf ^ 1);
+        const float* sdy = wlds + buf * 2 * TILE;
+        const float* sx = sdy + TILE;
+        if (do_bias && tid < 128) {
+#pragma unroll 8
+            for (int p = 0; p < PC; ++p) bsum += sdy[tid * LD + p];
+        }
+#pragma unroll 8
+        for (int ks = 0; ks < PC / 2; ++ks) {
+            const int pp = ks * 2 + lhi;
+            const float bv = sx[(wc * 32 + l31) * LD + pp];
+            const float a0 = sdy[(wo * 64 + l31) * LD + pp], a1 = sdy[(wo * 64 + 32 + l31) * LD + pp];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+        }
+        __syncthreads();   // chunk ch+1 has landed (the barrier waits for the DMA) and buffer `buf` is free again
+    }
+    float* part = a.partial + (size_t)split * a.O * a.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wo * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int c = c0 + wc * 32 + l31;
+            if (o < a.O && c < a.C) part[(size_t)o * a.C + c] = acc[i][r];
+        }
+    if (do_bias && tid < 128 && o0 + tid < a.O) a.bias_part[(size_t)split * a.O + o0 + tid] = bsum;
+}
+
+
 // out[i] = scale * sum_k partial[k][i], fixed order.  Four elements per thread (float4) and the k loop unrolled by
 // four keeps 16 independent loads in flight per thread: the first version (one dependent load chain per thread)
 // ran at 0.75 TB/s.
@@ -409,8 +488,20 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
               "wgrad_mfma: operand larger than 2 GiB (B=%d rows=%d L=%d)", a_in.B, std::max(a_in.O, a_in.C), a_in.L);
     WgradArgs a = a_in;
     const dim3 grid(ceil_div(a.O, 128), ceil_div(a.C, 128), T * a.nsplit);
-    if (T == 3) hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, s, a);
+    static const bool no_dma = getenv("DWS_WGRAD_NO_DMA") != nullptr;
+    if (T == 1 && !a.xact && !a.addc && !no_dma) {
+        constexpr int lds = 2 * 2 * 128 * 66 * 4;
+        static bool attr = false;
+        if (!attr) {
+            DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(512), lds, s, a);
+    } else if (T == 3) {
+        hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, s, a);
+    }
     const size_t n = (size_t)a.O * a.C * T;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, s, a.partial, dW, n, a.nsplit, scale);
     if (a.bias_part)
