@@ -1,0 +1,58 @@
+"""GPU: BASELINE.json's full sizes (B = 16, L = 16000) through size-independent properties: a clip's result does
+not depend on its batch neighbours (bitwise), equal inputs give equal outputs, the graph sampler is deterministic,
+plus direct parity of ONE clip against the CPU oracle at the full length."""
+import pytest
+import torch
+
+import bench
+from oracle import sashimi as osa
+from oracle import wavenet as own
+from tests import cases
+from tests.conftest import REL_TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    audio = torch.randn(B, 1, L, generator=g)
+    steps = torch.randint(0, 200, (B, 1), generator=g).float()
+    audio[7], steps[7] = audio[2], steps[2]          # two identical clips inside the batch
+    return audio, steps
+
+
+@pytest.mark.parametrize("config", ["wnet_h256_d36_T200", "unet_d64_n6_T200"])
+def test_config_at_full_size(gpu, config):
+    cfg = bench.CONFIGS[config]
+    B, L = cfg["B"], cfg["L"]
+    assert (B, L) == (16, 16000)
+    torch.manual_seed(3)
+    net = cases.build_ours(dict(cfg["model"]), 91).to(gpu)
+    audio, steps = _inputs(B, L, 92)
+    with torch.no_grad():
+        full = net((audio.to(gpu), steps.to(gpu)))
+        again = net((audio.to(gpu), steps.to(gpu)))
+        one = net((audio[3:4].to(gpu), steps[3:4].to(gpu)))
+    assert torch.isfinite(full).all() and float(full.abs().max()) > 1e-3
+    assert torch.equal(full, again)                              # deterministic
+    assert torch.equal(full[2], full[7])                         # equal clips -> equal results, wherever they sit
+    assert torch.equal(full[3:4], one)                           # independent of the batch neighbours, bitwise
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        if cfg["model"]["_name_"] == "wavenet":
+            ref = own.wavenet_forward(sd, cfg["model"], audio[3:4], steps[3:4])
+        else:
+            ref = osa.sashimi_forward(sd, cfg["model"], audio[3:4], steps[3:4])
+    assert rel_err(one.cpu(), ref) < REL_TOL
+
+
+def test_sampler_at_full_size_is_deterministic(gpu):
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    cfg = bench.CONFIGS["wnet_h256_d36_T200"]
+    net = cases.build_ours(dict(cfg["model"]), 93).to(gpu)
+    dh = calc_diffusion_hyperparams(3, 1e-4, 0.05)
+    a = sampling(net, (16, 1, 16000), dh, seed=5, use_graph=True)
+    b = sampling(net, (16, 1, 16000), dh, seed=5, use_graph=False)
+    c = sampling(net, (16, 1, 16000), dh, seed=6, use_graph=True)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+    assert abs(float(a.std()) - 1.0) < 0.5
