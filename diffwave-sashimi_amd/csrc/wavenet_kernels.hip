@@ -211,7 +211,9 @@ __device__ __forceinline__ f32x4 buf_load_f4(__amdgpu_buffer_rsrc_t r, int voff,
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int C, int S>
+// EXTRA = false is the unconditional sampling instance: the conditioner add and the training save of the gate
+// pre-activations (128 never-taken branches per tile otherwise) are compiled out.
+template <int C, int S, bool EXTRA>
 __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     using T = WnTile<C, S>;
     constexpr int P = T::P, KC = T::KC, NT = T::NT, MP = T::MP, MR = T::MR, MS = T::MS;
@@ -360,14 +362,14 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
                 const int ch = (wm * MP + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 float ht = acc[m][n][r] + bt_[r];
                 float hs = acc[MP + m][n][r] + bs_[r];
-                if (melb) {
+                if (EXTRA && melb) {
                     const int pos = l0 + col;
                     if (pos < L) {
                         ht += melb[ch * L + pos];
                         hs += melb[(C + ch) * L + pos];
                     }
                 }
-                if (a.hsave) {  // training: keep the pre-activations for the gate adjoint
+                if (EXTRA && a.hsave) {  // training: keep the pre-activations for the gate adjoint
                     const int pos = l0 + col;
                     if (pos < L) {
                         float* __restrict__ hb = a.hsave + (size_t)b * 2 * C * L;
@@ -529,7 +531,8 @@ template <int C, int S>
 static int launch_layer_t(const WnLayerArgs& a, hipStream_t s) {
     ProfileScope ps("wn_layer_mfma", s);
     const int ntl = ceil_div(a.L, WnTile<C, S>::P);
-    hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S>), dim3(a.B * ntl), dim3(256), 0, s, a);
+    if (a.melc || a.hsave) hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, true>), dim3(a.B * ntl), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, false>), dim3(a.B * ntl), dim3(256), 0, s, a);
     return DWS_OK;
 }
 
