@@ -159,10 +159,26 @@ def cpu_baseline(cfg, seconds_budget=25.0):
         if time.perf_counter() - t_begin > 2 * seconds_budget:
             break
     per_step = sum(times) / len(times)
-    return {"value": L / (T * per_step), "unit": "audio samples/s", "cores": best, "host_cpus": ncpu, "kind": "port",
-            "sample": f"{len(times)} forward steps at B=1, L={L} with {best} threads (best of a probe over 8..64), "
-                      f"extrapolated to the T={T} loop",
-            "ms_per_step_b1": per_step * 1e3}
+    out = {"value": L / (T * per_step), "unit": "audio samples/s", "cores": best, "host_cpus": ncpu, "kind": "port",
+           "sample": f"{len(times)} forward steps at B=1, L={L} with {best} threads (best of a probe over 8..64), "
+                     f"extrapolated to the T={T} loop",
+           "ms_per_step_b1": per_step * 1e3, "cpu_model": _cpu_model()}
+    if per_step * best < 20.0:     # single-thread figure when one step is predicted to fit in ~20 s
+        torch.set_num_threads(1)
+        t1 = one()
+        out["single_thread_value"] = L / (T * t1)
+        torch.set_num_threads(best)
+    return out
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
