@@ -68,6 +68,7 @@ CONFIGS = {
 }
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MEASURED_F32_MFMA_TFLOPS = 141.6  # tools/ubench/coexec.hip, MFMA-only leg on this pool's MI355X: extra context only
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA (three bf16 MFMAs per fp32-equivalent product)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
@@ -343,6 +344,8 @@ def main():
                                      cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
             "frac": ach / peak, "traffic": traffic if args.precision == "f32" else None,
+            **({"frac_of_measured_mfma_ceiling": ach / MEASURED_F32_MFMA_TFLOPS,
+                "measured_mfma_ceiling": MEASURED_F32_MFMA_TFLOPS} if args.precision == "f32" else {}),
             "avg_launch_ms": avg_ms, "launches_timed": n_launch.value,
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
             "hbm_achieved_GBs": bytes_ / (avg_ms * 1e-3) / 1e9,
@@ -364,6 +367,7 @@ def main():
             result["roofline"] = {
                 "kernel": "s4_tail_mfma_kernel<H,...> (all %d block launches of a step)" % nblocks, "bound": "mfma",
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "frac_of_measured_mfma_ceiling": ach / MEASURED_F32_MFMA_TFLOPS, "measured_mfma_ceiling": MEASURED_F32_MFMA_TFLOPS,
                 "traffic": None, "ms_per_step_in_kernel": step_ms, "launches_timed": n_launch.value,
                 "algorithmic_flops_per_step": flops, "algorithmic_bytes_per_step": bytes_,
                 "hbm_achieved_GBs": bytes_ / (step_ms * 1e-3) / 1e9,
