@@ -143,6 +143,29 @@ def local_directory(name, model_cfg, diffusion_cfg, dataset_cfg, output_director
     return local_path, output_directory
 
 
+def smooth_ckpt(path, min_ckpt, max_ckpt):
+    """``utils.py:47-74,154-166`` (experimental in the reference): running arithmetic mean of the
+    ``model_state_dict`` of every checkpoint with ``min_ckpt < iteration <= max_ckpt``."""
+    ckpts = []
+    for f in os.listdir(path):
+        if len(f) > 4 and f.endswith(".pkl"):
+            try:
+                it = int(f[:-4])
+            except ValueError:
+                continue
+            if min_ckpt < it <= max_ckpt:
+                ckpts.append(it)
+    state_dict = None
+    for n, it in enumerate(sorted(ckpts)):
+        model_path = os.path.join(path, f"{it}.pkl")
+        try:
+            sd = torch.load(model_path, map_location="cpu")["model_state_dict"]
+        except Exception:
+            raise Exception(f"No valid model found at iteration {it}, path {model_path}")
+        state_dict = sd if state_dict is None else {k: (state_dict[k] * n + sd[k]) / (n + 1) for k in sd}
+    return state_dict
+
+
 # --------------------------------------------------------------------------- generate
 @torch.no_grad()
 def generate(rank, diffusion_cfg, model_cfg, dataset_cfg, ckpt_iter="max", n_samples=1, name=None, batch_size=None,
@@ -162,20 +185,24 @@ def generate(rank, diffusion_cfg, model_cfg, dataset_cfg, ckpt_iter="max", n_sam
     net = construct_model(model_kwargs).cuda().eval()
 
     ckpt_path = os.path.join(exp_root, local_path, "checkpoint")
-    if ckpt_smooth is not None:
-        raise NotImplementedError("checkpoint averaging (`utils.py:47-74`, experimental in the reference) is not built")
     if ckpt_iter == "init":
         ckpt_iter = 0
     else:
         if ckpt_iter == "max":
             ckpt_iter = find_max_epoch(ckpt_path)
         ckpt_iter = int(ckpt_iter)
-        model_file = os.path.join(ckpt_path, f"{ckpt_iter}.pkl")
-        try:
-            checkpoint = torch.load(model_file, map_location="cpu")
-            net.load_state_dict(checkpoint["model_state_dict"])
-        except Exception as e:  # the reference raises a bare 'No valid model found' (`generate.py:110-112`)
-            raise Exception(f"No valid model found ({model_file}: {e})")
+        if ckpt_smooth is None:
+            model_file = os.path.join(ckpt_path, f"{ckpt_iter}.pkl")
+            try:
+                checkpoint = torch.load(model_file, map_location="cpu")
+                net.load_state_dict(checkpoint["model_state_dict"])
+            except Exception as e:  # the reference raises a bare 'No valid model found' (`generate.py:110-112`)
+                raise Exception(f"No valid model found ({model_file}: {e})")
+        else:                       # `generate.py:113-115`: average of the checkpoints in (ckpt_smooth, ckpt_iter]
+            state_dict = smooth_ckpt(ckpt_path, int(ckpt_smooth), ckpt_iter)
+            if state_dict is None:
+                raise Exception(f"No checkpoints in ({ckpt_smooth}, {ckpt_iter}] under {ckpt_path}")
+            net.load_state_dict(state_dict)
     output_directory = os.path.join(output_directory, str(ckpt_iter))
     os.makedirs(output_directory, mode=0o775, exist_ok=True)
 

@@ -111,6 +111,17 @@ def test_find_max_epoch(tmp_path):
     assert find_max_epoch(str(tmp_path / "empty")) == -1
 
 
+def test_checkpoint_smoothing_is_the_arithmetic_mean(tmp_path):
+    """`utils.py:47-74,154-166`: mean of the state dicts with min < iteration <= max."""
+    from diffwave_sashimi_amd.generate import smooth_ckpt
+    for it, v in ((1000, 1.0), (2000, 2.0), (3000, 6.0), (4000, 100.0)):
+        torch.save({"model_state_dict": {"w": torch.full((3,), v), "b": torch.tensor([v, -v])}}, str(tmp_path / f"{it}.pkl"))
+    (tmp_path / "notes.txt").write_text("x")
+    sd = smooth_ckpt(str(tmp_path), 1000, 3000)            # 2000 and 3000 only
+    assert torch.allclose(sd["w"], torch.full((3,), 4.0)) and torch.allclose(sd["b"], torch.tensor([4.0, -4.0]))
+    assert smooth_ckpt(str(tmp_path), 4000, 5000) is None
+
+
 @pytest.mark.gpu
 def test_generate_end_to_end_from_a_checkpoint(tmp_path, gpu):
     """Checkpoint ingest (`generate.py:105-112`) -> hipGraph sampler -> float32 wavs named like the reference."""
