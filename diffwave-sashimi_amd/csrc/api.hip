@@ -15,6 +15,8 @@ dws_model::~dws_model() {
     if (smp_ev_in) hipEventDestroy(smp_ev_in);
     if (smp_ev_out) hipEventDestroy(smp_ev_out);
     if (smp_stream) hipStreamDestroy(smp_stream);
+    if (copy_consumed) hipEventDestroy(copy_consumed);
+    if (copy_pinned) hipHostFree(copy_pinned);
     for (auto* p : params) delete p;
 }
 
@@ -210,7 +212,7 @@ __global__ void multi_copy_kernel(const CopyJob* __restrict__ jobs, int parts) {
 }
 }  // namespace dws
 
-static int multi_copy(std::vector<dws::CopyJob>& jobs, hipStream_t stream);
+static int multi_copy(dws_model* m, std::vector<dws::CopyJob>& jobs, hipStream_t stream);
 
 int dws_model_update_params(dws_model* m, int32_t count, const char* const* names, const float* const* srcs, void* stream) {
     DWS_CHECK(m && names && srcs && count >= 0, DWS_ERR_INVALID, "dws_model_update_params: null argument");
@@ -223,7 +225,7 @@ int dws_model_update_params(dws_model* m, int32_t count, const char* const* name
         DWS_CHECK(p->dtype == 0 && srcs[i], DWS_ERR_INVALID, "'%s': update_params takes float32 device tensors", names[i]);
         jobs[i] = {srcs[i], p->buf.f(), (int64_t)p->numel()};
     }
-    DWS_TRY(multi_copy(jobs, (hipStream_t)stream));
+    DWS_TRY(multi_copy(m, jobs, (hipStream_t)stream));
     m->dirty = true;
     m->drop_graph();
     return DWS_OK;
@@ -244,27 +246,24 @@ int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, f
         DWS_CHECK(g && dsts[i], DWS_ERR_HIP, "could not allocate the gradient of '%s'", names[i]);
         jobs[i] = {g, dsts[i], numels[i]};
     }
-    return multi_copy(jobs, (hipStream_t)stream);
+    return multi_copy(m, jobs, (hipStream_t)stream);
 }
 
 // One kernel for a list of device-to-device copies.  The job table travels through a pinned staging buffer so nothing
 // blocks the host; an event guards the buffer's reuse.
-static int multi_copy(std::vector<dws::CopyJob>& jobs, hipStream_t stream) {
-    static dws::DevBuf table;
-    static dws::CopyJob* pinned = nullptr;
-    static size_t pinned_cap = 0;
-    static hipEvent_t consumed = nullptr;
-    if (!consumed) DWS_HIP(hipEventCreateWithFlags(&consumed, hipEventDisableTiming));
-    else DWS_HIP(hipEventSynchronize(consumed));
-    if (pinned_cap < jobs.size()) {
-        if (pinned) hipHostFree(pinned);
-        pinned_cap = jobs.size() * 2;
-        DWS_HIP(hipHostMalloc((void**)&pinned, pinned_cap * sizeof(dws::CopyJob), hipHostMallocDefault));
+static int multi_copy(dws_model* m, std::vector<dws::CopyJob>& jobs, hipStream_t stream) {
+    if (!m->copy_consumed) DWS_HIP(hipEventCreateWithFlags(&m->copy_consumed, hipEventDisableTiming));
+    else DWS_HIP(hipEventSynchronize(m->copy_consumed));
+    if (m->copy_pinned_cap < jobs.size()) {
+        if (m->copy_pinned) hipHostFree(m->copy_pinned);
+        m->copy_pinned_cap = jobs.size() * 2;
+        DWS_HIP(hipHostMalloc(&m->copy_pinned, m->copy_pinned_cap * sizeof(dws::CopyJob), hipHostMallocDefault));
     }
-    std::memcpy(pinned, jobs.data(), jobs.size() * sizeof(dws::CopyJob));
-    DWS_TRY(table.ensure(pinned_cap * sizeof(dws::CopyJob)));
-    DWS_HIP(hipMemcpyAsync(table.p, pinned, jobs.size() * sizeof(dws::CopyJob), hipMemcpyHostToDevice, stream));
-    DWS_HIP(hipEventRecord(consumed, stream));
+    std::memcpy(m->copy_pinned, jobs.data(), jobs.size() * sizeof(dws::CopyJob));
+    dws::DevBuf& table = m->copy_table;
+    DWS_TRY(table.ensure(m->copy_pinned_cap * sizeof(dws::CopyJob)));
+    DWS_HIP(hipMemcpyAsync(table.p, m->copy_pinned, jobs.size() * sizeof(dws::CopyJob), hipMemcpyHostToDevice, stream));
+    DWS_HIP(hipEventRecord(m->copy_consumed, stream));
     const int parts = 8;
     hipLaunchKernelGGL(dws::multi_copy_kernel, dim3((unsigned)jobs.size(), parts), dim3(256), 0, stream,
                        (const dws::CopyJob*)table.p, parts);

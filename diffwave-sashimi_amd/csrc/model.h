@@ -57,6 +57,13 @@ struct dws_model {
     bool dirty = true;
     int64_t B = 0, L = 0;  // prepared workspace shape
 
+    dws::DevBuf lin_scratch;  // split-O partials of the embedding adjoint
+    // batched parameter / gradient copies (api.hip): device job table, pinned staging, reuse guard
+    dws::DevBuf copy_table;
+    void* copy_pinned = nullptr;
+    size_t copy_pinned_cap = 0;
+    hipEvent_t copy_consumed = nullptr;
+
     // sampler state (sampler.hip)
     dws::DevBuf smp_tables;   // [3][T] c1, c2, sigma
     int smp_T = 0;            // length of the uploaded tables

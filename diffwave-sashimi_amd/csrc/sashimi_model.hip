@@ -988,9 +988,9 @@ struct SashimiModel : dws_model {
             DWS_HIP(hipMemcpyAsync(G(l->prefix + ".fc_t.bias"), dbt_all.f() + l->pt_off, (size_t)l->H * 4,
                                    hipMemcpyDeviceToDevice, s));
         }
-        DWS_TRY(launch_lin_bwd_x(dpt.f(), Wt_all.f(), ta2.f(), dh2.f(), nB, Eout, pt_total, s));
+        DWS_TRY(launch_lin_bwd_x(dpt.f(), Wt_all.f(), ta2.f(), dh2.f(), nB, Eout, pt_total, lin_scratch, s));
         DWS_TRY(launch_lin_bwd_w(dh2.f(), h1.f(), G("fc_t2.weight"), G("fc_t2.bias"), nB, Emid, Eout, s));
-        DWS_TRY(launch_lin_bwd_x(dh2.f(), P("fc_t2.weight"), ta1.f(), dh1.f(), nB, Emid, Eout, s));
+        DWS_TRY(launch_lin_bwd_x(dh2.f(), P("fc_t2.weight"), ta1.f(), dh1.f(), nB, Emid, Eout, lin_scratch, s));
         DWS_TRY(launch_lin_bwd_w(dh1.f(), emb.f(), G("fc_t1.weight"), G("fc_t1.bias"), nB, Ein, Emid, s));
         DWS_HIP(hipGetLastError());
         return DWS_OK;

@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "dws_common.h"
+#include "model.h"
 
 namespace dws {
 int launch_rowsum(const float* dY, float* db, int B, int O, int L, float scale, int accumulate, hipStream_t s);
@@ -20,7 +21,8 @@ int launch_relu_bwd(float* dx, const float* y, size_t n, hipStream_t s);
 int launch_weight_norm_bwd(const float* dW, const float* v, const float* g, float* dv, float* dg, int O, int inner,
                            hipStream_t s);
 int launch_lin_bwd_w(const float* dy, const float* x, float* dW, float* db, int B, int K, int O, hipStream_t s);
-int launch_lin_bwd_x(const float* dy, const float* W, const float* pre, float* dx, int B, int K, int O, hipStream_t s);
+int launch_lin_bwd_x(const float* dy, const float* W, const float* pre, float* dx, int B, int K, int O, DevBuf& part,
+                     hipStream_t s);
 
 // ---- MFMA adjoints (wavenet_backward_mfma.hip)
 struct TapConvArgs {

@@ -297,8 +297,8 @@ __global__ void lin_bwd_x_finish_kernel(const float* __restrict__ part, const fl
     dx[i] = acc;
 }
 
-int launch_lin_bwd_x(const float* dy, const float* W, const float* pre, float* dx, int B, int K, int O, hipStream_t s) {
-    static DevBuf part;   // [nz][B][K] scratch, one per process (calls are stream-ordered)
+int launch_lin_bwd_x(const float* dy, const float* W, const float* pre, float* dx, int B, int K, int O, DevBuf& part,
+                     hipStream_t s) {   // part: [nz][B][K] scratch owned by the model
     const int ochunk = 128, nz = ceil_div(O, ochunk);
     DWS_TRY(part.ensure((size_t)nz * B * K * 4));
     hipLaunchKernelGGL(lin_bwd_x_partial_kernel, dim3(ceil_div(K, 128), B, nz), dim3(128), 0, s, dy, W, part.f(), K, O, ochunk);

@@ -465,10 +465,10 @@ struct WaveNetModel : dws_model {
                                    hipMemcpyDeviceToDevice, s));
             DWS_HIP(hipMemcpyAsync(G(p + ".fc_t.bias"), dbt_all.f() + (size_t)n * C, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
         }
-        DWS_TRY(launch_lin_bwd_x(dpt.f(), Wt_all.f(), ta2.f(), dh2.f(), nB, Eout, NL * C, s));   // d(pre-activation 2)
+        DWS_TRY(launch_lin_bwd_x(dpt.f(), Wt_all.f(), ta2.f(), dh2.f(), nB, Eout, NL * C, lin_scratch, s));   // d(pre-activation 2)
         DWS_TRY(launch_lin_bwd_w(dh2.f(), h1.f(), G("residual_layer.fc_t2.weight"), G("residual_layer.fc_t2.bias"), nB, Emid,
                                  Eout, s));
-        DWS_TRY(launch_lin_bwd_x(dh2.f(), P("residual_layer.fc_t2.weight"), ta1.f(), dh1.f(), nB, Emid, Eout, s));
+        DWS_TRY(launch_lin_bwd_x(dh2.f(), P("residual_layer.fc_t2.weight"), ta1.f(), dh1.f(), nB, Emid, Eout, lin_scratch, s));
         DWS_TRY(launch_lin_bwd_w(dh1.f(), emb.f(), G("residual_layer.fc_t1.weight"), G("residual_layer.fc_t1.bias"), nB, Ein,
                                  Emid, s));
         DWS_HIP(hipGetLastError());
