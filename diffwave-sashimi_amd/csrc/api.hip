@@ -148,6 +148,7 @@ int dws_model_set_param(dws_model* m, const char* name, const void* data, const 
                               want.c_str());
     }
     DWS_HIP(hipMemcpyAsync(p->buf.p, data, p->nbytes(), hipMemcpyDefault, (hipStream_t)stream));
+    if (dtype == 1) ++m->int_params_version;
     m->dirty = true;
     m->drop_graph();
     return DWS_OK;

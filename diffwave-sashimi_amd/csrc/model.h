@@ -55,6 +55,7 @@ struct dws_model {
     std::vector<dws::ParamSpec*> params;
     std::map<std::string, int> index;
     bool dirty = true;
+    uint64_t int_params_version = 1;  // bumped whenever an int64 tensor (S4 `L` buffers) is (re)set
     int64_t B = 0, L = 0;  // prepared workspace shape
 
     dws::DevBuf lin_scratch;  // split-O partials of the embedding adjoint

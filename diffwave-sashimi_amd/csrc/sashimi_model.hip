@@ -59,7 +59,8 @@ enum { L_BLOCK = 0, L_DOWN = 1, L_UP = 2 };
 struct SLayer {
     int kind, H, L, p = 1, Hout = 0, Lout = 0;   // L / Lout: lengths of the CURRENT run (prepare rescales them)
     int L0 = 0, Lout0 = 0;                       // as configured (model L)
-    int Lk = 0;                                  // S4 kernel length = the block's `L` buffer (>= L)
+    int Lk = 0;                                  // S4 kernel length = the block's `L` buffer
+    uint64_t Lk_version = 0;                     // int_params_version at which Lk was read back
     std::string prefix;
     int pt_off = 0;       // offset of this block's fc_t rows in the stacked projection
     int stage = 0;        // index into per-(H,L) workspaces
@@ -259,9 +260,12 @@ struct SashimiModel : dws_model {
     int build_kernel(SLayer* l, hipStream_t s) {
         const int H = l->H, L = l->L, N = NS;
         const std::string k = l->prefix + ".layer.kernel.kernel";
-        int64_t Lbuf = 0;
-        DWS_HIP(hipMemcpyAsync(&Lbuf, P(k + ".L"), 8, hipMemcpyDeviceToHost, s));
-        DWS_HIP(hipStreamSynchronize(s));
+        int64_t Lbuf = l->Lk;
+        if (l->Lk_version != int_params_version) {   // read back only when an int64 buffer was re-sent (not every step)
+            DWS_HIP(hipMemcpyAsync(&Lbuf, P(k + ".L"), 8, hipMemcpyDeviceToHost, s));
+            DWS_HIP(hipStreamSynchronize(s));
+            l->Lk_version = int_params_version;
+        }
         // the kernel is generated at its own length l_max; a run uses its first min(L, l_max) taps per direction
         // (`L_kernel`, s4.py:1387,805): shorter inputs truncate it, longer inputs keep l_max taps
         DWS_CHECK(Lbuf > 0 && Lbuf < (1 << 28), DWS_ERR_STATE,
