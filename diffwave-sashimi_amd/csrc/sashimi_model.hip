@@ -73,7 +73,8 @@ struct SLayer {
     DevBuf melW0, melW1, melWc, melc;
     DevBuf out;           // activation produced by this layer
     // training path: saved activations, gradient w.r.t. `out`, transposed weights in A-fragment order
-    DevBuf t_u, t_a, t_o, t_x1, t_n2, t_f1, t_xr, dbuf;
+    DevBuf t_u, t_a, t_g, t_o, t_x1, t_n2, t_f1, t_ge, t_xr, dbuf;   // t_g = gelu(t_a), t_ge = gelu(t_f1): kept so the
+                                                                    // weight gradients need no GELU recompute
     DevBuf tAo, tA1, tA2, tAp, tAoT, tA1T, tA2T, tApT;
 };
 
@@ -729,6 +730,7 @@ struct SashimiModel : dws_model {
             if (l->kind == L_BLOCK) {
                 const size_t n = (size_t)B * l->H * l->L * 4;
                 DWS_TRY(l->t_u.ensure(n)); DWS_TRY(l->t_a.ensure(n)); DWS_TRY(l->t_o.ensure(2 * n));
+                DWS_TRY(l->t_g.ensure(n)); DWS_TRY(l->t_ge.ensure((size_t)FF * n));
                 DWS_TRY(l->t_x1.ensure(n)); DWS_TRY(l->t_n2.ensure(n)); DWS_TRY(l->t_f1.ensure((size_t)FF * n));
                 DWS_TRY(l->dbuf.ensure(n));
             } else {
@@ -774,19 +776,19 @@ struct SashimiModel : dws_model {
                                   Ls, (size_t)Ls, s));
                 FftTables* t = tables[l->log2m];
                 FftConvArgs fa{};
-                fa.u = l->t_u.f(); fa.g = st->g.f(); fa.pre = l->t_a.f(); fa.D = P(p + ".layer.D");
+                fa.u = l->t_u.f(); fa.g = l->t_g.f(); fa.pre = l->t_a.f(); fa.D = P(p + ".layer.D");
                 fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
                 fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
                 fa.B = nB; fa.H = H; fa.L = Ls;
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
-                DWS_TRY(gemm(l->tAo.f(), 2 * H, H, st->g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"), nullptr,
+                DWS_TRY(gemm(l->tAo.f(), 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"), nullptr,
                              nullptr, nullptr, nullptr, s));
                 DWS_TRY(launch_glu_res(l->t_o.f(), x, melBm ? l->melc.f() : nullptr, l->t_x1.f(), nB, H, Ls, s));
                 DWS_TRY(launch_ln(l->t_x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, l->t_n2.f(), nB, H, Ls,
                                   (size_t)Ls, s));
                 DWS_TRY(gemm(l->tA1.f(), FF * H, H, l->t_n2.f(), l->t_f1.f(), Ls, 3, P(p + ".ff.ff.0.conv.bias"), nullptr,
-                             nullptr, nullptr, st->ffu.f(), s));
-                DWS_TRY(gemm(l->tA2.f(), H, FF * H, st->ffu.f(), l->out.f(), Ls, 4, P(p + ".ff.ff.2.conv.bias"), l->t_x1.f(),
+                             nullptr, nullptr, l->t_ge.f(), s));
+                DWS_TRY(gemm(l->tA2.f(), H, FF * H, l->t_ge.f(), l->out.f(), Ls, 4, P(p + ".ff.ff.2.conv.bias"), l->t_x1.f(),
                              add, nullptr, nullptr, s));
             } else if (l->kind == L_DOWN) {
                 DWS_TRY(launch_pool_rearrange(x, l->t_xr.f(), nullptr, 0, 0, nB, l->H, l->p, l->Lout, s));
@@ -910,7 +912,7 @@ struct SashimiModel : dws_model {
                 const int H = l->H, Ls = l->L, nblk = nB * ceil_div(Ls, 64);
                 // ff: out = x1 + W2 gelu(f1) + b2, f1 = W1 n2 + b1
                 DWS_TRY(gemm(l->tA2T.f(), FF * H, H, dy, st->d2.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_f1.f(), nullptr, s));
-                DWS_TRY(wgrad(dy, l->t_f1.f(), H, FF * H, Ls, 1, dWfold.f(), G(p + ".ff.ff.2.conv.bias"), s));
+                DWS_TRY(wgrad(dy, l->t_ge.f(), H, FF * H, Ls, 0, dWfold.f(), G(p + ".ff.ff.2.conv.bias"), s));
                 DWS_TRY(wn_bwd(p + ".ff.ff.2.conv", dWfold.f(), H, FF * H, s));
                 DWS_TRY(gemm(l->tA1T.f(), H, FF * H, st->d2.f(), st->dh.f(), Ls, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
                 DWS_TRY(wgrad(st->d2.f(), l->t_n2.f(), FF * H, H, Ls, 0, dWfold.f(), G(p + ".ff.ff.0.conv.bias"), s));
@@ -935,7 +937,7 @@ struct SashimiModel : dws_model {
                 // x1 = x + glu(o), o = Wo gelu(a) + bo
                 DWS_TRY(launch_glu_bwd(st->dx1.f(), l->t_o.f(), st->d2.f(), nB, H, Ls, s));
                 DWS_TRY(gemm(l->tAoT.f(), H, 2 * H, st->d2.f(), st->dh.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_a.f(), nullptr, s));
-                DWS_TRY(wgrad(st->d2.f(), l->t_a.f(), 2 * H, H, Ls, 1, G(p + ".layer.output_linear.0.weight"),
+                DWS_TRY(wgrad(st->d2.f(), l->t_g.f(), 2 * H, H, Ls, 0, G(p + ".layer.output_linear.0.weight"),
                               G(p + ".layer.output_linear.0.bias"), s));
                 // a = conv(u, K) + D u: du = conv^T(da) + D da; kernel parameters from corr(u, da)
                 FftTables* t = tables[l->log2m];
