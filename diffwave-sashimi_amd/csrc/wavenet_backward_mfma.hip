@@ -22,6 +22,7 @@ namespace dws {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
@@ -42,7 +43,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // T = 3: measured faster with 2 workgroups per CU than with 3 (456 -> 384 us on the C = 256 adjoint), so the
     // allocation is padded past a third of the 160 KB LDS
     constexpr int LDS_PAD = (T == 3) ? 2304 : 0;
-    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * P + LDS_PAD];
+    constexpr int EPI_FLOATS = (EPI == 1) ? 0 : 4 * 32 * P;   // one 32-row transposition tile per wave (float4 epilogue)
+    constexpr int LDS_FLOATS = (2 * ROWS * P + LDS_PAD) > EPI_FLOATS ? (2 * ROWS * P + LDS_PAD) : EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,6 +125,65 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     const int M = a.M;
     if (!wave_live) return;
+    if (EPI != 1 && (L & 3) == 0) {
+        // float4 epilogue: the accumulators of this wave's MT tiles go through a private LDS tile [rows][64 positions]
+        // and come back with 16 lanes per row, so every global access is a 16-byte buffer instruction covering 256
+        // contiguous bytes of a row (the per-lane dword form issued 4x the VMEM instructions and ran the HBM-bound
+        // 1x1 GEMMs at 3.2 TB/s).  (The last main-loop barrier has passed: the staging buffers are free.)
+        float* wl = lds + wave * (32 * P);   // one tile at a time: LDS operations of a wave execute in order
+        const size_t boff = (size_t)b * M * L;
+        const int ML4 = M * L * 4, L4 = L * 4;
+        constexpr int OOB = 0x7ffffff0;
+        __amdgpu_buffer_rsrc_t rOut = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + boff), 0, ML4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rAux = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((EPI == 0 ? (a.addin ? a.addin : a.out) : EPI == 4 ? a.res : EPI == 5 ? a.aux : a.out) + boff), 0, ML4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rAdd = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == 4 && a.addend ? a.addend : a.out) + boff), 0, ML4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rOut2 = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == 3 ? a.out2 : a.out) + boff), 0, ML4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? a.bias : a.out), 0, M * 4, 0x00020000);
+        const int lrow = lane >> 4, p4 = (lane & 15) * 4;
+        const int voff = (l0 + p4 < L) ? (lrow * L + l0 + p4) * 4 : OOB;
+        const bool has_bias = a.bias != nullptr, has_addin = a.addin != nullptr, has_addend = a.addend != nullptr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * lhi) * P + n * 32 + l31] = acc[m][n][r];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row0 = (mt[m] * 32 + it * 4);
+            const int soff = row0 * L4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(wl + (it * 4 + lrow) * P + p4);
+            if (EPI == 0) {
+                if (has_addin) {
+                    const f32x4 ad = buf_load4(rAux, voff, soff);
+                    v += ad * a.addscale;
+                }
+            } else if (EPI == 5) {
+                const f32x4 ax = buf_load4(rAux, voff, soff);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_b(ax[j]);
+            } else {
+                if (has_bias) {
+                    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, lrow * 4, row0 * 4, 0));
+                    v += bv;
+                }
+                if (EPI == 4) {
+                    v += buf_load4(rAux, voff, soff);
+                    if (has_addend) v += buf_load4(rAdd, voff, soff);
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rOut, voff, soff, 0);
+            if (EPI == 3) {
+                f32x4 gq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gq[j] = gelu_b(v[j]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, gq), rOut2, voff, soff, 0);
+            }
+        }
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int pos = l0 + n * 32 + l31;
