@@ -66,7 +66,7 @@ struct SLayer {
     int stage = 0;        // index into per-(H,L) workspaces
     DevBuf W1, W2, Wp;    // folded ff / pool weights
     DevBuf Ao, A1, A2, rs1, Ap;  // MFMA-packed copies (+ row sums of W1 for the folded LayerNorm)
-    bool mfma = false;
+    bool mfma = false, mfma2 = false;
     DevBuf Kf;            // rocFFT path: [H][L+1] complex spectrum of the two-sided kernel (n = 2L)
     DevBuf kfa, kfb, kfs; // fused path: pair-ordered spectrum at the power-of-two size (fftconv.h)
     int log2m = 0;        // > 0: fused LDS FFT convolution is used for this block
@@ -364,7 +364,10 @@ struct SashimiModel : dws_model {
                 DWS_TRY(l->Wp.ensure((size_t)O * K * 4));
                 DWS_TRY(fold(l->prefix + ".linear.conv", l->Wp.f(), O, K, s));
                 l->mfma = pw_mfma_supported(l->kind == L_DOWN ? 0 : 1, K, O, l->p) && !getenv("DWS_SASHIMI_GENERIC");
-                if (l->mfma) {
+                // shapes the fused pooling kernel does not cover (e.g. 128 -> 64 channels of unet_d32) still run on MFMA:
+                // explicit rearrangement + the position-tile GEMM of the training path
+                l->mfma2 = !l->mfma && tapconv_mfma_supported(O, K, 0, 1) && !getenv("DWS_SASHIMI_GENERIC");
+                if (l->mfma || l->mfma2) {
                     DWS_TRY(l->Ap.ensure((size_t)O * K * 4));
                     DWS_TRY(launch_pack_a_frag(l->Wp.f(), l->Ap.f(), O, K, s));
                 }
@@ -427,10 +430,13 @@ struct SashimiModel : dws_model {
             DWS_TRY(st->n2.ensure(rows * Ls * 4));
             DWS_TRY(st->ffu.ensure(rows * FF * Ls * 4));
         }
+        size_t pool_max = 4;
         for (auto* l : all) {
             const size_t n = (l->kind == L_BLOCK) ? (size_t)B * l->H * l->L : (size_t)B * l->Hout * l->Lout;
             DWS_TRY(l->out.ensure(n * 4));
+            if (l->kind != L_BLOCK) pool_max = std::max(pool_max, std::max((size_t)B * l->H * l->L, n) * 4);
         }
+        DWS_TRY(pool_scr.ensure(pool_max));
         // FFT plans allocate: create them here, never inside a stream capture
         for (auto* st : stages) {
             int lg = 0;
@@ -548,6 +554,16 @@ struct SashimiModel : dws_model {
             if (l->kind == L_DOWN) { a.K = l->H * l->p; a.M = l->Hout; a.L = l->Lout; a.addend = nullptr; }
             else { a.K = l->H; a.M = l->Hout * l->p; a.L = l->L; a.addend = addend; }
             return launch_pw_mfma(l->kind == L_DOWN ? 0 : 1, a, s);
+        }
+        if (l->mfma2) {
+            const float* bias = P(l->prefix + ".linear.conv.bias");
+            if (l->kind == L_DOWN) {
+                DWS_TRY(launch_pool_rearrange(x, pool_scr.f(), nullptr, 0, 0, (int)B, l->H, l->p, l->Lout, s));
+                return gemm(l->Ap.f(), l->Hout, l->H * l->p, pool_scr.f(), l->out.f(), l->Lout, 2, bias, nullptr, nullptr, nullptr,
+                            nullptr, s);
+            }
+            DWS_TRY(gemm(l->Ap.f(), l->Hout * l->p, l->H, x, pool_scr.f(), l->L, 2, bias, nullptr, nullptr, nullptr, nullptr, s));
+            return launch_pool_rearrange(pool_scr.f(), l->out.f(), addend, 1, 0, (int)B, l->Hout, l->p, l->L, s);
         }
         if (l->kind == L_DOWN)
             return launch_pw_downpool(x, l->Wp.f(), P(l->prefix + ".linear.conv.bias"), l->out.f(), (int)B, l->H, l->p,

@@ -621,8 +621,9 @@ int launch_wn_layer_generic(int C, int S, const WnLayerArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------
 template <int S>
 __global__ __launch_bounds__(256, 2) void wn_final_mfma_kernel(WnFinalArgs a) {
-    constexpr int P = 64, WAVES = 4;
+    constexpr int P = (S >= 64) ? 64 : 128, WAVES = 4;   // S = 32: one M tile, the four waves split 128 positions
     constexpr int WM = (S / 32 >= 4) ? 4 : S / 32, WN = WAVES / WM, NT = (P / 32) / WN, MT = S / 32 / WM;
+    static_assert(NT >= 1 && WN * NT * 32 == P, "N split");
     __shared__ __attribute__((aligned(16))) float lds[S * P];
     __shared__ float red[WAVES][P];
 
@@ -725,12 +726,14 @@ __global__ void wn_final_generic_kernel(WnFinalArgs a, int S) {
     }
 }
 
-bool wn_final_mfma_supported(int S) { return S == 64 || S == 128 || S == 256; }
+bool wn_final_mfma_supported(int S) { return S == 32 || S == 64 || S == 128 || S == 256; }
 
 int launch_wn_final(int S, const WnFinalArgs& a, hipStream_t s) {
     ProfileScope ps("wn_final", s);
-    const int ntl = ceil_div(a.L, 64);
-    if (S == 64)
+    const int ntl = ceil_div(a.L, S >= 64 ? 64 : 128);
+    if (S == 32)
+        hipLaunchKernelGGL((wn_final_mfma_kernel<32>), dim3(a.B * ntl), dim3(256), 0, s, a);
+    else if (S == 64)
         hipLaunchKernelGGL((wn_final_mfma_kernel<64>), dim3(a.B * ntl), dim3(256), 0, s, a);
     else if (S == 128)
         hipLaunchKernelGGL((wn_final_mfma_kernel<128>), dim3(a.B * ntl), dim3(256), 0, s, a);
