@@ -265,6 +265,43 @@ def g_sashimi_varlen():
     save("sashimi_varlen", **out)
 
 
+from make_golden_cases import GRAD_CASES  # noqa: E402
+
+
+def g_grads():
+    """Reference gradients of the training loss (`train.py:198-222`, restated inline: train.py itself pulls in wandb and
+    the data loaders): loss = MSE(net((x_t, t), mel), z) with t, z drawn from the global RNG after manual_seed, backward
+    through the imported reference modules (SaShiMi: after the first-forward `_setup_C`, through the S4 kernel
+    generation with the symmetric Cauchy semantics).  Stores the initial state_dict, inputs, loss and every gradient."""
+    _, _, utils, _ = _refimport.load()
+    out = {"symmetric_cauchy": np.array(1)}
+    for name, (cfg, B, L, Tmel) in GRAD_CASES.items():
+        ours = cases.build_ours(cfg, 311)
+        sd0 = {k: v.detach().clone() for k, v in ours.state_dict().items()}
+        net = ref_model(cfg, sd0).train()
+        dh = utils.calc_diffusion_hyperparams(T=50, beta_0=1e-4, beta_T=0.05, beta=None, fast=False)
+        g = torch.Generator().manual_seed(312)
+        audio = torch.randn(B, 1, L, generator=g) * 0.3
+        mel = None if Tmel is None else torch.cat([cases.mel_inputs(1, Tmel, 313 + i) for i in range(B)])
+        torch.manual_seed(314)
+        T_, Alpha_bar = dh["T"], dh["Alpha_bar"]
+        steps = torch.randint(T_, size=(B, 1, 1))
+        z = torch.normal(0, 1, size=audio.shape)
+        x_t = torch.sqrt(Alpha_bar[steps]) * audio + torch.sqrt(1 - Alpha_bar[steps]) * z
+        loss = torch.nn.MSELoss()(net((x_t, steps.view(B, 1)), mel_spec=mel), z)
+        loss.backward()
+        out.update(sd_arrays(sd0, f"{name}/sd0/"))
+        out[f"{name}/audio"], out[f"{name}/loss"] = audio, loss.detach().reshape(1)
+        if mel is not None:
+            out[f"{name}/mel"] = mel
+        n = 0
+        for k, p in net.named_parameters():
+            out[f"{name}/grad/{k}"] = torch.zeros_like(p) if p.grad is None else p.grad.detach()
+            n += 1
+        print(name, "loss", float(loss), "params with grads", n)
+    save("grads", **out)
+
+
 def g_s4_parts():
     """Function-level vectors: TransposedLN, DownPool/UpPool index maps, FF, setup_C."""
     models, _, _, s4 = _refimport.load()
@@ -331,7 +368,7 @@ def g_mel():
     save("mel", **out)
 
 
-GROUPS = {"mel": g_mel, "sashimi_varlen": g_sashimi_varlen, "sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
+GROUPS = {"grads": g_grads, "mel": g_mel, "sashimi_varlen": g_sashimi_varlen, "sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
           "wavenet_cond": g_wavenet_cond, "sampler": g_sampler}
 
 if __name__ == "__main__":
