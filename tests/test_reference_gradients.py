@@ -7,13 +7,16 @@ import torch.nn as nn
 
 from oracle import sashimi as osa
 from oracle import wavenet as own
+from tests import cases
 from tests.conftest import load_golden
 from tests.golden.make_golden_cases import GRAD_CASES
 
 
 def _case(g, name):
     cfg, B, L, Tmel = GRAD_CASES[name]
-    sd0 = {k[len(name) + 5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f"{name}/sd0/")}
+    sd0 = {k: v.detach().clone() for k, v in cases.build_ours(cfg, 311).state_dict().items()}   # as the generator did
+    digest = float(torch.stack([v.double().sum() for v in sd0.values() if v.is_floating_point()]).sum())
+    assert abs(digest - float(g[f"{name}/sd0_digest"][0])) < 1e-6 * max(1.0, abs(digest)), "seeded weights differ"
     grads = {k[len(name) + 6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f"{name}/grad/")}
     audio = torch.from_numpy(g[f"{name}/audio"])
     mel = torch.from_numpy(g[f"{name}/mel"]) if f"{name}/mel" in g else None
