@@ -217,7 +217,9 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
     for _ in range(args.steps):
         loss = step()
     ddist.barrier()
-    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, red_dev)
+    mine = time.perf_counter() - t0
+    elapsed = ddist.max_over_ranks(mine, red_dev)
+    per_rank_ms = [t / args.steps * 1e3 for t in ddist.gather_over_ranks(mine, red_dev)]
     ms = elapsed / args.steps * 1e3
     if rank == 0:
         print(json.dumps({
@@ -227,8 +229,45 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic U(-0.3,0.3) audio",
             "config": {"workload": args.config + " training", "batch_per_gpu": B, "L": L,
                        "parallelism": "dp%d, bucketed asynchronous RCCL all-reduce of the gradients" % world},
+            "per_rank_ms_per_step": per_rank_ms, "process_group": ddist.group_info(),
             "final_loss": float(loss)}))
     ddist.shutdown()
+
+
+def spawn_ranks(n):
+    """Re-execute this command line once per rank (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the environment, rendezvous
+    on 127.0.0.1); rank 0 inherits stdout, so exactly one JSON line is printed.  Any rank failing fails the job."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+            if rc:                       # a dead rank leaves the others in a collective: stop them
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                p.kill()
+    if rc:
+        sys.exit(rc)
 
 
 def main():
@@ -250,11 +289,18 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves, one process per GPU, as the reference
+        # does (`generate.py:220-227`, `train.py:244-251`); under torch.distributed.run the env is already set
+        return spawn_ranks(args.gpus)
     from diffwave_sashimi_amd import dist as ddist
     # DWS_BENCH_SHARE_GPU=1 (tests only): all ranks on cuda:0 with gloo, to exercise the N > 1 control flow on a
     # one-GPU box (one device cannot host two RCCL ranks).  Real runs: one rank per GPU over RCCL.
     share = os.environ.get("DWS_BENCH_SHARE_GPU") == "1"
-    world, rank, local_rank = ddist.init(("gloo" if share else "nccl") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    # DWS_BENCH_FORCE_PG=1: a 1-rank RCCL group at N = 1, so the timing barrier / reductions run over RCCL on a one-GPU box
+    force_pg = os.environ.get("DWS_BENCH_FORCE_PG") == "1"
+    world, rank, local_rank = ddist.init(("gloo" if share else "nccl")
+                                         if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or force_pg) else None, force=force_pg)
     if world == 1 or share:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -304,8 +350,9 @@ def main():
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = ddist.max_over_ranks(elapsed, red_dev)
+    mine = time.perf_counter() - t0
+    elapsed = ddist.max_over_ranks(mine, red_dev)
+    per_rank_ms = [t / args.steps * 1e3 for t in ddist.gather_over_ranks(mine, red_dev)]
     ms_per_step = elapsed / args.steps * 1e3
     value = ddist.aggregate_throughput(B * L / T, world, ms_per_step * 1e-3)
 
@@ -317,6 +364,7 @@ def main():
         "config": {"workload": args.config, "backbone": cfg["model"]["_name_"], "batch_per_gpu": B, "L": L, "T": T,
                    "parallelism": "independent clips per GPU, no collective",
                    "sampler": "hipGraph replay, on-device Philox noise"},
+        "per_rank_ms_per_step": per_rank_ms, "process_group": ddist.group_info(),
     }
 
     if rank == 0 and not args.no_roofline and cfg["model"]["_name_"] == "wavenet":

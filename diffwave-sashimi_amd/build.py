@@ -2,27 +2,42 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the
 resulting ``diffwave-sashimi_amd/libdws.so`` is git-ignored but travels to the
-GPU box with the tree.
+GPU box with the tree.  Each ``csrc/*.hip`` is compiled to its own object under
+``csrc/build/`` (in parallel, only when it or a header changed), then linked.
 """
 import glob
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdws.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "dws.h")]
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "dws.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build():
+    return _stale(LIB, sources() + _headers())
 
 
 def build(force=False, verbose=False):
@@ -30,15 +45,29 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-           "-o", LIB] + sources() + ["-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, proc.stdout[-4000:], proc.stderr[-8000:]))
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in sources()] + \
+          ["-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout[-4000:] + proc.stderr[-8000:])
+        raise RuntimeError("link failed:\n" + proc.stdout[-4000:] + proc.stderr[-8000:])
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force="--force" in os.sys.argv, verbose=True))

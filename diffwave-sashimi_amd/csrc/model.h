@@ -68,6 +68,7 @@ struct dws_model {
     // sampler state (sampler.hip)
     dws::DevBuf smp_tables;   // [3][T] c1, c2, sigma
     int smp_T = 0;            // length of the uploaded tables
+    std::vector<float> smp_host_tables;  // host copy of what is resident (upload skipped when identical)
     dws::DevBuf smp_state;    // int32 step index
     dws::DevBuf smp_eps;      // eps[B, Cout, L]
     dws::DevBuf smp_steps;    // float steps[B]

@@ -16,11 +16,16 @@ def env_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend=None):
-    """Initialise from the torchrun environment; no-op for a single process."""
+def init(backend=None, force=False):
+    """Initialise from the torchrun environment; no-op for a single process unless ``force`` (a 1-rank
+    group: the same RCCL barrier / reductions as an N-rank job, runnable on a one-GPU box)."""
     world, rank, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
@@ -29,6 +34,15 @@ def init(backend=None):
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, **kw)
     return world, rank, local_rank
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def barrier():
@@ -45,6 +59,23 @@ def max_over_ranks(seconds, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(seconds, device=None):
+    """Every rank's time, in rank order (reported beside the max so a slow shard is visible)."""
+    if not dist.is_initialized():
+        return [float(seconds)]
+    t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def group_info():
+    """Backend and size of the live process group ("nccl" is RCCL on ROCm)."""
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1}
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
 
 
 def rank_seed(base_seed, rank):

@@ -39,7 +39,11 @@ def init_distributed(rank, num_gpus, group_name, dist_backend, dist_url):
     torch has no such argument).  Pins the process to its GPU when there is one."""
     if torch.cuda.is_available():
         torch.cuda.set_device(rank % torch.cuda.device_count())
-    dist.init_process_group(dist_backend, init_method=dist_url, world_size=num_gpus, rank=rank)
+    import datetime
+    # rank 0 checkpoints and generates while the other ranks wait in the next exchange (`train.py:166-183`):
+    # give the group a timeout that covers a T-step sampling run
+    dist.init_process_group(dist_backend, init_method=dist_url, world_size=num_gpus, rank=rank,
+                            timeout=datetime.timedelta(minutes=60))
 
 
 def _real_view(t):
@@ -61,6 +65,8 @@ def broadcast_state(module, src=0):
             n = v.numel()
             v.copy_(flat[off:off + n].view_as(v))
             off += n
+    if hasattr(module, "invalidate"):    # the .data writes above are invisible to the engine's version-counter cache
+        module.invalidate()
 
 
 class _Bucket:

@@ -26,6 +26,22 @@ import yaml
 
 
 # --------------------------------------------------------------------------- config
+class _Loader(yaml.SafeLoader):
+    """SafeLoader with the YAML-1.2 float grammar OmegaConf/Hydra use: PyYAML (YAML 1.1) reads ``2e-4`` -- the
+    reference's ``train.learning_rate`` (``configs/config.yaml``) -- as a string."""
+
+
+_Loader.add_implicit_resolver(
+    "tag:yaml.org,2002:float",
+    re.compile(r"^[-+]?(?:\d[\d_]*\.[\d_]*(?:[eE][-+]?\d+)?|\.[\d_]+(?:[eE][-+]?\d+)?|\d[\d_]*[eE][-+]?\d+"
+               r"|[-+]?\.(?:inf|Inf|INF)|\.(?:nan|NaN|NAN))$"),
+    list("-+0123456789."))
+
+
+def _yaml(text):
+    return yaml.load(text, Loader=_Loader)
+
+
 def _deep_merge(dst, src):
     for k, v in src.items():
         if isinstance(v, dict) and isinstance(dst.get(k), dict):
@@ -38,7 +54,7 @@ def _deep_merge(dst, src):
 def _load_yaml(path):
     with open(path) as f:
         text = f.read()
-    return (yaml.safe_load(text) or {}), ("@package _global_" in text.split("\n", 1)[0])
+    return (_yaml(text) or {}), ("@package _global_" in text.split("\n", 1)[0])
 
 
 def _set_dotted(cfg, key, value):
@@ -81,7 +97,7 @@ def load_config(config_dir, overrides=(), config_name="config"):
         if "." not in k and os.path.isdir(os.path.join(config_dir, k)):
             groups[k] = v
         else:
-            values.append((k, yaml.safe_load(v)))
+            values.append((k, _yaml(v)))
     root, _ = _load_yaml(os.path.join(config_dir, config_name + ".yaml"))
     cfg = {}
 
@@ -169,7 +185,8 @@ def smooth_ckpt(path, min_ckpt, max_ckpt):
 # --------------------------------------------------------------------------- generate
 @torch.no_grad()
 def generate(rank, diffusion_cfg, model_cfg, dataset_cfg, ckpt_iter="max", n_samples=1, name=None, batch_size=None,
-             ckpt_smooth=None, mel_path=None, mel_name=None, dataloader=None, exp_root="exp", seed=None):
+             ckpt_smooth=None, mel_path=None, mel_name=None, dataloader=None, exp_root="exp", seed=None,
+             written=None):
     """``generate.py:58-200``.  ``ckpt_iter`` may additionally be ``"init"``: seeded random weights
     (no checkpoint), for smoke runs without trained weights."""
     from .models import construct_model
@@ -238,6 +255,8 @@ def generate(rank, diffusion_cfg, model_cfg, dataset_cfg, ckpt_iter="max", n_sam
         outfile = "{}k_{}.wav".format(ckpt_iter // 1000, n_samples * rank + i)   # `generate.py:189`
         wavwrite(os.path.join(output_directory, outfile), dataset_cfg["sampling_rate"],
                  generated_audio[i].squeeze().cpu().numpy().astype(np.float32))
+        if written is not None:
+            written.append(os.path.join(output_directory, outfile))
     return generated_audio
 
 

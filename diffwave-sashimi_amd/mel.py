@@ -7,7 +7,8 @@ runs in ``dws_mel_spectrogram`` (``csrc/mel_kernels.hip``); this module builds t
 the host (window, filterbank) and keeps the reference's call surface.
 
 The filterbank restates the published algorithm of ``librosa.filters.mel`` (``htk=False``,
-``norm='slaney'``) -- librosa itself is not a dependency here.
+``norm='slaney'``) -- librosa itself is not a dependency here; its numbers are pinned against an independent
+implementation through ``tests/golden/mel.npz`` (``tests/test_mel.py``).
 """
 import numpy as np
 import torch

@@ -26,6 +26,8 @@ class _EngineTrainFn(torch.autograd.Function):
         _lib.check(lib.dws_model_forward_train(module._handle, x.data_ptr(), steps.data_ptr(), out.data_ptr(),
                                                _lib.current_stream()))
         ctx.module, ctx.x, ctx.steps = module, x, steps      # x must stay alive until backward (init_conv adjoint)
+        module._train_generation += 1                        # the activations inside the dws_model belong to THIS forward
+        ctx.generation = module._train_generation
         ctx.meta = [(n, tuple(p.shape), p.dtype) for n, p in module.named_parameters()]
         return out
 
@@ -33,6 +35,9 @@ class _EngineTrainFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         m = ctx.module
+        if ctx.generation != m._train_generation:
+            raise RuntimeError("the engine keeps the activations of ONE training forward: another forward ran on this "
+                               "module before this backward (accumulate gradients with forward/backward pairs)")
         d = dout.detach().to(torch.float32).contiguous()
         _lib.check(lib.dws_model_backward(m._handle, d.data_ptr(), _lib.current_stream()))
         n = len(ctx.meta)
@@ -59,6 +64,8 @@ class EngineModule(nn.Module):
         self._versions = {}
         self._shape = None
         self._mel_key = None
+        self._mel_ref = None
+        self._train_generation = 0
 
     # -- handle management ---------------------------------------------------
     def _desc(self):
@@ -85,6 +92,14 @@ class EngineModule(nn.Module):
         """Engine option, e.g. ``set_option("precision", "bf16x3")`` (see dws_model_set_option)."""
         _lib.check(_lib.load().dws_model_set_option(self._ensure_handle(), key.encode(), str(value).encode()))
         return self
+
+    def invalidate(self):
+        """Forget what the engine holds: the next call re-sends every parameter and re-runs the conditioner.
+        Needed after writes the version counters cannot see (``p.data.copy_``, in-place kernels on ``.data``)."""
+        # keep the shapes: same-shape float32 GPU tensors then go through the one-launch batched refresh
+        self._versions = {k: (None, -1) + tuple(v[2:]) for k, v in self._versions.items()}
+        self._mel_key = None
+        self._mel_ref = None
 
     def _engine_state(self):
         """(name, tensor) pairs handed to dws_model_set_param: the state_dict."""
@@ -136,16 +151,18 @@ class EngineModule(nn.Module):
         if mel_spec is None:
             if self._mel_key is not None:
                 _lib.check(lib.dws_model_set_condition(h, 0, 0, 0, _lib.current_stream()))
-                self._mel_key = None
+                self._mel_key = self._mel_ref = None
             return
+        # Same tensor OBJECT with an unchanged version counter: the cached conditioner terms still hold.  The
+        # strong reference keeps that tensor alive, so a new mel can never reuse its address and match by accident.
         key = (mel_spec.data_ptr(), mel_spec._version, tuple(mel_spec.shape))
-        if key == self._mel_key:
+        if mel_spec is self._mel_ref and key == self._mel_key:
             return
         mel = mel_spec.detach().to(torch.float32).contiguous()
         if mel.dim() != 3:
             raise RuntimeError("mel_spec must be [B or 1, mel_bands, Tmel]")
         _lib.check(lib.dws_model_set_condition(h, mel.data_ptr(), mel.shape[0], mel.shape[2], _lib.current_stream()))
-        self._mel_key = key
+        self._mel_key, self._mel_ref = key, mel_spec
 
     # -- reference surface -----------------------------------------------------
     def forward(self, input_data, mel_spec=None):

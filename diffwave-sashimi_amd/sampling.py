@@ -39,7 +39,8 @@ def sampling(net, size, diffusion_hyperparams, condition=None, *, x_T=None, nois
     Extra keyword-only arguments (not in the reference):
       x_T    initial state [B,C,L]; default: drawn on the device from the Philox stream
       noise  injected variance noise [T,B,C,L] (``noise[t]`` is added after step t>0) -- parity mode
-      seed   Philox seed for the on-device RNG (default: torch's initial seed)
+      seed   Philox seed for the on-device RNG (default: a fresh draw from torch's CPU generator per call, so
+             successive unseeded calls differ -- as the reference's do -- and ``torch.manual_seed`` still governs)
     """
     dh = diffusion_hyperparams
     T, Alpha, Alpha_bar, Sigma = dh["T"], dh["Alpha"], dh["Alpha_bar"], dh["Sigma"]
@@ -48,7 +49,7 @@ def sampling(net, size, diffusion_hyperparams, condition=None, *, x_T=None, nois
     lib = _lib.load()
     dev = torch.device("cuda")
     if seed is None:
-        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        seed = int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64).item())
     with torch.no_grad():
         net._sync_params(L)
         net._prepare(B, L)

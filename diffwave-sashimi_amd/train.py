@@ -154,6 +154,7 @@ def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, c
     print(f"{type(net).__name__} parameters: {sum(p.numel() for p in net.parameters()) / 1e6:.6f}M")   # `utils.py:76-88`
     if num_gpus > 1:
         net = apply_gradient_allreduce(net)
+    learning_rate = float(learning_rate)
     optimizer = torch.optim.Adam(net.parameters(), lr=learning_rate)
 
     if ckpt_iter == "max":
@@ -213,10 +214,15 @@ def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, c
                            os.path.join(checkpoint_directory, f"{n_iter}.pkl"))
                 print(f"model at iteration {n_iter} is saved")
                 if generate_cfg and generate_cfg.get("n_samples", 0):
+                    if not model_cfg["unconditional"]:
+                        assert generate_cfg.get("mel_name") is not None     # `train.py:170`
                     gen = dict(generate_cfg, ckpt_iter=n_iter)
                     net.eval()
-                    generate(rank, diffusion_cfg, model_cfg, dataset_cfg, name=name, exp_root=exp_root, **gen)
+                    wavs = []
+                    generate(rank, diffusion_cfg, model_cfg, dataset_cfg, name=name, exp_root=exp_root,
+                             written=wavs, **gen)
                     net.train()
+                    log({"val/audio": wavs}, n_iter)     # the reference logs the clips to wandb (`train.py:180-183`)
             n_iter += 1
             if n_iter >= n_iters + 1:
                 break

@@ -1,6 +1,7 @@
-"""Training-step pieces around the network (``train.py:198-222``).  The backward of
-the HIP engine is not built yet; these functions are the callers on
-either side of it and work with any differentiable ``net`` of the reference surface."""
+"""Training-step pieces around the network (``train.py:198-222``): q-sample and the epsilon loss.  ``net`` is
+any differentiable module of the reference surface; with the engine modules the call goes through
+``models.engine._EngineTrainFn`` (``dws_model_forward_train`` / ``dws_model_backward``), which keeps the
+activations of exactly one forward per module -- pair every forward with its backward."""
 import torch
 
 

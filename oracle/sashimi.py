@@ -97,7 +97,9 @@ def ss_kernel_nplr(sd, prefix, L):
     dt = torch.exp(log_dt)
     Q = P.conj()
     w = -torch.exp(inv_w_real) + 1j * w_imag
-    omega, z = omega_z(Lk)
+    omega, z = omega_z(Lk)                  # complex64 nodes, as the reference computes them
+    if w.dtype != omega.dtype:              # float64 state_dict (conditioning studies): the SAME nodes, widened
+        omega, z = omega.to(w.dtype), z.to(w.dtype)
     w = w * dt.unsqueeze(-1)
     Bc = torch.cat([Bp, P], dim=-3)           # (2, H, N)
     Cc = torch.cat([C, Q], dim=-3)            # (3, H, N)

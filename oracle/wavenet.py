@@ -77,6 +77,7 @@ def step_embedding_mlp(sd, prefix, diffusion_steps, dim_in=128):
     ``models/sashimi.py:287-289``).  ``prefix`` includes the trailing dot (or
     is empty for SaShiMi where fc_t1/fc_t2 hang off the root module)."""
     e = calc_diffusion_step_embedding(diffusion_steps, dim_in)
+    e = e.to(sd[prefix + "fc_t1.weight"].dtype)   # float64 state_dict: the same graph in double (conditioning studies)
     e = swish(F.linear(e, sd[prefix + "fc_t1.weight"], sd[prefix + "fc_t1.bias"]))
     e = swish(F.linear(e, sd[prefix + "fc_t2.weight"], sd[prefix + "fc_t2.bias"]))
     return e

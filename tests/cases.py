@@ -74,6 +74,12 @@ SASHIMI_COND_CASES = {
 }
 
 
+# BASELINE config 4 at its own geometry: unet_d32_n6, mel-conditional, L = 16000 = 62.5 frames of hop 256 -> mel
+# [., 80, 63] upsampled to 16128 and truncated to 16000 / 4000 / 1000 per stage (`sashimi.py:160-175`), T = 50.
+# (cfg, B, Tmel, weight_seed, input_seed)
+SASHIMI_C4 = (ss_cfg(unconditional=False, d_model=32, n_layers=6, L=16000, mel_upsample=[16, 16]), 2, 63, 191, 192)
+
+
 def randomize_zero_conv(model, seed):
     """``final_conv[2]`` is zero-initialised in the reference (`wavenet.py:35-36`)
     so an untrained net outputs 0; re-initialise it N(0, 0.1^2) or parity is

@@ -265,17 +265,36 @@ def g_sashimi_varlen():
     save("sashimi_varlen", **out)
 
 
-from make_golden_cases import GRAD_CASES  # noqa: E402
+def g_sashimi_c4():
+    """BASELINE config 4 at its own geometry (cases.SASHIMI_C4): mel [1 | B, 80, 63] -> 16128 upsampled frames truncated
+    to 16000 / 4000 / 1000 per stage."""
+    cfg, B, Tmel, wseed, iseed = cases.SASHIMI_C4
+    out = {"symmetric_cauchy": np.array(1)}
+    for Bm in (1, B):
+        mel = cases.mel_inputs(Bm, Tmel, iseed)
+        net, sd0, sd1, audio, steps, eps, pre = _ss_run(cfg, B, wseed, iseed, mel=mel)
+        out[f"eps_bm{Bm}"] = eps
+        for k, v in cases.summarize(pre, stride=64).items():
+            out[f"pre_final_bm{Bm}/{k}"] = v
+        print("c4 Bm", Bm, "eps absmax", float(eps.abs().max()))
+    save("sashimi_c4", **out)
 
 
-def g_grads():
+from make_golden_cases import GRAD_CASES, GRAD_CASES_D32, grad_slice  # noqa: E402
+
+
+def g_grads_d32():
+    g_grads(GRAD_CASES_D32, "grads_d32", grad_slice)
+
+
+def g_grads(case_table=None, fname="grads", keep=lambda t: t):
     """Reference gradients of the training loss (`train.py:198-222`, restated inline: train.py itself pulls in wandb and
     the data loaders): loss = MSE(net((x_t, t), mel), z) with t, z drawn from the global RNG after manual_seed, backward
     through the imported reference modules (SaShiMi: after the first-forward `_setup_C`, through the S4 kernel
     generation with the symmetric Cauchy semantics).  Stores the initial state_dict, inputs, loss and every gradient."""
     _, _, utils, _ = _refimport.load()
     out = {"symmetric_cauchy": np.array(1)}
-    for name, (cfg, B, L, Tmel) in GRAD_CASES.items():
+    for name, (cfg, B, L, Tmel) in (case_table or GRAD_CASES).items():
         ours = cases.build_ours(cfg, 311)
         sd0 = {k: v.detach().clone() for k, v in ours.state_dict().items()}
         net = ref_model(cfg, sd0).train()
@@ -297,10 +316,10 @@ def g_grads():
             out[f"{name}/mel"] = mel
         n = 0
         for k, p in net.named_parameters():
-            out[f"{name}/grad/{k}"] = torch.zeros_like(p) if p.grad is None else p.grad.detach()
+            out[f"{name}/grad/{k}"] = keep(torch.zeros_like(p) if p.grad is None else p.grad.detach())
             n += 1
         print(name, "loss", float(loss), "params with grads", n)
-    save("grads", **out)
+    save(fname, **out)
 
 
 def g_s4_parts():
@@ -328,11 +347,13 @@ def g_s4_parts():
 def g_mel():
     """`dataloaders/stft.py` (TacotronSTFT) imported from the reference.  `librosa` is absent from this image, so
     a stand-in module supplies the two functions stft.py takes from it: `librosa.util.pad_center` (zero padding,
-    trivial) and `librosa.filters.mel`, for which OUR restatement of the published Slaney filterbank is used --
-    i.e. these vectors pin the STFT / magnitude / matmul / log chain, NOT the filterbank (recorded as `mel_basis`
-    and flagged `filterbank_pinned = 0`)."""
+    trivial) and `librosa.filters.mel`.  The filterbank comes from an implementation INDEPENDENT of this repo:
+    `transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")` (installed in this image; Hugging
+    Face's own test-suite checks it against `librosa.filters.mel`, whose defaults htk=False / norm='slaney' it
+    reproduces), rounded to float32 as librosa returns it.  So these vectors pin the whole chain including the
+    filterbank (`filterbank_pinned = 1`, `mel_basis` recorded)."""
     import types
-    from diffwave_sashimi_amd.mel import mel_filterbank
+    from transformers.audio_utils import mel_filter_bank
     lib = types.ModuleType("librosa")
     lib.util = types.ModuleType("librosa.util")
     lib.filters = types.ModuleType("librosa.filters")
@@ -343,14 +364,16 @@ def g_mel():
         return np.pad(data, (lpad, size - n - lpad))
     lib.util.pad_center = pad_center
     lib.util.tiny = lambda x: np.finfo(np.float32).tiny
-    lib.filters.mel = lambda sr, n_fft, n_mels=128, fmin=0.0, fmax=None: mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    lib.filters.mel = lambda sr, n_fft, n_mels=128, fmin=0.0, fmax=None: np.ascontiguousarray(mel_filter_bank(
+        n_fft // 2 + 1, n_mels, fmin, sr / 2.0 if fmax is None else fmax, sr, norm="slaney", mel_scale="slaney").T
+    ).astype(np.float32)
     sys.modules["librosa"], sys.modules["librosa.util"], sys.modules["librosa.filters"] = lib, lib.util, lib.filters
     import importlib.util                      # the package __init__ pulls in torchvision / torchaudio: load the file itself
     spec = importlib.util.spec_from_file_location("ref_stft", os.path.join(_refimport.REF, "dataloaders", "stft.py"))
     ref_stft = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref_stft)
     TacotronSTFT = ref_stft.TacotronSTFT
-    out = {"filterbank_pinned": np.zeros(1)}
+    out = {"filterbank_pinned": np.ones(1)}
     g = torch.Generator().manual_seed(77)
     cases_ = {"lj": dict(filter_length=1024, hop_length=256, win_length=1024, sampling_rate=22050, mel_fmin=0.0, mel_fmax=8000.0),
               "small": dict(filter_length=256, hop_length=64, win_length=200, sampling_rate=16000, mel_fmin=50.0, mel_fmax=7000.0)}
@@ -369,7 +392,7 @@ def g_mel():
     save("mel", **out)
 
 
-GROUPS = {"grads": g_grads, "mel": g_mel, "sashimi_varlen": g_sashimi_varlen, "sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
+GROUPS = {"sashimi_c4": g_sashimi_c4, "grads_d32": g_grads_d32, "grads": g_grads, "mel": g_mel, "sashimi_varlen": g_sashimi_varlen, "sashimi": g_sashimi, "sashimi_cond": g_sashimi_cond, "s4_parts": g_s4_parts, "cauchy": g_cauchy, "embedding": g_embedding, "schedule": g_schedule, "wavenet": g_wavenet,
           "wavenet_cond": g_wavenet_cond, "sampler": g_sampler}
 
 if __name__ == "__main__":

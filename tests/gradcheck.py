@@ -1,0 +1,79 @@
+"""Shared gradient-comparison rule of the training tests.
+
+north_star's bound is 1e-3 relative in fp32.  A few parameter gradients of SaShiMi are heavily cancelling sums over
+all positions and channels (the scalar TransposedLN parameters `norm*.m`, the 1-input weight-normed `weight_v`): two
+mathematically identical fp32 evaluation orders differ there by more than 1e-3 -- the REFERENCE's own gradient of
+`c_layers.0.norm2.m` in tests/golden/grads_d32.npz is 1.07e-2 away from the float64 evaluation of the same graph.  So
+the bound is 1e-3 per tensor unless the measured fp32 rounding noise of that tensor is larger: the noise is the distance
+between fp32 implementations (the reference's stored gradients where a fixture holds them, the oracle's fp32 autograd)
+and the oracle's autograd in FLOAT64 on the same weights / inputs / complex64 FFT nodes, and the tolerance then is
+3x that noise.  Errors are `max|a-b| / max(max|b|, 1e-5 * largest gradient of the model)`."""
+import torch
+import torch.nn as nn
+
+from oracle import sashimi as osa
+from oracle import wavenet as own
+
+TOL = 1e-3
+
+
+def oracle_grads(cfg, sd, loss_of, dtype=torch.float32):
+    """Autograd of `loss_of(net)` through the CPU oracle on `sd` (post-`_setup_C` state_dict), in `dtype`."""
+    leaf = {k: (v.detach().clone().to(dtype).requires_grad_(True) if v.is_floating_point() else v.clone())
+            for k, v in sd.items()}
+    fwd = own.wavenet_forward if cfg["_name_"] == "wavenet" else osa.sashimi_forward
+
+    def net(inp, mel_spec=None):
+        mel = None if mel_spec is None else mel_spec.to(dtype)
+        return fwd(leaf, cfg, inp[0].to(dtype), inp[1], mel_spec=mel)
+
+    loss = loss_of(net, dtype)
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).double()
+             for k, v in leaf.items() if v.is_floating_point() and v.requires_grad}
+    return float(loss), grads
+
+
+def _scale(ref, gmax):
+    return max(float(ref.abs().max()), 1e-5 * gmax)
+
+
+def errors(got, ref):
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    return {k: float((got[k].double() - r.double()).abs().max()) / _scale(r, gmax) for k, r in ref.items()}
+
+
+def compare(got, ref, truth64, fp32_impls=(), label=""):
+    """`got` vs `ref` per tensor: 1e-3, or 3x the fp32 noise of that tensor measured as the distance of the given fp32
+    implementations (always including `ref`) from `truth64`.  Returns (worst error, its key)."""
+    gmax = max(float(v.abs().max()) for v in truth64.values())
+    bad, worst, worst_k = [], 0.0, None
+    for k, r in ref.items():
+        sc = _scale(truth64[k], gmax)
+        noise = max(float((impl[k].double() - truth64[k]).abs().max()) / sc for impl in (ref, *fp32_impls))
+        err = float((got[k].double() - r.double()).abs().max()) / sc
+        tol = max(TOL, 3.0 * noise)
+        if err > worst:
+            worst, worst_k = err, k
+        if not err < tol:
+            bad.append(f"{k}: err {err:.2e} >= tol {tol:.2e} (fp32 noise {noise:.2e})")
+    assert not bad, f"{label}: {len(bad)} of {len(ref)} gradients off:\n" + "\n".join(bad[:30])
+    return worst, worst_k
+
+
+def mse_training_loss(audio, dh, mel=None, seed=None, generator=None):
+    """`loss_of(net, dtype)` for `oracle_grads`: the `train.py:198-222` loss with steps / noise drawn once in fp32
+    (global RNG after `seed`, or `generator`), so every evaluation sees identical x_t, t, z."""
+    from diffwave_sashimi_amd.training import q_sample
+    if seed is not None:
+        torch.manual_seed(seed)
+    B = audio.shape[0]
+    steps = torch.randint(dh["T"], size=(B, 1, 1), generator=generator)
+    z = torch.normal(0, 1, size=audio.shape, generator=generator)
+    x_t = q_sample(audio, steps, dh["Alpha_bar"], z)
+
+    def loss_of(net, dtype=torch.float32):
+        eps = net((x_t, steps.view(B, 1)), mel_spec=mel)
+        return nn.MSELoss()(eps, z.to(eps.dtype))
+
+    return loss_of

@@ -46,6 +46,42 @@ def test_config_at_full_size(gpu, config):
     assert rel_err(one.cpu(), ref) < REL_TOL
 
 
+def test_config4_at_full_size(gpu):
+    """BASELINE config 4 at its workload: unet_d32_n6 mel-conditional, B = 32, L = 16000, mel [32, 80, 63].  Batch
+    independence / determinism (bitwise), a mel row conditions only its own clip, a batch-1 mel broadcasts
+    (`generate.py:140,155`), one clip against the CPU oracle at the full length, and the T = 50 graph sampler."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    cfg = bench.CONFIGS["unet_d32_n6_T50_cond"]
+    B, L, Tmel = cfg["B"], cfg["L"], cfg["Tmel"]
+    assert (B, L, Tmel) == (32, 16000, 63)
+    net = cases.build_ours(dict(cfg["model"]), 95).to(gpu)
+    audio, steps = _inputs(B, L, 96)
+    steps = steps.clamp(max=49.0)
+    mel = torch.cat([cases.mel_inputs(1, Tmel, 300 + i) for i in range(B)])
+    mel[7] = mel[2]
+    with torch.no_grad():
+        full = net((audio.to(gpu), steps.to(gpu)), mel_spec=mel.to(gpu))
+        again = net((audio.to(gpu), steps.to(gpu)), mel_spec=mel.to(gpu))
+        one = net((audio[3:4].to(gpu), steps[3:4].to(gpu)), mel_spec=mel[3:4].to(gpu))
+        bcast = net((audio.to(gpu), steps.to(gpu)), mel_spec=mel[3:4].to(gpu))
+        other = mel.clone()
+        other[5] = mel[6]
+        changed = net((audio.to(gpu), steps.to(gpu)), mel_spec=other.to(gpu))
+    assert torch.isfinite(full).all() and float(full.abs().max()) > 1e-3
+    assert torch.equal(full, again) and torch.equal(full[2], full[7]) and torch.equal(full[3:4], one)
+    assert torch.equal(bcast[3], full[3]) and not torch.equal(bcast[4], full[4])
+    keep = [i for i in range(B) if i != 5]
+    assert torch.equal(changed[keep], full[keep]) and not torch.equal(changed[5], full[5])
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = osa.sashimi_forward(sd, cfg["model"], audio[3:4], steps[3:4], mel_spec=mel[3:4])
+    assert rel_err(one.cpu(), ref) < REL_TOL
+    dh = calc_diffusion_hyperparams(**cfg["diffusion"])
+    a = sampling(net, (B, 1, L), dh, condition=mel.to(gpu), seed=5, use_graph=True)
+    b = sampling(net, (B, 1, L), dh, condition=mel.to(gpu), seed=5, use_graph=True)
+    assert torch.equal(a, b) and torch.isfinite(a).all() and torch.equal(a[2], a[2]) and not torch.equal(a[2], a[3])
+
+
 def test_sampler_at_full_size_is_deterministic(gpu):
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
     cfg = bench.CONFIGS["wnet_h256_d36_T200"]

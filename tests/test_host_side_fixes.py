@@ -1,0 +1,136 @@
+"""Host-side behaviours the reference has and a cache / default could silently break: YAML-1.2 floats in the config
+composer (CPU); per-call sampling seeds, the conditioner cache, the sampler's schedule tables, forward/backward pairing
+of the training path (GPU)."""
+import os
+import textwrap
+
+import pytest
+import torch
+import torch.nn as nn
+
+from tests import cases
+
+
+def test_config_floats_without_a_dot_are_floats(tmp_path):
+    """`configs/config.yaml` spells `learning_rate: 2e-4`; OmegaConf reads a float, PyYAML's YAML-1.1 resolver a str
+    (-> `Adam(lr='2e-4')` TypeError).  Same for a command-line override."""
+    from diffwave_sashimi_amd.generate import load_config
+    (tmp_path / "config.yaml").write_text(textwrap.dedent("""\
+        train:
+          learning_rate: 2e-4
+          n_iters: 1000
+          name: null
+        diffusion: {T: 200, beta_0: 1e-4, beta_T: 0.02}
+        """))
+    cfg = load_config(str(tmp_path))
+    assert cfg["train"]["learning_rate"] == 2e-4 and isinstance(cfg["train"]["learning_rate"], float)
+    assert cfg["diffusion"]["beta_0"] == 1e-4 and cfg["train"]["n_iters"] == 1000 and cfg["train"]["name"] is None
+    cfg = load_config(str(tmp_path), ["train.learning_rate=3E-5", "train.name=run1e", "diffusion.T=50"])
+    assert cfg["train"]["learning_rate"] == 3e-5 and cfg["train"]["name"] == "run1e" and cfg["diffusion"]["T"] == 50
+    torch.optim.Adam([nn.Parameter(torch.zeros(1))], lr=cfg["train"]["learning_rate"])
+
+
+@pytest.mark.gpu
+def test_unseeded_sampling_calls_differ_and_manual_seed_governs(gpu):
+    """The reference draws x_T / z from torch's generator, which advances (`generate.py:47,54`): successive batches of
+    one `generate` run are different clips.  With `seed=None` each call takes a fresh Philox seed from that generator."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    cfg, B, L, wseed, _, _ = cases.WAVENET_CASES["wn_tiny"]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    dh = calc_diffusion_hyperparams(4, 1e-4, 0.05)
+    torch.manual_seed(77)
+    a, b = sampling(net, (B, 1, L), dh), sampling(net, (B, 1, L), dh)
+    assert not torch.equal(a, b)
+    torch.manual_seed(77)
+    a2, b2 = sampling(net, (B, 1, L), dh), sampling(net, (B, 1, L), dh)
+    assert torch.equal(a, a2) and torch.equal(b, b2)
+
+
+@pytest.mark.gpu
+def test_sampler_tables_follow_the_schedule_not_only_T(gpu):
+    """Same T, different betas: `dws_sampler_steps` must not reuse the resident c1 / c2 / sigma tables."""
+    import ctypes
+
+    import numpy as np
+
+    from diffwave_sashimi_amd import _lib
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    cfg, B, L, wseed, _, _ = cases.WAVENET_CASES["wn_tiny"]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    lib = _lib.load()
+    T = 6
+    outs = {}
+    for bT in (0.05, 0.2, 0.05):
+        dh = calc_diffusion_hyperparams(T, 1e-4, bT)
+        tabs = [np.ascontiguousarray(dh[k].numpy()) for k in ("Alpha", "Alpha_bar", "Sigma")]
+        ptabs = [t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) for t in tabs]
+        x = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(1)).to(gpu)
+        net._sync_params()
+        net._prepare(B, L)
+        _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, T, 9, 1, _lib.current_stream()))
+        torch.cuda.synchronize()
+        ref = sampling(net, (B, 1, L), dh, x_T=torch.randn(B, 1, L, generator=torch.Generator().manual_seed(1)), seed=9)
+        assert torch.equal(x, ref), bT          # dws_sampler_run always uploads: the two entry points must agree
+        outs.setdefault(bT, x.clone())
+        assert torch.equal(outs[bT], x)
+    assert not torch.equal(outs[0.05], outs[0.2])
+
+
+@pytest.mark.gpu
+def test_conditioner_cache_sees_a_new_mel_at_a_recycled_address(gpu):
+    """A freed mel tensor's address is handed to the next one of the same shape (version counter 0 again): the engine
+    must still install the new conditioner.  Also in-place edits of the same tensor, and `invalidate()` after a write
+    the version counters cannot see."""
+    cfg, B, Tmel, wseed, iseed, _ = cases.SASHIMI_COND_CASES["ss_cond_tiny"]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    audio, steps = audio.to(gpu), steps.to(gpu)
+
+    def run(mel):
+        with torch.no_grad():
+            return net((audio, steps), mel_spec=mel).clone()
+
+    m1, m2 = cases.mel_inputs(B, Tmel, 1), cases.mel_inputs(B, Tmel, 2)
+    want1, want2 = run(m1.to(gpu)), run(m2.to(gpu))
+    assert not torch.equal(want1, want2)
+    hits = 0
+    for _ in range(8):                      # the caching allocator recycles the block of the tensor just dropped
+        t = m1.to(gpu)
+        p = t.data_ptr()
+        assert torch.equal(run(t), want1)
+        del t
+        t = m2.to(gpu)
+        hits += t.data_ptr() == p
+        assert torch.equal(run(t), want2)
+        del t
+    assert hits > 0, "the allocator never recycled the address: the test did not exercise the case"
+    t = m1.to(gpu)
+    assert torch.equal(run(t), want1)
+    t.copy_(m2.to(gpu))                     # in place: same object, version counter bumps
+    assert torch.equal(run(t), want2)
+    t.data.copy_(m1.to(gpu))                # through .data: invisible to the version counter ...
+    net.invalidate()                        # ... so the caller says so
+    assert torch.equal(run(t), want1)
+    with torch.no_grad():                   # parameters: a .data write + invalidate() reaches the engine too
+        w = net.state_dict()["final_conv.2.conv.bias"]
+        w.data.add_(1.0)
+    net.invalidate()
+    assert torch.allclose(run(t), want1 + 1.0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_backward_of_a_stale_training_forward_raises(gpu):
+    """The engine keeps ONE forward's activations: a backward after another training forward ran must not silently use
+    the wrong ones."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from diffwave_sashimi_amd.training import training_loss
+    cfg, B, L = cases.wn_cfg(res_channels=64, skip_channels=64, num_res_layers=2, dilation_cycle=2), 2, 128
+    net = cases.build_ours(cfg, 5).to(gpu).train()
+    dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
+    audio = (torch.randn(B, 1, L, generator=torch.Generator().manual_seed(1)) * 0.3).to(gpu)
+    l1 = training_loss(net, nn.MSELoss(), audio, dh, generator=torch.Generator().manual_seed(3))
+    l2 = training_loss(net, nn.MSELoss(), audio, dh, generator=torch.Generator().manual_seed(4))
+    with pytest.raises(RuntimeError, match="ONE training forward"):
+        l1.backward()
+    l2.backward()                           # the latest forward is still valid
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())

@@ -9,11 +9,11 @@ from oracle import sashimi as osa
 from oracle import wavenet as own
 from tests import cases
 from tests.conftest import load_golden
-from tests.golden.make_golden_cases import GRAD_CASES
+from tests.golden.make_golden_cases import GRAD_CASES, GRAD_CASES_D32, grad_slice
 
 
 def _case(g, name):
-    cfg, B, L, Tmel = GRAD_CASES[name]
+    cfg, B, L, Tmel = {**GRAD_CASES, **GRAD_CASES_D32}[name]
     sd0 = {k: v.detach().clone() for k, v in cases.build_ours(cfg, 311).state_dict().items()}   # as the generator did
     digest = float(torch.stack([v.double().sum() for v in sd0.values() if v.is_floating_point()]).sum())
     assert abs(digest - float(g[f"{name}/sd0_digest"][0])) < 1e-6 * max(1.0, abs(digest)), "seeded weights differ"
@@ -31,35 +31,27 @@ def _loss(net, audio, mel):
     return training_loss(net, nn.MSELoss(), audio, dh, mel_spec=mel)
 
 
-def _compare(got, ref, tol):
-    gmax = max(float(v.abs().max()) for v in ref.values())
-    bad = []
-    for k, r in ref.items():
-        scale = max(float(r.abs().max()), 1e-5 * gmax)
-        err = float((got[k] - r).abs().max()) / scale
-        if err >= tol:
-            bad.append(f"{k}: {err:.2e}")
-    assert not bad, bad[:20]
-
-
 @pytest.mark.parametrize("name", list(GRAD_CASES))
 def test_oracle_autograd_matches_reference_gradients(name):
+    """1e-3 per tensor, widened only where the reference's own fp32 rounding noise (against the float64 evaluation of the
+    same graph) is larger -- tests/gradcheck.py."""
+    from diffwave_sashimi_amd.models import construct_model
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from tests import gradcheck
     g = load_golden("grads")
     cfg, B, L, sd0, ref, audio, mel, ref_loss = _case(g, name)
-    from diffwave_sashimi_amd.models import construct_model
     m = construct_model(dict(cfg))
     m.load_state_dict(sd0)
     if cfg["_name_"] == "sashimi":
         m._setup_C()                            # what the reference's first forward does before its graph is built
-    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
-    fwd = own.wavenet_forward if cfg["_name_"] == "wavenet" else osa.sashimi_forward
-    loss = _loss(lambda inp, mel_spec=None: fwd(sd, cfg, inp[0], inp[1], mel_spec=mel_spec), audio, mel)
-    loss.backward()
-    assert abs(float(loss) - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
-    got = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in ref}
-    # SaShiMi: the scalar LayerNorm parameters and the 1-input weight_v are heavily cancelling sums (their fp32 noise
-    # between two equivalent op orders reaches 5e-3 of the tensor's largest gradient); everything else is < 1e-3
-    _compare(got, ref, 2e-3 if cfg["_name_"] == "wavenet" else 1e-2)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    loss_of = gradcheck.mse_training_loss(audio, calc_diffusion_hyperparams(50, 1e-4, 0.05), mel, seed=314)
+    loss32, got = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
+    _, truth = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float64)
+    assert abs(loss32 - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
+    worst, k = gradcheck.compare(got, ref, truth, label=name)
+    noisy = {k: round(e, 5) for k, e in gradcheck.errors(ref, truth).items() if e >= gradcheck.TOL}
+    print(f"{name}: worst {worst:.2e} at {k}; reference tensors beyond 1e-3 of float64: {noisy}")
 
 
 @pytest.mark.gpu
@@ -88,4 +80,60 @@ def test_engine_wavenet_backward_matches_reference_gradients(gpu):
     loss = _loss(net, audio.to(gpu), None)
     loss.backward()
     assert abs(float(loss.detach()) - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
-    _compare({k: p.grad.detach().cpu() for k, p in net.named_parameters()}, ref, 2e-3)
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from tests import gradcheck
+    loss_of = gradcheck.mse_training_loss(audio, calc_diffusion_hyperparams(50, 1e-4, 0.05), None, seed=314)
+    _, truth = gradcheck.oracle_grads(cfg, sd0, loss_of, torch.float64)
+    worst, k = gradcheck.compare({k: p.grad.detach().cpu() for k, p in net.named_parameters()}, ref, truth, label="wn")
+    print(f"engine WaveNet backward vs reference gradients: worst {worst:.2e} at {k}")
+
+
+def _d32_setup():
+    from diffwave_sashimi_amd.models import construct_model
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from tests import gradcheck
+    g = load_golden("grads_d32")
+    cfg, B, L, sd0, ref, audio, mel, ref_loss = _case(g, "ss_d32")
+    m = construct_model(dict(cfg))
+    m.load_state_dict(sd0)
+    m._setup_C()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    loss_of = gradcheck.mse_training_loss(audio, calc_diffusion_hyperparams(50, 1e-4, 0.05), mel, seed=314)
+    loss64, truth = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float64)
+    loss32, o32 = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
+    keep = lambda d: {k: grad_slice(v) for k, v in d.items() if k in ref}
+    return cfg, sd0, ref, audio, ref_loss, loss32, keep(o32), keep(truth)
+
+
+def test_oracle_autograd_matches_reference_gradients_d32():
+    """Channel counts the engine trains at (H = 32 / 64 / 128): tests/golden/grads_d32.npz keeps a fixed-stride
+    subsample (`grad_slice`) of every reference gradient tensor.  Bound: 1e-3, widened only where the reference's own
+    fp32 rounding noise against the float64 evaluation of the same graph is larger (tests/gradcheck.py)."""
+    from tests import gradcheck
+    cfg, sd0, ref, audio, ref_loss, loss32, o32, truth = _d32_setup()
+    assert abs(loss32 - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
+    worst, k = gradcheck.compare(o32, ref, truth, label="oracle fp32 vs reference")
+    noisy = {k: e for k, e in gradcheck.errors(ref, truth).items() if e >= gradcheck.TOL}
+    # the widening applies to a handful of cancelling sums only; everything else holds the plain 1e-3
+    assert len(noisy) <= 3 and all(k.endswith(("norm2.m", "norm1.m", "weight_v")) for k in noisy), noisy
+    print(f"oracle vs reference (d32): worst {worst:.2e} at {k}; reference tensors beyond 1e-3 of float64: {noisy}")
+
+
+@pytest.mark.gpu
+def test_engine_sashimi_backward_matches_reference_gradients_d32(gpu):
+    """The engine's hand-written SaShiMi backward (MFMA adjoints, FFT-conv adjoints, Cauchy / Woodbury chain) against
+    gradients taken through the imported REFERENCE modules -- no oracle in between (the oracle only supplies the
+    float64 yardstick for the per-tensor rounding noise, tests/gradcheck.py)."""
+    from tests import gradcheck
+    cfg, sd0, ref, audio, ref_loss, loss32, o32, truth = _d32_setup()
+    from diffwave_sashimi_amd.models import construct_model
+    net = construct_model(dict(cfg)).to(gpu).train()
+    net.load_state_dict({k: v.to(gpu) for k, v in sd0.items()})
+    loss = _loss(net, audio.to(gpu), None)
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    got = {k: grad_slice(p.grad.detach().cpu()) for k, p in net.named_parameters()}
+    assert set(got) == set(ref)
+    worst, k = gradcheck.compare(got, ref, truth, fp32_impls=(o32,), label="engine vs reference")
+    e64 = gradcheck.errors(got, truth)
+    print(f"engine vs reference (d32): worst {worst:.2e} at {k}; engine vs float64: worst {max(e64.values()):.2e}")

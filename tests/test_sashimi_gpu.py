@@ -96,6 +96,23 @@ def test_sashimi_conditional_matches_reference(gpu, name):
     assert rel_err(_run(net, gpu, audio, steps), g[f"{name}/eps_nomel"]) < REL_TOL
 
 
+def test_config4_geometry_matches_reference(gpu):
+    """BASELINE config 4's own geometry against the reference (tests/golden/sashimi_c4.npz): unet_d32_n6, L = 16000,
+    mel [1 | B, 80, 63] whose 16128 upsampled frames are truncated to 16000 / 4000 / 1000 at the three stages."""
+    cfg, B, Tmel, wseed, iseed = cases.SASHIMI_C4
+    g = load_golden("sashimi_c4")
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    for Bm in (1, B):
+        mel = cases.mel_inputs(Bm, Tmel, iseed)
+        eps = _run(net, gpu, audio, steps, mel)
+        err = rel_err(eps, g[f"eps_bm{Bm}"])
+        assert err < REL_TOL, f"Bm={Bm}: {err:.3e}"
+        pre = net.read_tap("pre_final", (B, cfg["d_model"], cfg["L"]))
+        assert rel_err(cases.summarize(pre.cpu(), stride=64)["strided"], g[f"pre_final_bm{Bm}/strided"]) < REL_TOL
+        print(f"config-4 geometry, mel batch {Bm}: rel err vs reference {err:.3e}")
+
+
 def test_sashimi_matches_oracle_fresh_weights_and_first_forward_mutation(gpu):
     cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES["ss_knobs"]
     net = cases.build_ours(cfg, wseed + 9).to(gpu)

@@ -144,6 +144,21 @@ def test_sashimi_cond_oracle_matches_reference(name):
         assert rel_err(osa.sashimi_forward(sd0, cfg, audio, steps), g[f"{name}/eps_nomel"]) < 1e-4
 
 
+def test_config4_geometry_oracle_matches_reference():
+    """BASELINE config 4 at its own workload shape (unet_d32_n6, mel [1 | B, 80, 63] -> 16128 upsampled frames cut to
+    16000 / 4000 / 1000 per stage, `sashimi.py:160-175`), B = 2: tests/golden/sashimi_c4.npz."""
+    cfg, B, Tmel, wseed, iseed = cases.SASHIMI_C4
+    g = load_golden("sashimi_c4")
+    sd0 = {k: v.detach().clone() for k, v in cases.build_ours(cfg, wseed).state_dict().items()}
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    with torch.no_grad():
+        for Bm in (1, B):
+            mel = cases.mel_inputs(Bm, Tmel, iseed)
+            eps, pre = osa.sashimi_forward(sd0, cfg, audio, steps, mel_spec=mel, return_pre_final=True)
+            assert rel_err(eps, g[f"eps_bm{Bm}"]) < 1e-4
+            assert rel_err(cases.summarize(pre, stride=64)["strided"], g[f"pre_final_bm{Bm}/strided"]) < 1e-4
+
+
 def test_shim_setup_C_mutates_like_the_reference():
     """Our module's first-use transform leaves a state_dict a reference checkpoint would hold:
     L buffers = l_max and C = C~ (SURVEY.md 8c trap 3)."""

@@ -1,0 +1,5 @@
+#!/bin/bash
+# ISA of one csrc/*.hip for gfx950: tools/isa.sh fftconv_kernels > /tmp/fc.s
+set -e
+src="$(dirname "$0")/../diffwave-sashimi_amd/csrc/$1.hip"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -o - "$src"
