@@ -15,6 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdws.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# Per-file additions.  fftconv_kernels: the SLP vectoriser turns the complex butterflies into v_pk_*_f32 plus ~450
+# v_mov shuffles per kernel; packed fp32 issues at half rate on gfx950's SIMD-32 (no throughput gain), so the scalar
+# form is both shorter and spill-free at 128 VGPRs.
+FILE_FLAGS = {"fftconv_kernels": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -50,7 +54,10 @@ def build(force=False, verbose=False):
     todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", _obj(src)]
+        stem = os.path.basename(src)[:-4]
+        extra = os.environ.get("DWS_HIPCC_FLAGS_" + stem)      # experiments: override a file's extra flags
+        extra = FILE_FLAGS.get(stem, []) if extra is None else extra.split()
+        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         proc = subprocess.run(cmd, capture_output=True, text=True)
@@ -70,4 +77,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in os.sys.argv, verbose=True))
+    print(build(force="--force" in os.sys.argv, verbose="-v" in os.sys.argv))

@@ -18,279 +18,212 @@
 // patterns are bank-conflict free for ds_read_b64 / ds_write_b64.
 #include "fftconv.h"
 
+#include "fft_core.h"
+
 namespace dws {
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul_(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-__device__ __forceinline__ float2 mul_pos_i(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
-__device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
 __device__ __forceinline__ float gelu_f(float x) { return dws_gelu(x); }
-
-// W_16^k = exp(-2 pi i k / 16), k = 0..7
-__device__ __forceinline__ float2 w16(int k) {
-    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r = 0.70710678118654752440f;
-    switch (k & 7) {
-        case 0: return make_float2(1.f, 0.f);
-        case 1: return make_float2(c1, -s1);
-        case 2: return make_float2(r, -r);
-        case 3: return make_float2(s1, -c1);
-        case 4: return make_float2(0.f, -1.f);
-        case 5: return make_float2(-s1, -c1);
-        case 6: return make_float2(-r, -r);
-        default: return make_float2(-c1, -s1);
-    }
-}
-
-// 16-point transforms on registers (the lowest four index bits).
-template <bool INV>
-__device__ __forceinline__ void fft16_regs(float2 (&x)[16]) {
-    if (!INV) {  // DIF: spans 8,4,2,1 ; x[i+h] = (u - v) * W_{2h}^{i mod h}
-#pragma unroll
-        for (int h = 8; h >= 1; h >>= 1) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if ((i & h) == 0) {
-                    const float2 u = x[i], v = x[i + h];
-                    x[i] = cadd(u, v);
-                    x[i + h] = cmul_(csub(u, v), w16((i & (h - 1)) * (8 / h)));
-                }
-            }
-        }
-    } else {  // DIT: spans 1,2,4,8 ; v = x[i+h] * conj(W_{2h}^{i mod h})
-#pragma unroll
-        for (int h = 1; h <= 8; h <<= 1) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if ((i & h) == 0) {
-                    const float2 u = x[i], v = cmulc(x[i + h], w16((i & (h - 1)) * (8 / h)));
-                    x[i] = cadd(u, v);
-                    x[i + h] = csub(u, v);
-                }
-            }
-        }
-    }
-}
-
-// One fused radix-4 pass over index bits (log2(s)+1, log2(s)).  Butterfly t uses W_{4s}^j, j = t mod s;
-// the caller supplies it from registers (w[i] for this thread's i-th butterfly): the twiddles of ALL
-// passes are fetched once at kernel start (radix4_twiddles) instead of one L2 round trip per pass.
-template <int LOG2M, int THREADS, bool INV, bool TOPPASS>
-__device__ __forceinline__ void radix4_pass(float2* __restrict__ X, const float2* __restrict__ tw, float2 wreg,
-                                            int log2s, int tid) {
-    constexpr int M = 1 << LOG2M;
-    const int s = 1 << log2s;
-    const int twstep = M >> (log2s + 2);  // W_{4s}^j = tw[j * M/(4s)]
-#pragma unroll 1
-    for (int t = tid; t < M / 4; t += THREADS) {
-        const int j = t & (s - 1);
-        const int base = ((t >> log2s) << (log2s + 2)) + j;
-        const float2 w1 = TOPPASS ? tw[j * twstep] : wreg;   // narrower passes: j = tid mod s, fetched at kernel start
-        const float2 w2 = cmul_(w1, w1);
-        float2 x0 = X[pidx(base)], x1 = X[pidx(base + s)], x2 = X[pidx(base + 2 * s)], x3 = X[pidx(base + 3 * s)];
-        if (!INV) {
-            // stage h = 2s: pairs (0,2) tw w1, (1,3) tw w1 * (-i); stage h = s: pairs (0,1), (2,3) tw w2
-            const float2 a0 = cadd(x0, x2), a2 = cmul_(csub(x0, x2), w1);
-            const float2 a1 = cadd(x1, x3), a3 = cmul_(mul_neg_i(csub(x1, x3)), w1);
-            x0 = cadd(a0, a1);
-            x1 = cmul_(csub(a0, a1), w2);
-            x2 = cadd(a2, a3);
-            x3 = cmul_(csub(a2, a3), w2);
-        } else {
-            // stage h = s first (conj w2), then h = 2s (conj w1, and +i for the odd pair)
-            const float2 v1 = cmulc(x1, w2), v3 = cmulc(x3, w2);
-            const float2 a0 = cadd(x0, v1), a1 = csub(x0, v1), a2 = cadd(x2, v3), a3 = csub(x2, v3);
-            const float2 b2 = cmulc(a2, w1), b3 = mul_pos_i(cmulc(a3, w1));
-            x0 = cadd(a0, b2);
-            x2 = csub(a0, b2);
-            x1 = cadd(a1, b3);
-            x3 = csub(a1, b3);
-        }
-        X[pidx(base)] = x0; X[pidx(base + s)] = x1; X[pidx(base + 2 * s)] = x2; X[pidx(base + 3 * s)] = x3;
-    }
-}
-
-// Register-resident twiddles of the narrower radix-4 passes.  With THREADS = M/16 a thread owns
-// butterflies t = tid + i*THREADS (i < 4).  In the widest pass (s = M/4 or M/8) j = t mod s differs per
-// i and is read from the table in the pass; in every narrower pass s <= THREADS, so j = tid mod s for
-// all i -> ONE value per pass, fetched once at kernel start and reused by forward and inverse.
-template <int LOG2M, int THREADS>
-struct FftTw {
-    static constexpr int M = 1 << LOG2M;
-    static constexpr bool ODD = ((LOG2M - 4) & 1) != 0;
-    static constexpr int TOP = LOG2M - (ODD ? 3 : 2);         // log2(s) of the widest radix-4 pass
-    static constexpr int NLOW = (TOP - 4) / 2;                // narrower passes: log2s = TOP-2, ..., 4
-    static constexpr int NBF = M / 4 / THREADS;
-    float2 wlow[NLOW > 0 ? NLOW : 1];
-    __device__ __forceinline__ void load(const float2* __restrict__ tw, int tid) {
-#pragma unroll
-        for (int p = 0; p < NLOW; ++p) {
-            const int log2s = TOP - 2 * (p + 1);
-            wlow[p] = tw[(tid & ((1 << log2s) - 1)) * (M >> (log2s + 2))];
-        }
-    }
-};
-
-template <int LOG2M, int THREADS, bool INV>
-__device__ __forceinline__ void radix2_top_pass(float2* __restrict__ X, const float2* __restrict__ tw, int tid) {
-    constexpr int M = 1 << LOG2M, h = M / 2;
-    for (int t = tid; t < h; t += THREADS) {
-        const float2 u = X[pidx(t)], v = X[pidx(t + h)];
-        if (!INV) {
-            X[pidx(t)] = cadd(u, v);
-            X[pidx(t + h)] = cmul_(csub(u, v), tw[t]);
-        } else {
-            const float2 vv = cmulc(v, tw[t]);
-            X[pidx(t)] = cadd(u, vv);
-            X[pidx(t + h)] = csub(u, vv);
-        }
-    }
-}
-
-template <int LOG2M, int THREADS, bool INV>
-__device__ __forceinline__ void low16_pass(float2* __restrict__ X, int tid) {
-    constexpr int M = 1 << LOG2M;
-    for (int t = tid; t < M / 16; t += THREADS) {
-        float2 x[16];
-#pragma unroll
-        for (int d = 0; d < 16; ++d) x[d] = X[17 * t + d];  // pidx(16 t + d) = 17 t + d
-        fft16_regs<INV>(x);
-#pragma unroll
-        for (int d = 0; d < 16; ++d) X[17 * t + d] = x[d];
-    }
-}
-
-template <int LOG2M, int THREADS>
-__device__ __forceinline__ void fft_forward(float2* X, const float2* tw, const FftTw<LOG2M, THREADS>& W, int tid) {
-    using F = FftTw<LOG2M, THREADS>;
-    static_assert(F::NBF * THREADS * 4 == (1 << LOG2M), "one 16-point group per thread");
-    if (F::ODD) {
-        radix2_top_pass<LOG2M, THREADS, false>(X, tw, tid);
-        __syncthreads();
-    }
-    radix4_pass<LOG2M, THREADS, false, true>(X, tw, make_float2(0.f, 0.f), F::TOP, tid);
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < F::NLOW; ++p) {
-        radix4_pass<LOG2M, THREADS, false, false>(X, tw, W.wlow[p], F::TOP - 2 * (p + 1), tid);
-        __syncthreads();
-    }
-    low16_pass<LOG2M, THREADS, false>(X, tid);
-    __syncthreads();
-}
-
-template <int LOG2M, int THREADS>
-__device__ __forceinline__ void fft_inverse(float2* X, const float2* tw, const FftTw<LOG2M, THREADS>& W, int tid) {
-    using F = FftTw<LOG2M, THREADS>;
-    low16_pass<LOG2M, THREADS, true>(X, tid);
-    __syncthreads();
-#pragma unroll
-    for (int p = F::NLOW - 1; p >= 0; --p) {
-        radix4_pass<LOG2M, THREADS, true, false>(X, tw, W.wlow[p], F::TOP - 2 * (p + 1), tid);
-        __syncthreads();
-    }
-    radix4_pass<LOG2M, THREADS, true, true>(X, tw, make_float2(0.f, 0.f), F::TOP, tid);
-    __syncthreads();
-    if (F::ODD) {
-        radix2_top_pass<LOG2M, THREADS, true>(X, tw, tid);
-        __syncthreads();
-    }
-}
-
 __device__ __forceinline__ int brev(int k, int bits) { return (int)(__brev((unsigned)k) >> (32 - bits)); }
 
-// Pointwise stage in bit-reversed order.  Pair q <-> positions p = 2q (k = brev(p) < M/2) and the
-// position of M - k.  With N = 2M, Wk = exp(-2 pi i k / N):
-//   Xe = (Zk + conj Zm)/2, Xo = -(i/2)(Zk - conj Zm), t = Wk Xo
-//   A[k] = Xe + t, A[M-k] = conj(Xe - t);  Y = A * Kf
-//   Ye = (Yk + conj Ym)/2, Yo = (Yk - conj Ym)/2 * conj(Wk);  Zy[k] = Ye + i Yo, Zy[M-k] = conj(Ye - i Yo)
+// Forward passes P0 .. of the plan on an LDS-resident row (a barrier after each).  A thread owns the NG groups
+// g = tid + i*THREADS, THREADS = M/16/NG.
+template <int LOG2M, int NG, int P0>
+__device__ __forceinline__ void fft_forward_from(float2* X, const FftTw<LOG2M, NG>& W, int tid) {
+    using P = FftPlan<LOG2M>;
+    constexpr int THREADS = (P::M / 16) / NG;
+    if constexpr (P0 < P::N16) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            if (i) __builtin_amdgcn_sched_barrier(0);   // one group's 16 points in registers at a time
+            pass16_lds<LOG2M, P::b0(P0), false>(X, W.theta[P0][i], tid + i * THREADS);
+        }
+        __syncthreads();
+        fft_forward_from<LOG2M, NG, P0 + 1>(X, W, tid);
+    } else if constexpr (P::TAIL4) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) pass4_lds<false>(X, tid + i * THREADS);
+        __syncthreads();
+    }
+}
+
+// Inverse passes in mirrored order down to (and including) radix-16 pass P0.
+template <int LOG2M, int NG, int P0, int PCUR>
+__device__ __forceinline__ void fft_inverse_passes(float2* X, const FftTw<LOG2M, NG>& W, int tid) {
+    constexpr int THREADS = (FftPlan<LOG2M>::M / 16) / NG;
+    if constexpr (PCUR > P0) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            if (i) __builtin_amdgcn_sched_barrier(0);
+            pass16_lds<LOG2M, FftPlan<LOG2M>::b0(PCUR - 1), true>(X, W.theta[PCUR - 1][i], tid + i * THREADS);
+        }
+        __syncthreads();
+        fft_inverse_passes<LOG2M, NG, P0, PCUR - 1>(X, W, tid);
+    }
+}
+
+template <int LOG2M, int NG, int P0>
+__device__ __forceinline__ void fft_inverse_to(float2* X, const FftTw<LOG2M, NG>& W, int tid) {
+    using P = FftPlan<LOG2M>;
+    constexpr int THREADS = (P::M / 16) / NG;
+    if constexpr (P::TAIL4) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) pass4_lds<true>(X, tid + i * THREADS);
+        __syncthreads();
+    }
+    fft_inverse_passes<LOG2M, NG, P0, P::N16>(X, W, tid);
+}
+
+// Whole transforms of an LDS-resident row; the caller has synchronised after filling X.
+template <int LOG2M, int NG>
+__device__ __forceinline__ void fft_forward(float2* X, const float2* tw, const FftTw<LOG2M, NG>& W, int tid) {
+    constexpr int THREADS = (1 << LOG2M) / 16 / NG;
+    if constexpr (FftPlan<LOG2M>::ODD) {
+        for (int t = tid; t < (1 << LOG2M) / 2; t += THREADS) pass2_top<LOG2M, false>(X, tw, t);
+        __syncthreads();
+    }
+    fft_forward_from<LOG2M, NG, 0>(X, W, tid);
+}
+
+template <int LOG2M, int NG>
+__device__ __forceinline__ void fft_inverse(float2* X, const float2* tw, const FftTw<LOG2M, NG>& W, int tid) {
+    constexpr int THREADS = (1 << LOG2M) / 16 / NG;
+    fft_inverse_to<LOG2M, NG, 0>(X, W, tid);
+    if constexpr (FftPlan<LOG2M>::ODD) {
+        for (int t = tid; t < (1 << LOG2M) / 2; t += THREADS) pass2_top<LOG2M, true>(X, tw, t);
+        __syncthreads();
+    }
+}
+
+// Pointwise stage in bit-reversed order (fft_core.h: pointwise_pair / pointwise_self), M/2 pairs over the workgroup.
 template <int LOG2M, int THREADS>
 __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const float2* __restrict__ twp,
                                                 const float2* __restrict__ kfa, const float2* __restrict__ kfb,
-                                                const float2* __restrict__ kfs, int tid, float csign) {
+                                                const float2* __restrict__ kfs, int tid_in, float csign) {
     constexpr int M = 1 << LOG2M;
+    // opaque: the pair addresses are invariant over the rows a workgroup walks; hoisted out of that loop they would
+    // occupy ~5 VGPRs per pair for the kernel's lifetime
+    const int tid = opaque(tid_in);
 #pragma unroll 1
     for (int it = 0; it < M / 2 / THREADS; ++it) {
         const int q = tid + it * THREADS;
-        const int p = 2 * q;
         if (q == 0) {
-            // k = 0 (self-paired, carries DC and Nyquist) and k = M/2 (position 1, self-paired)
-            const float2 z0 = X[pidx(0)];
-            const float y0 = (z0.x + z0.y) * kfs[0].x;   // A[0] = Re+Im, real; irfft ignores Im of DC / Nyquist
-            const float ym = (z0.x - z0.y) * kfs[1].x;   // A[M] = Re-Im
-            X[pidx(0)] = make_float2(0.5f * (y0 + ym), 0.5f * (y0 - ym));
-            X[pidx(1)] = cmulc(X[pidx(1)], make_float2(kfs[2].x, csign * kfs[2].y));  // Zy[M/2] = Z[M/2] * conj(Kf[M/2])
+            float2 z0 = X[pidx(0)], z1 = X[pidx(1)];
+            pointwise_self(z0, z1, kfs[0], kfs[1], kfs[2], csign);
+            X[pidx(0)] = z0;
+            X[pidx(1)] = z1;
             continue;
         }
-        const int k = brev(p, LOG2M);
-        const int pm = brev(M - k, LOG2M);
-        const float2 zk = X[pidx(p)], zm = X[pidx(pm)];
-        const float2 wk = twp[q];
-        const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);           // Zk - conj Zm
-        const float2 xo = make_float2(0.5f * d.y, -0.5f * d.x);           // -(i/2) d
-        const float2 t = cmul_(wk, xo);
-        const float2 ak = cadd(xe, t), am = cconj(csub(xe, t));
-        const float2 ka = kfa[q], kb = kfb[q];   // csign = -1: conj(K_f), the adjoint of the convolution
-        const float2 yk = cmul_(ak, make_float2(ka.x, csign * ka.y)), ym = cmul_(am, make_float2(kb.x, csign * kb.y));
-        const float2 ye = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
-        const float2 e = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));  // (Yk - conj Ym)/2
-        const float2 yo = cmulc(e, wk);
-        const float2 iyo = mul_pos_i(yo);
-        X[pidx(p)] = cadd(ye, iyo);
-        X[pidx(pm)] = cconj(csub(ye, iyo));
+        const int p = 2 * q;
+        const int pm = brev(M - brev(p, LOG2M), LOG2M);
+        float2 zk = X[pidx(p)], zm = X[pidx(pm)];
+        pointwise_pair(zk, zm, twp[q], kfa[q], kfb[q], csign);
+        X[pidx(p)] = zk;
+        X[pidx(pm)] = zm;
     }
 }
 
+// Row schedule: a persistent grid whose block b sits on XCD b % 8 (observed dispatch order); every XCD gets a contiguous
+// range of rows, i.e. whole channels -- the rows of one channel share K_f, which then lives in ONE L2.
+struct RowSchedule {
+    int first, end, step;
+    __device__ __forceinline__ RowSchedule(int rows) {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, per_xcd = (rows + 7) >> 3;
+        first = xcd * per_xcd + (blockIdx.x >> 3);
+        end = min(rows, (xcd + 1) * per_xcd);
+        step = nwg >> 3;    // the launcher makes nwg a multiple of 8
+    }
+};
+
 // g[b,h,:] = GELU(conv(u, K_h)[:L] + D[h] * u)
+//
+// Even sizes: the top radix-16 pass works straight from / to global memory -- a thread's 16 points are tid + THREADS*r,
+// of which r >= 8 are the zero padding (never loaded) on the way in and never needed on the way out.
 template <int LOG2M, int THREADS>
 __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
+    using P = FftPlan<LOG2M>;
     constexpr int M = 1 << LOG2M;
+    constexpr bool DIRECT = !P::ODD;
     extern __shared__ __attribute__((aligned(16))) float2 X[];  // M + M/16 complex
     const int tid = threadIdx.x;
-    // rows of one channel h are adjacent in the launch order (the kernel spectrum is shared by the batch)
-    const int row = blockIdx.x;
-    const int h = row / a.B, b = row % a.B;
     const int L = a.L, Lc = L / 2;  // L even
-    const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
-    FftTw<LOG2M, THREADS> W;
+    constexpr int NG = (1 << LOG2M) / 16 / THREADS;
+    FftTw<LOG2M, NG> W;
     W.load(a.tw, tid);
-    for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
-    __syncthreads();
-    fft_forward<LOG2M, THREADS>(X, a.tw, W, tid);
-    pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
-                                    a.kfs + (size_t)h * 3, tid, a.conj_k ? -1.f : 1.f);
-    __syncthreads();
-    fft_inverse<LOG2M, THREADS>(X, a.tw, W, tid);
-    const float scale = 1.f / (float)M, Dh = a.D[h];
-    float2* __restrict__ g2 = reinterpret_cast<float2*>(a.g + ((size_t)b * a.H + h) * L);
-    float2* __restrict__ p2 = a.pre ? reinterpret_cast<float2*>(a.pre + ((size_t)b * a.H + h) * L) : nullptr;
-    for (int j = tid; j < Lc; j += THREADS) {
-        const float2 y = X[pidx(j)], uu = u2[j];
-        const float2 v = make_float2(fmaf(y.x, scale, Dh * uu.x), fmaf(y.y, scale, Dh * uu.y));
-        if (p2) p2[j] = v;
-        g2[j] = a.no_act ? v : make_float2(gelu_f(v.x), gelu_f(v.y));
+    const float scale = 1.f / (float)M, csign = a.conj_k ? -1.f : 1.f;
+    const RowSchedule sch(a.B * a.H);
+#pragma unroll 1
+    for (int row = sch.first; row < sch.end; row += sch.step) {
+        // rows of one channel h are adjacent (the kernel spectrum is shared by the batch)
+        const int h = row / a.B, b = row % a.B;
+        const size_t off = ((size_t)b * a.H + h) * L;
+        const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + off);
+        if constexpr (DIRECT) {
+            float2 x[16];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + THREADS * r;
+                x[r] = (i < Lc) ? u2[i] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 8; r < 16; ++r) x[r] = make_float2(0.f, 0.f);
+            fft16<false, true, true>(x, W.theta[0][0]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[pidx(tid + THREADS * r)] = x[r];
+            __syncthreads();
+            fft_forward_from<LOG2M, 1, 1>(X, W, tid);
+        } else {
+            for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
+            __syncthreads();
+            fft_forward<LOG2M, NG>(X, a.tw, W, tid);
+        }
+        pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
+                                        a.kfs + (size_t)h * 3, tid, csign);
+        __syncthreads();
+        const float Dh = a.D[h];
+        float2* __restrict__ g2 = reinterpret_cast<float2*>(a.g + off);
+        float2* __restrict__ p2 = a.pre ? reinterpret_cast<float2*>(a.pre + off) : nullptr;
+        auto finish = [&](int j, float2 y) {
+            const float2 uu = u2[j];
+            const float2 v = make_float2(fmaf(y.x, scale, Dh * uu.x), fmaf(y.y, scale, Dh * uu.y));
+            if (p2) p2[j] = v;
+            g2[j] = a.no_act ? v : make_float2(gelu_f(v.x), gelu_f(v.y));
+        };
+        if constexpr (DIRECT) {
+            fft_inverse_to<LOG2M, 1, 1>(X, W, tid);
+            float2 x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = X[pidx(tid + THREADS * r)];
+            fft16<true, true, false, true>(x, W.theta[0][0]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + THREADS * r;
+                if (i < Lc) finish(i, x[r]);
+            }
+        } else {
+            fft_inverse<LOG2M, NG>(X, a.tw, W, tid);
+            for (int j = tid; j < Lc; j += THREADS) finish(j, X[pidx(j)]);
+        }
+        __syncthreads();   // the next row overwrites X
     }
 }
 
 // Kernel-gradient partials (FftCorrArgs): the block owns channel h and a chunk of the batch; per sample it
 // transforms u then dA through the same LDS FFT and accumulates conj(U) * dA for the bins its threads own.
+// At M = 16384 the accumulators, the bins of U and a radix-16 pass do not fit in the 128 VGPRs of a 1024-thread workgroup:
+// that size runs with 512 threads (two 16-point groups per thread and pass, 256 VGPRs) and parks the bins of U in the
+// block's own output slab (coalesced, re-read by the thread that wrote them; results overwrite it after the last sample).
 template <int LOG2M, int THREADS>
 __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
     constexpr int M = 1 << LOG2M, NP = M / 2 / THREADS;
     extern __shared__ __attribute__((aligned(16))) float2 X[];
-    const int tid = threadIdx.x, h = blockIdx.x, bs = blockIdx.y;
+    const int tid0 = threadIdx.x, h = blockIdx.x, bs = blockIdx.y;
     const int L = a.L, Lc = L / 2;
-    FftTw<LOG2M, THREADS> W;
-    W.load(a.tw, tid);
-    float2 ua[NP], ub[NP], pa[NP], pb[NP];
+    constexpr int NG = (1 << LOG2M) / 16 / THREADS;
+    FftTw<LOG2M, NG> W;
+    W.load(a.tw, tid0);
+    constexpr bool PARK = LOG2M >= 14;
+    float2 ua[PARK ? 1 : NP], ub[PARK ? 1 : NP], pa[NP], pb[NP];
+    float2* __restrict__ o = a.part + ((size_t)bs * a.H + h) * (M + 1);
     float u0 = 0.f, uM = 0.f, p0 = 0.f, pM = 0.f;
     float2 uh = make_float2(0.f, 0.f), ph = make_float2(0.f, 0.f);
 #pragma unroll
@@ -311,25 +244,37 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
     };
 #pragma unroll 1
     for (int b = bs * a.bchunk; b < b_end; ++b) {
+        // opaque copies of the thread index per phase: addresses derived from it (pair positions, table offsets) are
+        // loop invariant and would otherwise be hoisted and kept in ~100 VGPRs across the transforms
+        int tid = opaque(tid0);
         const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
         const float2* __restrict__ d2 = reinterpret_cast<const float2*>(a.da + ((size_t)b * a.H + h) * L);
         for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
         __syncthreads();
-        fft_forward<LOG2M, THREADS>(X, a.tw, W, tid);
+        fft_forward<LOG2M, NG>(X, a.tw, W, tid);
+        tid = opaque(tid0);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int q = tid + i * THREADS;
             if (q == 0) {
                 const float2 z0 = X[pidx(0)];
                 u0 = z0.x + z0.y; uM = z0.x - z0.y; uh = cconj(X[pidx(1)]);   // A[0], A[M], A[M/2]
+            } else if (PARK) {
+                float2 k1, k2;
+                bins(q, k1, k2);
+                o[q] = k1;
+                o[M / 2 + q] = k2;
             } else {
                 bins(q, ua[i], ub[i]);
             }
+            if (NP > 8 && (i & 1)) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight (registers)
         }
         __syncthreads();
+        tid = opaque(tid0);
         for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? d2[j] : make_float2(0.f, 0.f);
         __syncthreads();
-        fft_forward<LOG2M, THREADS>(X, a.tw, W, tid);
+        fft_forward<LOG2M, NG>(X, a.tw, W, tid);
+        tid = opaque(tid0);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int q = tid + i * THREADS;
@@ -341,16 +286,17 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
             } else {
                 float2 dk, dm;
                 bins(q, dk, dm);
-                pa[i] = cadd(pa[i], cmulc(dk, ua[i]));   // dA * conj(U)
-                pb[i] = cadd(pb[i], cmulc(dm, ub[i]));
+                const float2 uka = PARK ? o[q] : ua[i], ukb = PARK ? o[M / 2 + q] : ub[i];
+                pa[i] = cadd(pa[i], cmulc(dk, uka));   // dA * conj(U)
+                pb[i] = cadd(pb[i], cmulc(dm, ukb));
             }
+            if (NP > 8 && (i & 1)) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
-    float2* __restrict__ o = a.part + ((size_t)bs * a.H + h) * (M + 1);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int q = tid + i * THREADS;
+        const int q = tid0 + i * THREADS;
         if (q == 0) {
             o[0] = make_float2(p0, 0.f);
             o[M] = make_float2(pM, 0.f);
@@ -373,11 +319,12 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float2 X[];
     const int tid = threadIdx.x, h = blockIdx.x;
     const float2* __restrict__ r2 = reinterpret_cast<const float2*>(in + (size_t)h * 2 * M);
-    FftTw<LOG2M, THREADS> W;
+    constexpr int NG = (1 << LOG2M) / 16 / THREADS;
+    FftTw<LOG2M, NG> W;
     W.load(tw, tid);
     for (int j = tid; j < M; j += THREADS) X[pidx(j)] = r2[j];
     __syncthreads();
-    fft_forward<LOG2M, THREADS>(X, tw, W, tid);
+    fft_forward<LOG2M, NG>(X, tw, W, tid);
     float2* __restrict__ o = out + (size_t)h * (M + 1);
     for (int k = tid; k <= M / 2; k += THREADS) {
         if (k == 0) {
@@ -446,6 +393,17 @@ bool fftconv_supported(int L, int* log2m) {
     return true;
 }
 
+static int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 template <int LOG2M>
 static int launch_fc(const FftConvArgs& a, hipStream_t s) {
     using C = FcCfg<LOG2M>;
@@ -455,20 +413,25 @@ static int launch_fc(const FftConvArgs& a, hipStream_t s) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(C::THREADS), C::LDS, s, a);
+    // one resident workgroup per LDS slot of every CU walks several rows (RowSchedule); small rows: one row per block
+    const int rows = a.B * a.H;
+    const int slots = cu_count() * std::max(1, std::min((int)(160 * 1024 / C::LDS), 2048 / C::THREADS));
+    const int nwg = (std::min(rows, LOG2M >= 13 ? slots : rows) + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(C::THREADS), C::LDS, s, a);
     return DWS_OK;
 }
 
 template <int LOG2M>
 static int launch_fcorr(const FftCorrArgs& a, hipStream_t s) {
     using C = FcCfg<LOG2M>;
-    auto kern = fftcorr_kernel<LOG2M, C::THREADS>;
+    constexpr int TH = C::THREADS > 512 ? 512 : C::THREADS;
+    auto kern = fftcorr_kernel<LOG2M, TH>;
     static bool attr = false;
     if (!attr) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.H, ceil_div(a.B, a.bchunk)), dim3(C::THREADS), C::LDS, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.H, ceil_div(a.B, a.bchunk)), dim3(TH), C::LDS, s, a);
     return DWS_OK;
 }
 

@@ -1,0 +1,157 @@
+// Host emulation of a workgroup running the FFT core of the S4 convolution kernels (csrc/fft_core.h), thread by thread
+// and pass by pass (a loop over the thread index stands in for the barrier between passes).  Test infrastructure:
+// built by tests/test_fft_core_cpu.py with g++, compared against numpy there.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../diffwave-sashimi_amd/csrc/fft_core.h"
+
+using namespace dws;
+
+template <int LOG2M, int P0>
+static void fwd_from(float2* X, const float2* tw) {
+    using P = FftPlan<LOG2M>;
+    constexpr int T = (1 << LOG2M) / 16;
+    if constexpr (P0 < P::N16) {
+        for (int tid = 0; tid < T; ++tid) {
+            FftTw<LOG2M> W;
+            W.load(tw, tid);
+            pass16_lds<LOG2M, P::b0(P0), false>(X, W.theta[P0][0], tid);
+        }
+        fwd_from<LOG2M, P0 + 1>(X, tw);
+    } else if constexpr (P::TAIL4) {
+        for (int tid = 0; tid < T; ++tid) pass4_lds<false>(X, tid);
+    }
+}
+
+template <int LOG2M, int P0, int PCUR>
+static void inv_passes(float2* X, const float2* tw) {
+    constexpr int T = (1 << LOG2M) / 16;
+    if constexpr (PCUR > P0) {
+        for (int tid = 0; tid < T; ++tid) {
+            FftTw<LOG2M> W;
+            W.load(tw, tid);
+            pass16_lds<LOG2M, FftPlan<LOG2M>::b0(PCUR - 1), true>(X, W.theta[PCUR - 1][0], tid);
+        }
+        inv_passes<LOG2M, P0, PCUR - 1>(X, tw);
+    }
+}
+
+template <int LOG2M, int P0>
+static void inv_to(float2* X, const float2* tw) {
+    using P = FftPlan<LOG2M>;
+    constexpr int T = (1 << LOG2M) / 16;
+    if constexpr (P::TAIL4)
+        for (int tid = 0; tid < T; ++tid) pass4_lds<true>(X, tid);
+    inv_passes<LOG2M, P0, P::N16>(X, tw);
+}
+
+template <int LOG2M>
+static void forward_lds(float2* X, const float2* tw) {
+    constexpr int M = 1 << LOG2M;
+    if constexpr (FftPlan<LOG2M>::ODD)
+        for (int t = 0; t < M / 2; ++t) pass2_top<LOG2M, false>(X, tw, t);
+    fwd_from<LOG2M, 0>(X, tw);
+}
+
+template <int LOG2M>
+static void inverse_lds(float2* X, const float2* tw) {
+    constexpr int M = 1 << LOG2M;
+    inv_to<LOG2M, 0>(X, tw);
+    if constexpr (FftPlan<LOG2M>::ODD)
+        for (int t = 0; t < M / 2; ++t) pass2_top<LOG2M, true>(X, tw, t);
+}
+
+// complex transform, natural order in, BIT-REVERSED order out (forward) / the reverse (inverse, unnormalised)
+template <int LOG2M>
+static void transform(float* data, const float* tw, int inverse) {
+    constexpr int M = 1 << LOG2M;
+    std::vector<float2> X(M + M / 16);
+    float2* d = reinterpret_cast<float2*>(data);
+    for (int i = 0; i < M; ++i) X[pidx(i)] = d[i];
+    if (inverse) inverse_lds<LOG2M>(X.data(), reinterpret_cast<const float2*>(tw));
+    else forward_lds<LOG2M>(X.data(), reinterpret_cast<const float2*>(tw));
+    for (int i = 0; i < M; ++i) d[i] = X[pidx(i)];
+}
+
+// One row of fftconv_kernel: out[0..L) = conv part only (scaled by 1/M), as the kernel sequences it -- for even sizes the
+// top radix-16 pass runs on registers straight from the (zero padded) input and straight to the output.
+template <int LOG2M>
+static void conv_row(const float* u, int L, const float* tw_, const float* twp_, const float* kfa_, const float* kfb_,
+                     const float* kfs_, float csign, float* out) {
+    using P = FftPlan<LOG2M>;
+    constexpr int M = 1 << LOG2M, T = M / 16;
+    const int Lc = L / 2;
+    const float2* u2 = reinterpret_cast<const float2*>(u);
+    const float2 *tw = reinterpret_cast<const float2*>(tw_), *twp = reinterpret_cast<const float2*>(twp_);
+    const float2 *kfa = reinterpret_cast<const float2*>(kfa_), *kfb = reinterpret_cast<const float2*>(kfb_);
+    const float2* kfs = reinterpret_cast<const float2*>(kfs_);
+    float2* o2 = reinterpret_cast<float2*>(out);
+    std::vector<float2> X(M + M / 16);
+    if constexpr (!P::ODD) {
+        for (int tid = 0; tid < T; ++tid) {
+            FftTw<LOG2M> W;
+            W.load(tw, tid);
+            float2 x[16];
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + T * r;
+                x[r] = (i < Lc) ? u2[i] : make_float2(0.f, 0.f);
+            }
+            for (int r = 8; r < 16; ++r) x[r] = make_float2(0.f, 0.f);
+            fft16<false, true, true>(x, W.theta[0][0]);
+            for (int r = 0; r < 16; ++r) X[pidx(tid + T * r)] = x[r];
+        }
+        fwd_from<LOG2M, 1>(X.data(), tw);
+    } else {
+        for (int j = 0; j < M; ++j) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
+        forward_lds<LOG2M>(X.data(), tw);
+    }
+    for (int q = 0; q < M / 2; ++q) {
+        if (q == 0) {
+            pointwise_self(X[pidx(0)], X[pidx(1)], kfs[0], kfs[1], kfs[2], csign);
+            continue;
+        }
+        const int p = 2 * q;
+        const int pm = brev_bits(M - brev_bits(p, LOG2M), LOG2M);
+        pointwise_pair(X[pidx(p)], X[pidx(pm)], twp[q], kfa[q], kfb[q], csign);
+    }
+    const float scale = 1.f / (float)M;
+    if constexpr (!P::ODD) {
+        inv_to<LOG2M, 1>(X.data(), tw);
+        for (int tid = 0; tid < T; ++tid) {
+            FftTw<LOG2M> W;
+            W.load(tw, tid);
+            float2 x[16];
+            for (int r = 0; r < 16; ++r) x[r] = X[pidx(tid + T * r)];
+            fft16<true, true, false, true>(x, W.theta[0][0]);
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + T * r;
+                if (i < Lc) o2[i] = make_float2(x[r].x * scale, x[r].y * scale);
+            }
+        }
+    } else {
+        inverse_lds<LOG2M>(X.data(), tw);
+        for (int j = 0; j < Lc; ++j) o2[j] = make_float2(X[pidx(j)].x * scale, X[pidx(j)].y * scale);
+    }
+}
+
+#define DISPATCH(FN, ...)                      \
+    switch (log2m) {                           \
+        case 6: FN<6>(__VA_ARGS__); return 0;  \
+        case 7: FN<7>(__VA_ARGS__); return 0;  \
+        case 8: FN<8>(__VA_ARGS__); return 0;  \
+        case 10: FN<10>(__VA_ARGS__); return 0; \
+        case 11: FN<11>(__VA_ARGS__); return 0; \
+        case 12: FN<12>(__VA_ARGS__); return 0; \
+        case 13: FN<13>(__VA_ARGS__); return 0; \
+        case 14: FN<14>(__VA_ARGS__); return 0; \
+    }                                          \
+    return -1
+
+extern "C" int dws_host_fft(int log2m, float* data, const float* tw, int inverse) { DISPATCH(transform, data, tw, inverse); }
+
+extern "C" int dws_host_conv_row(int log2m, const float* u, int L, const float* tw, const float* twp, const float* kfa,
+                                 const float* kfb, const float* kfs, float csign, float* out) {
+    DISPATCH(conv_row, u, L, tw, twp, kfa, kfb, kfs, csign, out);
+}

@@ -1,0 +1,101 @@
+"""CPU: the FFT core of the S4 convolution kernels (csrc/fft_core.h: radix-16 register passes, bit-reversed spectrum,
+real-input pointwise stage) emulated on the host thread by thread (tests/native/fft_core_host.cpp, built here with g++)
+against numpy: the transforms themselves, and one row of `fftconv_kernel`'s sequence against the definition of the
+two-sided S4 convolution (`s4.py:1391-1406`) evaluated in float64."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+SRC = os.path.join(ROOT, "tests", "native", "fft_core_host.cpp")
+LIB = os.path.join(ROOT, "tests", "native", "libfft_core_host.so")
+
+
+@pytest.fixture(scope="module")
+def host():
+    hdr = os.path.join(ROOT, "diffwave-sashimi_amd", "csrc", "fft_core.h")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
+    lib = ctypes.CDLL(LIB)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.dws_host_fft.argtypes = [ctypes.c_int, fp, fp, ctypes.c_int]
+    lib.dws_host_conv_row.argtypes = [ctypes.c_int, fp, ctypes.c_int, fp, fp, fp, fp, fp, ctypes.c_float, fp]
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _brev(k, bits):
+    return int(format(k, f"0{bits}b")[::-1], 2) if bits else 0
+
+
+def _tables(lg):
+    """`build_fft_tables` / `kf_permute_kernel` of fftconv_kernels.hip, restated."""
+    M = 1 << lg
+    k = np.arange(M // 2)
+    tw = np.exp(-2j * np.pi * k / M).astype(np.complex64)
+    kk = np.array([_brev(2 * q, lg) for q in range(M // 2)])
+    twp = np.exp(-1j * np.pi * kk / M).astype(np.complex64)
+    return tw, twp, kk
+
+
+def _c2f(z):
+    return np.ascontiguousarray(z.astype(np.complex64)).view(np.float32)
+
+
+@pytest.mark.parametrize("lg", [6, 7, 8, 10, 11, 12, 13, 14])
+def test_forward_is_the_bit_reversed_dft_and_inverse_undoes_it(host, lg):
+    M = 1 << lg
+    rng = np.random.default_rng(lg)
+    x = (rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64)
+    tw, _, _ = _tables(lg)
+    d = _c2f(x).copy()
+    assert host.dws_host_fft(lg, _p(d), _p(_c2f(tw)), 0) == 0
+    got = d.view(np.complex64)
+    ref = np.fft.fft(x.astype(np.complex128))
+    perm = np.array([_brev(p, lg) for p in range(M)])
+    err = np.abs(got - ref[perm]).max() / np.abs(ref).max()
+    assert err < 2e-6, err
+    assert host.dws_host_fft(lg, _p(d), _p(_c2f(tw)), 1) == 0          # consumes the bit-reversed order
+    back = d.view(np.complex64) / M
+    assert np.abs(back - x).max() / np.abs(x).max() < 2e-6
+
+
+@pytest.mark.parametrize("lg,L", [(10, 1000), (10, 64), (12, 4000), (14, 16000), (14, 16384), (11, 1500), (13, 8000)])
+@pytest.mark.parametrize("csign", [1.0, -1.0])
+def test_convolution_row_matches_the_definition(host, lg, L, csign):
+    """y[i] = sum_j k0[j] u[i-j] + sum_{m>=1} k1[m-1] u[i+m] (csign = -1: the adjoint, i.e. correlation with the same
+    two-sided kernel), via the kernel's own sequence: half-size complex FFT of the packed real row, pointwise stage in
+    bit-reversed pair order against K_f of the re-placed two-sided kernel, mirrored inverse."""
+    M, Nf = 1 << lg, 2 << lg
+    rng = np.random.default_rng(100 * lg + L)
+    u = rng.standard_normal(L).astype(np.float32)
+    decay = np.exp(-np.arange(L) / (L / 6.0))
+    k0 = (rng.standard_normal(L) * decay).astype(np.float32)
+    k1 = (rng.standard_normal(L) * decay).astype(np.float32)
+    K = np.zeros(Nf)
+    K[:L] = k0
+    K[Nf - L:] = k1[::-1]                                          # K[Nf - m] = k1[m - 1], m = 1..L
+    Kf = np.fft.rfft(K)                                            # Nf/2 + 1 = M + 1 bins
+    tw, twp, kk = _tables(lg)
+    kfa, kfb = Kf[kk].astype(np.complex64), Kf[M - kk].astype(np.complex64)
+    kfa[0], kfb[0] = Kf[0], Kf[M]
+    kfs = np.array([Kf[0], Kf[M], Kf[M // 2]]).astype(np.complex64)
+    out = np.zeros(L, dtype=np.float32)
+    rc = host.dws_host_conv_row(lg, _p(u), L, _p(_c2f(tw)), _p(_c2f(twp)), _p(_c2f(kfa)), _p(_c2f(kfb)), _p(_c2f(kfs)),
+                                csign, _p(out))
+    assert rc == 0
+    U = np.fft.rfft(np.concatenate([u.astype(np.float64), np.zeros(Nf - L)]))
+    ref = np.fft.irfft(U * (Kf if csign > 0 else np.conj(Kf)), n=Nf)[:L]
+    if csign > 0 and L <= 4000:                                    # the FFT reference itself against the direct sums
+        k0d, k1d, ud = k0.astype(np.float64), k1.astype(np.float64), u.astype(np.float64)
+        direct = np.array([np.dot(k0d[:i + 1][::-1], ud[:i + 1]) + np.dot(k1d[:L - 1 - i], ud[i + 1:]) for i in range(L)])
+        assert np.abs(direct - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err < 5e-6, err
