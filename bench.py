@@ -164,6 +164,24 @@ def cpu_baseline(cfg, seconds_budget=25.0):
            "sample": f"{len(times)} forward steps at B=1, L={L} with {best} threads (best of a probe over 8..64), "
                      f"extrapolated to the T={T} loop",
            "ms_per_step_b1": per_step * 1e3, "cpu_model": _cpu_model()}
+    # the config's own batch (SURVEY.md 8d asks for B=1 and the config's B): one warm-up + up to 2 timed steps, bounded
+    Bc = cfg["B"]
+    if Bc > 1 and per_step * Bc < 40.0:
+        audio_b, steps_b = torch.randn(Bc, 1, L), torch.full((Bc, 1), float(T - 1))
+        mel_b = None if mel is None else mel.expand(Bc, -1, -1).contiguous()
+
+        def one_b():
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                fwd(sd, cfg["model"], audio_b, steps_b, mel_spec=mel_b)
+            return time.perf_counter() - t0
+
+        one_b()
+        tbs = [one_b()]
+        if tbs[0] < 15.0:
+            tbs.append(one_b())
+        tb = sum(tbs) / len(tbs)
+        out["at_config_batch"] = {"B": Bc, "value": Bc * L / (T * tb), "ms_per_step": tb * 1e3, "steps_timed": len(tbs)}
     if per_step * best < 20.0:     # single-thread figure when one step is predicted to fit in ~20 s
         torch.set_num_threads(1)
         t1 = one()

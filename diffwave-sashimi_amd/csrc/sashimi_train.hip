@@ -94,11 +94,98 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// The same adjoint with the block's x and dy columns held in registers: ONE pass over HBM (the kernel above reads both
+// tensors three times; its re-reads mostly miss: 64 positions x H channels x 2 tensors per block, 8 blocks per CU).
+// Block = 64 positions x PARTS channel groups, a thread owns RP = H / PARTS channels (h = part + PARTS * r).
+template <int RP, int PARTS>
+__global__ __launch_bounds__(64 * PARTS) void ln_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ m_p, const float* __restrict__ s_p,
+                                                              const float* __restrict__ base, float* __restrict__ out,
+                                                              int accumulate, float* __restrict__ partial, int L) {
+    constexpr int H = RP * PARTS;
+    __shared__ float red[4][PARTS][64];
+    __shared__ float cs[2][64];
+    const int b = blockIdx.y, col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int l = blockIdx.x * 64 + col;
+    const bool ok = l < L;
+    const size_t off = (size_t)b * H * L + (ok ? l : 0);
+    const float* __restrict__ xb = x + off;
+    const float* __restrict__ db = dy + off;
+    float xv[RP], dv[RP];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        xv[r] = xb[(size_t)(part + PARTS * r) * L];
+        dv[r] = db[(size_t)(part + PARTS * r) * L];
+    }
+    float sx = 0.f, sd = 0.f;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) { sx += xv[r]; sd += dv[r]; }
+    red[0][part][col] = sx;
+    red[1][part][col] = sd;
+    __syncthreads();
+    const float invH = 1.f / (float)H;
+    float mean = 0.f, sdy = 0.f;
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) { mean += red[0][q][col]; sdy += red[1][q][col]; }
+    mean *= invH;
+    float var = 0.f, sdx = 0.f;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        xv[r] -= mean;
+        var = fmaf(xv[r], xv[r], var);
+        sdx = fmaf(dv[r], xv[r], sdx);
+    }
+    red[2][part][col] = var;
+    red[3][part][col] = sdx;
+    __syncthreads();
+    var = 0.f; sdx = 0.f;
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) { var += red[2][q][col]; sdx += red[3][q][col]; }
+    const float sdv = sqrtf(var * invH), rs = 1.f / sdv;
+    const float m = m_p[0], s = s_p[0];
+    const float mdy = sdy * invH;
+    const float c2 = sdx * rs * invH + m * rs * mdy;
+    const float sc = s * rs;
+    if (ok) {
+        float* __restrict__ ob = out + off;
+        const float* __restrict__ bb = base ? base + off : nullptr;
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+            const size_t ho = (size_t)(part + PARTS * r) * L;
+            float v = sc * (dv[r] - mdy - (xv[r] * rs) * c2);
+            if (bb) v += bb[ho];
+            if (accumulate) v += ob[ho];
+            ob[ho] = v;
+        }
+    }
+    if (part == 0) {
+        cs[0][col] = ok ? sc * sdy : 0.f;                         // dm
+        cs[1][col] = ok ? sdx * rs + m * rs * sdy : 0.f;          // ds
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const float v = wave_sum_t(cs[threadIdx.x >> 6][threadIdx.x & 63]);
+        if ((threadIdx.x & 63) == 0)
+            partial[(size_t)(threadIdx.x >> 6) * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = v;
+    }
+}
+
 int launch_ln_bwd(const float* x, const float* dy, const float* m_p, const float* s_p, const float* base, float* out,
                   int accumulate, float* partial, int B, int H, int L, hipStream_t s) {
     ProfileScope ps("ln_bwd", s);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, dy, m_p, s_p, base, out, accumulate,
-                       partial, H, L);
+    const dim3 grid(ceil_div(L, 64), B);
+#define DWS_LN_BWD(RP, PARTS)                                                                                         \
+    hipLaunchKernelGGL((ln_bwd_reg_kernel<RP, PARTS>), grid, dim3(64 * PARTS), 0, s, x, dy, m_p, s_p, base, out, accumulate, \
+                       partial, L)
+    switch (H) {
+        case 32: DWS_LN_BWD(8, 4); return DWS_OK;
+        case 64: DWS_LN_BWD(16, 4); return DWS_OK;
+        case 128: DWS_LN_BWD(32, 4); return DWS_OK;
+        case 256: DWS_LN_BWD(32, 8); return DWS_OK;
+        case 512: DWS_LN_BWD(32, 16); return DWS_OK;
+    }
+#undef DWS_LN_BWD
+    hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(256), 0, s, x, dy, m_p, s_p, base, out, accumulate, partial, H, L);
     return DWS_OK;
 }
 
