@@ -36,6 +36,7 @@ DWS_HD float2 cmul_(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b
 DWS_HD float2 cmulc(float2 a, float2 b) {  // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
+DWS_HD float2 csqr(float2 a) { return make_float2(a.x * a.x - a.y * a.y, 2.f * a.x * a.y); }
 DWS_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 DWS_HD float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
 DWS_HD float2 mul_pos_i(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
@@ -138,12 +139,16 @@ DWS_HD float2 tw16(float2 theta) {
 template <bool INV, bool TW, bool ZERO_HI = false, bool LO_ONLY = false>
 DWS_HD void fft16(float2 (&x)[16], float2 theta_in) {
     const float2 theta = TW ? opaque(theta_in) : theta_in;
-    const float2 t2 = cmul_(theta, theta), t4 = cmul_(t2, t2), t8 = cmul_(t4, t4);   // dead code when !TW
+    const float2 t2 = csqr(theta), t4 = csqr(t2), t8 = csqr(t4);   // dead code when !TW
+    // w2 of butterfly r0 is w1^2 = theta^2 W_8^{r0}: {1, (1-i)/sqrt2, -i, -(1+i)/sqrt2} are cheaper than a squaring
+    constexpr float RH = 0.70710678118654752440f;
+    const float2 t2w[4] = {t2, make_float2(RH * (t2.x + t2.y), RH * (t2.y - t2.x)), mul_neg_i(t2),
+                           make_float2(RH * (t2.y - t2.x), -RH * (t2.x + t2.y))};
 #define DWS_STEP1(R0)                                                                                   \
     {                                                                                                   \
         const float2 w1 = tw16<TW, R0>(theta);                                                          \
-        const float2 w2 = TW ? cmul_(w1, w1) : (R0 == 0 ? make_float2(1.f, 0.f) : R0 == 1 ? w16c<2>()  \
-                                               : R0 == 2 ? make_float2(0.f, -1.f) : mul_neg_i(w16c<2>())); \
+        const float2 w2 = TW ? t2w[R0] : (R0 == 0 ? make_float2(1.f, 0.f) : R0 == 1 ? w16c<2>()         \
+                                          : R0 == 2 ? make_float2(0.f, -1.f) : mul_neg_i(w16c<2>()));   \
         if (!INV) {                                                                                     \
             if (ZERO_HI) bf4_fwd_zero_hi(x[R0], x[R0 + 4], x[R0 + 8], x[R0 + 12], w1, w2);              \
             else bf4<false>(x[R0], x[R0 + 4], x[R0 + 8], x[R0 + 12], w1, w2);                           \

@@ -151,19 +151,34 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     W.load(a.tw, tid);
     const float scale = 1.f / (float)M, csign = a.conj_k ? -1.f : 1.f;
     const RowSchedule sch(a.B * a.H);
+    // rows of one channel h are adjacent (the kernel spectrum is shared by the batch)
+    auto row_u = [&](int row) {
+        const int h = row / a.B, b = row % a.B;
+        return reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
+    };
+    constexpr bool PREFETCH = DIRECT && LOG2M >= 13;   // persistent sizes: a workgroup walks several rows
+    float2 xin[DIRECT ? 8 : 1];     // the next row's input points, fetched while the current row is finished
+    auto fetch = [&](int row) {
+        if constexpr (DIRECT) {
+            const float2* __restrict__ u2 = row_u(row);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + THREADS * r;
+                xin[r] = (i < Lc) ? u2[i] : make_float2(0.f, 0.f);
+            }
+        }
+    };
+    if (PREFETCH && sch.first < sch.end) fetch(sch.first);
 #pragma unroll 1
     for (int row = sch.first; row < sch.end; row += sch.step) {
-        // rows of one channel h are adjacent (the kernel spectrum is shared by the batch)
         const int h = row / a.B, b = row % a.B;
         const size_t off = ((size_t)b * a.H + h) * L;
         const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + off);
         if constexpr (DIRECT) {
+            if (!PREFETCH) fetch(row);
             float2 x[16];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = tid + THREADS * r;
-                x[r] = (i < Lc) ? u2[i] : make_float2(0.f, 0.f);
-            }
+            for (int r = 0; r < 8; ++r) x[r] = xin[r];
 #pragma unroll
             for (int r = 8; r < 16; ++r) x[r] = make_float2(0.f, 0.f);
             fft16<false, true, true>(x, W.theta[0][0]);
@@ -182,14 +197,15 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
         const float Dh = a.D[h];
         float2* __restrict__ g2 = reinterpret_cast<float2*>(a.g + off);
         float2* __restrict__ p2 = a.pre ? reinterpret_cast<float2*>(a.pre + off) : nullptr;
-        auto finish = [&](int j, float2 y) {
-            const float2 uu = u2[j];
+        auto finish = [&](int j, float2 y, float2 uu) {
             const float2 v = make_float2(fmaf(y.x, scale, Dh * uu.x), fmaf(y.y, scale, Dh * uu.y));
             if (p2) p2[j] = v;
             g2[j] = a.no_act ? v : make_float2(gelu_f(v.x), gelu_f(v.y));
         };
         if constexpr (DIRECT) {
             fft_inverse_to<LOG2M, 1, 1>(X, W, tid);
+            // the next row's input is in flight during the last pass and the GELU epilogue
+            if (PREFETCH && row + sch.step < sch.end) fetch(row + sch.step);
             float2 x[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = X[pidx(tid + THREADS * r)];
@@ -197,11 +213,11 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int i = tid + THREADS * r;
-                if (i < Lc) finish(i, x[r]);
+                if (i < Lc) finish(i, x[r], u2[i]);   // this row's input once more for the D u term (an L2 hit)
             }
         } else {
             fft_inverse<LOG2M, NG>(X, a.tw, W, tid);
-            for (int j = tid; j < Lc; j += THREADS) finish(j, X[pidx(j)]);
+            for (int j = tid; j < Lc; j += THREADS) finish(j, X[pidx(j)], u2[j]);
         }
         __syncthreads();   // the next row overwrites X
     }
