@@ -439,6 +439,21 @@ def main():
                 "hbm_achieved_GBs": bytes_ / (step_ms * 1e-3) / 1e9,
                 "note": "fp32 MFMA and VALU do not co-issue on gfx950 (DESIGN.md 6): the GELU/GLU/LN VALU work of the "
                         "tail adds to the MFMA time"}
+        # second kernel family of the step: the fused FFT long convolution, HBM-bound by design (8 H L bytes per block:
+        # the row is read once and written once), in fact limited by its LDS passes and butterflies
+        _lib.check(lib.dws_profile_enable(b"fftconv"))
+        _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, nprof, seed, 0, stream))
+        torch.cuda.synchronize()
+        _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
+        lib.dws_profile_disable()
+        if n_launch.value == nprof * nblocks and "roofline" in result:
+            fc_ms = tot_ms.value / nprof
+            fc_bytes = bytes_ * 8 // 12          # 8 H L per block against the tail's 12 H L
+            result["roofline"]["fftconv"] = {
+                "kernel": "fftconv_kernel<log2 M, M/16> (all %d block launches of a step)" % nblocks, "bound": "hbm",
+                "achieved": fc_bytes / (fc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": fc_bytes / (fc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "ms_per_step_in_kernel": fc_ms,
+                "algorithmic_bytes_per_step": fc_bytes}
     if (rank == 0 and world == 1 and args.precision == "f32" and cfg["model"]["_name_"] == "wavenet"
             and not args.no_roofline):
         # Additional, clearly separate measurement (NOT `value`): the opt-in bf16x3 matrix arithmetic

@@ -144,10 +144,18 @@ DWS_HD void fft16(float2 (&x)[16], float2 theta_in) {
     constexpr float RH = 0.70710678118654752440f;
     const float2 t2w[4] = {t2, make_float2(RH * (t2.x + t2.y), RH * (t2.y - t2.x)), mul_neg_i(t2),
                            make_float2(RH * (t2.y - t2.x), -RH * (t2.x + t2.y))};
+    // w2 = w1^2 by an actual squaring: deriving it as theta^2 W_8^{r0} saves ~8 instructions per pass, but on the GPU the
+    // SaShiMi parameter gradients (ill-conditioned through TransposedLN without eps) then drift from 0.9e-3 to 2.8e-3 of
+    // the reference (tests/test_sashimi_training_gpu.py, d32); the transform's own error is the same 4e-7 either way
+#if defined(DWS_FFT_TW_DERIVED)
+#define DWS_W2(R0) t2w[R0]
+#else
+#define DWS_W2(R0) cmul_(w1, w1)
+#endif
 #define DWS_STEP1(R0)                                                                                   \
     {                                                                                                   \
         const float2 w1 = tw16<TW, R0>(theta);                                                          \
-        const float2 w2 = TW ? t2w[R0] : (R0 == 0 ? make_float2(1.f, 0.f) : R0 == 1 ? w16c<2>()         \
+        const float2 w2 = TW ? DWS_W2(R0) : (R0 == 0 ? make_float2(1.f, 0.f) : R0 == 1 ? w16c<2>()         \
                                           : R0 == 2 ? make_float2(0.f, -1.f) : mul_neg_i(w16c<2>()));   \
         if (!INV) {                                                                                     \
             if (ZERO_HI) bf4_fwd_zero_hi(x[R0], x[R0 + 4], x[R0 + 8], x[R0 + 12], w1, w2);              \
@@ -171,6 +179,7 @@ DWS_HD void fft16(float2 (&x)[16], float2 theta_in) {
     }
 #undef DWS_STEP1
 #undef DWS_STEP2
+#undef DWS_W2
 }
 
 // Pass plan of size 2^LOG2M with THREADS = M/16 (one 16-point group per thread and pass).
@@ -272,6 +281,23 @@ DWS_HD void pointwise_pair(float2& zk_io, float2& zm_io, float2 wk, float2 ka, f
     const float2 iyo = mul_pos_i(cmulc(e, wk));
     zk_io = cadd(ye, iyo);
     zm_io = cconj(csub(ye, iyo));
+}
+
+// The two halves of pointwise_pair on their own (kernels that accumulate several spectra between them):
+// bins A[k], A[M-k] of the real row from the packed spectrum, and the packed form of a real-row spectrum Y[k], Y[M-k].
+DWS_HD void pair_bins(float2 zk, float2 zm, float2 wk, float2& ak, float2& am) {
+    const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);
+    const float2 t = cmul_(wk, make_float2(0.5f * d.y, -0.5f * d.x));
+    ak = cadd(xe, t);
+    am = cconj(csub(xe, t));
+}
+DWS_HD void pair_repack(float2 yk, float2 ym, float2 wk, float2& zk, float2& zm) {
+    const float2 ye = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+    const float2 e = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+    const float2 iyo = mul_pos_i(cmulc(e, wk));
+    zk = cadd(ye, iyo);
+    zm = cconj(csub(ye, iyo));
 }
 
 // q = 0: k = 0 (self-paired, carries DC and Nyquist, both real) and k = M/2 (position 1, self-paired).

@@ -34,6 +34,29 @@ struct FftCorrArgs {
 };
 int launch_fftcorr(int log2m, const FftCorrArgs& a, hipStream_t s);
 
+// Rows longer than the largest in-LDS transform (L > 16384: vocoding lengths, `generate.py:156`): segments of
+// S = 16384 samples; output segment j = first half of IFFT(A_j K_f + A_{j-1} Kc' + A_{j+1} Ka') where A_i is the spectrum
+// of input segment i and Kc' / Ka' the spectra of the causal / anti-causal kernel half alone, times (-1)^k (a shift by S).
+// Needs at most S kernel taps per direction (`s4.py:1387`: min(L, l_max) taps).
+struct FftConvSegArgs {
+    const float* u;        // [B,H,L]
+    float* g;              // [B,H,L]  GELU(conv + D u)
+    const float* D;        // [H]
+    const float2* tw;
+    const float2* twp;
+    const float2* kfa[3];  // pair-ordered spectra [H][M/2]: full, causal', anti-causal'
+    const float2* kfb[3];
+    const float2* kfs[3];  // [H][3]
+    int B, H, L;
+};
+constexpr int FFTCONV_SEG_LOG2M = 14;
+bool fftconv_seg_supported(int L, int taps);
+int launch_fftconv_seg(const FftConvSegArgs& a, hipStream_t s);
+// which = 0: both halves (== launch_s4_twosided_pow2), 1: causal taps only, 2: anti-causal taps only
+int launch_s4_twosided_pow2_part(const float* k, float* K, int H, int Lt, int Nf, int Lk, int which, hipStream_t s);
+// sign_alt: multiply bin k by (-1)^k
+int launch_kf_permute_signed(const float* kf, float* kfa, float* kfb, float* kfs, int H, int log2m, int sign_alt, hipStream_t s);
+
 bool fftconv_supported(int L, int* log2m);
 int launch_fftconv(int log2m, const FftConvArgs& a, hipStream_t s);
 int launch_rfft_rows(int log2m, const float* in, float* out, const float* tw, const float* twn, int H, hipStream_t s);

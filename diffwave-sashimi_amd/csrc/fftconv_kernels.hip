@@ -156,7 +156,9 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
         const int h = row / a.B, b = row % a.B;
         return reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
     };
-    constexpr bool PREFETCH = DIRECT && LOG2M >= 13;   // persistent sizes: a workgroup walks several rows
+    // fetching the next row's points before the last pass of the current one was measured SLOWER (99 vs 88 us at
+    // M = 16384: 16 more live registers at the 128-VGPR limit of a 1024-thread workgroup): off, kept for wider budgets
+    constexpr bool PREFETCH = false;
     float2 xin[DIRECT ? 8 : 1];     // the next row's input points, fetched while the current row is finished
     auto fetch = [&](int row) {
         if constexpr (DIRECT) {
@@ -325,6 +327,86 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
     }
 }
 
+// Rows longer than the transform (FftConvSegArgs): block = (row, output segment j).  Three input segments (j, j-1, j+1)
+// go through the forward transform; their real-row bins times the matching kernel spectrum accumulate in registers
+// (16 pairs per thread at 512 threads); the sum is re-packed into LDS, inverse-transformed, and its first half is output
+// segment j (+ D u, GELU).  Twice the transform work of a short row, 16-20 bytes of HBM traffic per sample.
+template <int LOG2M, int THREADS>
+__global__ __launch_bounds__(THREADS) void fftconv_seg_kernel(FftConvSegArgs a) {
+    constexpr int M = 1 << LOG2M, S = M, NP = M / 2 / THREADS;
+    constexpr int NG = M / 16 / THREADS;
+    extern __shared__ __attribute__((aligned(16))) float2 X[];
+    const int tid0 = threadIdx.x, row = blockIdx.x, j = blockIdx.y;
+    const int h = row / a.B, b = row % a.B;
+    const int L = a.L, nseg = (L + S - 1) / S;
+    const size_t off = ((size_t)b * a.H + h) * L;
+    const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + off);   // L even: samples (2i, 2i+1)
+    FftTw<LOG2M, NG> W;
+    W.load(a.tw, tid0);
+    float2 ya[NP], yb[NP];
+    float y0 = 0.f, yM = 0.f;
+    float2 yh = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ya[i] = yb[i] = make_float2(0.f, 0.f);
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {
+        const int sj = j + (t == 0 ? 0 : t == 1 ? -1 : 1);
+        if (sj < 0 || sj >= nseg) continue;        // uniform over the block
+        int tid = opaque(tid0);
+        const int c0 = sj * (S / 2), cn = min(S / 2, L / 2 - c0);   // packed points of this segment that exist
+        for (int i = tid; i < M; i += THREADS) X[pidx(i)] = (i < cn) ? u2[c0 + i] : make_float2(0.f, 0.f);
+        __syncthreads();
+        fft_forward<LOG2M, NG>(X, a.tw, W, tid);
+        tid = opaque(tid0);
+        const float2* __restrict__ kfa = a.kfa[t] + (size_t)h * (M / 2);
+        const float2* __restrict__ kfb = a.kfb[t] + (size_t)h * (M / 2);
+        const float2* __restrict__ kfs = a.kfs[t] + (size_t)h * 3;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int q = tid + i * THREADS;
+            if (q == 0) {
+                const float2 z0 = X[pidx(0)];
+                y0 = fmaf(z0.x + z0.y, kfs[0].x, y0);
+                yM = fmaf(z0.x - z0.y, kfs[1].x, yM);
+                yh = cadd(yh, cmul_(cconj(X[pidx(1)]), kfs[2]));
+            } else {
+                const int p = 2 * q, pm = brev(M - brev(p, LOG2M), LOG2M);
+                float2 ak, am;
+                pair_bins(X[pidx(p)], X[pidx(pm)], a.twp[q], ak, am);
+                ya[i] = cadd(ya[i], cmul_(ak, kfa[q]));
+                yb[i] = cadd(yb[i], cmul_(am, kfb[q]));
+            }
+        }
+        __syncthreads();
+    }
+    {
+        const int tid = opaque(tid0);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int q = tid + i * THREADS;
+            if (q == 0) {
+                X[pidx(0)] = make_float2(0.5f * (y0 + yM), 0.5f * (y0 - yM));
+                X[pidx(1)] = cconj(yh);
+            } else {
+                const int p = 2 * q, pm = brev(M - brev(p, LOG2M), LOG2M);
+                float2 zk, zm;
+                pair_repack(ya[i], yb[i], a.twp[q], zk, zm);
+                X[pidx(p)] = zk;
+                X[pidx(pm)] = zm;
+            }
+        }
+    }
+    __syncthreads();
+    fft_inverse<LOG2M, NG>(X, a.tw, W, opaque(tid0));
+    const float scale = 1.f / (float)M, Dh = a.D[h];
+    float2* __restrict__ g2 = reinterpret_cast<float2*>(a.g + off);
+    const int c0 = j * (S / 2), cn = min(S / 2, L / 2 - c0);
+    for (int i = tid0; i < cn; i += THREADS) {
+        const float2 y = X[pidx(i)], uu = u2[c0 + i];
+        g2[c0 + i] = make_float2(gelu_f(fmaf(y.x, scale, Dh * uu.x)), gelu_f(fmaf(y.y, scale, Dh * uu.y)));
+    }
+}
+
 // Forward real FFT only (weight time): spectrum of the re-placed two-sided kernel, natural order
 // out[h][k], k = 0..M (Nf/2+1 bins).  Used to build K_f with the SAME transform the convolution uses.
 template <int LOG2M, int THREADS>
@@ -363,33 +445,40 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* __restr
 //   K[j] = k0[j]/L (j < L);  K[Nf - m] = k1[m-1]/L (m = 1..L);  0 elsewhere.
 // k rows have length Lk (the kernel's own length); the first Lt = min(run length, Lk) taps of each direction are used
 // (`L_kernel`, s4.py:1387,805); 1/Lk is the irfft normalisation the unnormalised C2R left out.
-__global__ void s4_twosided_pow2_kernel(const float* __restrict__ k, float* __restrict__ K, int H, int Lt, int Nf, int Lk) {
+// which = 0: both directions, 1: causal taps only, 2: anti-causal taps only (the segmented long-row path).
+__global__ void s4_twosided_pow2_kernel(const float* __restrict__ k, float* __restrict__ K, int H, int Lt, int Nf, int Lk,
+                                        int which) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (j >= Nf) return;
     const float inv = 1.f / (float)Lk;
     float v = 0.f;
-    if (j < Lt) v = k[(size_t)h * Lk + j] * inv;
-    else if (j >= Nf - Lt) v = k[((size_t)H + h) * Lk + (Nf - j - 1)] * inv;
+    if (j < Lt && which != 2) v = k[(size_t)h * Lk + j] * inv;
+    else if (j >= Nf - Lt && j >= Lt && which != 1) v = k[((size_t)H + h) * Lk + (Nf - j - 1)] * inv;
     K[(size_t)h * Nf + j] = v;
 }
 
 // Pair-ordered copies of the spectrum for the pointwise stage: q -> k = brev(2q):
 //   kfa[h][q] = Kf[h][k], kfb[h][q] = Kf[h][M-k];  kfs[h] = {Kf[0], Kf[M], Kf[M/2]}
+// sign_alt: bin k is multiplied by (-1)^k, i.e. the kernel is shifted by half the transform (segmented long rows).
 __global__ void kf_permute_kernel(const float2* __restrict__ kf, float2* __restrict__ kfa, float2* __restrict__ kfb,
-                                  float2* __restrict__ kfs, int log2m) {
+                                  float2* __restrict__ kfs, int log2m, int sign_alt) {
     const int M = 1 << log2m;
     const int q = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y;
     if (q >= M / 2) return;
     const float2* r = kf + (size_t)h * (M + 1);
+    auto bin = [&](int k) {
+        const float2 v = r[k];
+        return (sign_alt && (k & 1)) ? make_float2(-v.x, -v.y) : v;
+    };
     if (q == 0) {
-        kfs[h * 3 + 0] = r[0]; kfs[h * 3 + 1] = r[M]; kfs[h * 3 + 2] = r[M / 2];
-        kfa[(size_t)h * (M / 2)] = r[0]; kfb[(size_t)h * (M / 2)] = r[M];
+        kfs[h * 3 + 0] = bin(0); kfs[h * 3 + 1] = bin(M); kfs[h * 3 + 2] = bin(M / 2);
+        kfa[(size_t)h * (M / 2)] = bin(0); kfb[(size_t)h * (M / 2)] = bin(M);
         return;
     }
     const int k = brev(2 * q, log2m);
-    kfa[(size_t)h * (M / 2) + q] = r[k];
-    kfb[(size_t)h * (M / 2) + q] = r[M - k];
+    kfa[(size_t)h * (M / 2) + q] = bin(k);
+    kfb[(size_t)h * (M / 2) + q] = bin(M - k);
 }
 
 template <int LOG2M>
@@ -490,15 +579,42 @@ int launch_rfft_rows(int log2m, const float* in, float* out, const float* tw, co
     DWS_FC_DISPATCH(launch_rf, in, out, tw, twn, H, s);
 }
 
+int launch_s4_twosided_pow2_part(const float* k, float* K, int H, int Lt, int Nf, int Lk, int which, hipStream_t s) {
+    hipLaunchKernelGGL(s4_twosided_pow2_kernel, dim3(ceil_div(Nf, 256), H), dim3(256), 0, s, k, K, H, Lt, Nf, Lk, which);
+    return DWS_OK;
+}
+
 int launch_s4_twosided_pow2(const float* k, float* K, int H, int Lt, int Nf, int Lk, hipStream_t s) {
-    hipLaunchKernelGGL(s4_twosided_pow2_kernel, dim3(ceil_div(Nf, 256), H), dim3(256), 0, s, k, K, H, Lt, Nf, Lk);
+    return launch_s4_twosided_pow2_part(k, K, H, Lt, Nf, Lk, 0, s);
+}
+
+int launch_kf_permute_signed(const float* kf, float* kfa, float* kfb, float* kfs, int H, int log2m, int sign_alt,
+                             hipStream_t s) {
+    const int M = 1 << log2m;
+    hipLaunchKernelGGL(kf_permute_kernel, dim3(ceil_div(M / 2, 256), H), dim3(256), 0, s, (const float2*)kf,
+                       (float2*)kfa, (float2*)kfb, (float2*)kfs, log2m, sign_alt);
     return DWS_OK;
 }
 
 int launch_kf_permute(const float* kf, float* kfa, float* kfb, float* kfs, int H, int log2m, hipStream_t s) {
-    const int M = 1 << log2m;
-    hipLaunchKernelGGL(kf_permute_kernel, dim3(ceil_div(M / 2, 256), H), dim3(256), 0, s, (const float2*)kf,
-                       (float2*)kfa, (float2*)kfb, (float2*)kfs, log2m);
+    return launch_kf_permute_signed(kf, kfa, kfb, kfs, H, log2m, 0, s);
+}
+
+bool fftconv_seg_supported(int L, int taps) {
+    return L > (1 << FFTCONV_SEG_LOG2M) && (L & 1) == 0 && taps <= (1 << FFTCONV_SEG_LOG2M);
+}
+
+int launch_fftconv_seg(const FftConvSegArgs& a, hipStream_t s) {
+    using C = FcCfg<FFTCONV_SEG_LOG2M>;
+    constexpr int TH = 512, S = 1 << FFTCONV_SEG_LOG2M;
+    ProfileScope ps("fftconv_seg", s);
+    auto kern = fftconv_seg_kernel<FFTCONV_SEG_LOG2M, TH>;
+    static bool attr = false;
+    if (!attr) {
+        DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B * a.H, ceil_div(a.L, S)), dim3(TH), C::LDS, s, a);
     return DWS_OK;
 }
 

@@ -20,6 +20,13 @@ struct S4TailArgs {
     const float* b2;      // [H]
     const float* addend;  // nullable U-Net skip [B,H,L]
     float* out;           // [B,H,L]
+    // optional: also emit the NEXT block's S4 input  y = LN1_next(out) + fc_t_next(e)[b, h]  (`sashimi.py:148-152`),
+    // so the next block of the same stage needs no separate LayerNorm pass
+    float* ynext;         // nullable [B,H,L]
+    const float* n1_m;    // next block's norm1.m, norm1.s (device scalars)
+    const float* n1_s;
+    const float* e_next;  // next block's step-embedding projection: e_next[b * e_stride + h]
+    int e_stride;
     int B, L;
 };
 

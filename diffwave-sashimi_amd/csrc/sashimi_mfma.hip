@@ -80,6 +80,41 @@ __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* _
     }
 }
 
+// TransposedLN statistics of an [H][P] tile in LDS, down each column (population std, no eps; `sashimi.py:17-20`):
+// the tile is centred in place, colmean[col] = mean, colalpha[col] = s / std.  THREADS = P * PARTS; ends with a barrier.
+template <int H, int P, int PARTS>
+__device__ __forceinline__ void column_stats(float* __restrict__ tile, float* __restrict__ red, float* __restrict__ colmean,
+                                             float* __restrict__ colalpha, float s_scale, int tid) {
+    const int col = tid % P, part = tid / P;
+    constexpr int RP = H / PARTS;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < RP; ++r) s += tile[(part * RP + r) * P + col];
+    red[part * P + col] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) mean += red[q * P + col];
+    mean *= (1.f / (float)H);
+    float v = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < RP; ++r) {
+        const float d = tile[(part * RP + r) * P + col] - mean;
+        tile[(part * RP + r) * P + col] = d;
+        v = fmaf(d, d, v);
+    }
+    red[(PARTS + part) * P + col] = v;
+    __syncthreads();
+    if (part == 0) {
+        float var = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) var += red[(PARTS + q) * P + col];
+        colmean[col] = mean;
+        colalpha[col] = s_scale / sqrtf(var * (1.f / (float)H));
+    }
+    __syncthreads();
+}
+
 // two waves per SIMD at least: without the bound hipcc spends > 256 registers per lane on one resident workgroup
 template <int H, int WM, int WN, int NT, int FFE>
 __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64 * WM * WN) : 1)) void s4_tail_mfma_kernel(
@@ -191,36 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
     __syncthreads();
 
     // ---- LN2 statistics per column (population std, no eps; `sashimi.py:17-20`), centre in place
-    {
-        const int col = tid % P, part = tid / P;
-        constexpr int RP = H / PARTS;
-        float s = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < RP; ++r) s += tile[(part * RP + r) * P + col];
-        red[part * P + col] = s;
-        __syncthreads();
-        float mean = 0.f;
-#pragma unroll
-        for (int q = 0; q < PARTS; ++q) mean += red[q * P + col];
-        mean *= (1.f / (float)H);
-        float v = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < RP; ++r) {
-            const float d = tile[(part * RP + r) * P + col] - mean;
-            tile[(part * RP + r) * P + col] = d;
-            v = fmaf(d, d, v);
-        }
-        red[(PARTS + part) * P + col] = v;
-        __syncthreads();
-        if (part == 0) {
-            float var = 0.f;
-#pragma unroll
-            for (int q = 0; q < PARTS; ++q) var += red[(PARTS + q) * P + col];
-            colmean[col] = mean;
-            colalpha[col] = a.ln_s[0] / sqrtf(var * (1.f / (float)H));
-        }
-        __syncthreads();
-    }
+    column_stats<H, P, PARTS>(tile, red, colmean, colalpha, a.ln_s[0], tid);
 
     // ---- FF: per H-row chunk q of u: GEMM-1 chunk -> GELU -> LDS -> GEMM-2 partial
     const float4* A1 = reinterpret_cast<const float4*>(a.A1);
@@ -305,6 +311,37 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
                 const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const float v = (tile[h * P + col] + mean) + (acc2[m][n][r] + b2v[r]) + ad[r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0);
+                if (a.ynext) tile[h * P + col] = v;    // this thread's own element: the block output stays in LDS
+            }
+        }
+    }
+    if (a.ynext == nullptr) return;   // uniform
+
+    // ---- the next block's S4 input: LN1_next down the columns of the output tile + its step-embedding projection
+    __syncthreads();
+    column_stats<H, P, PARTS>(tile, red, colmean, colalpha, a.n1_s[0], tid);
+    {
+        __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e_next + (size_t)b * a.e_stride), 0, H * 4, 0x00020000);
+        const float n1m = a.n1_m[0];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float ev[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ev[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rE, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = (wn * NT + n) * 32 + l31;
+                const int pos = l0 + col;
+                const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
+                const float al = colalpha[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float y = fmaf(al, tile[h * P + col] + n1m, ev[r]);      // (s/sd)(x - mu + m) + fc_t(e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rY, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0);
+                }
             }
         }
     }

@@ -70,6 +70,8 @@ struct SLayer {
     DevBuf Kf;            // rocFFT path: [H][L+1] complex spectrum of the two-sided kernel (n = 2L)
     DevBuf kfa, kfb, kfs; // fused path: pair-ordered spectrum at the power-of-two size (fftconv.h)
     int log2m = 0;        // > 0: fused LDS FFT convolution is used for this block
+    bool seg = false;     // stage longer than the largest LDS transform: segmented fused path (fftconv_seg_kernel)
+    DevBuf kfa_c, kfb_c, kfs_c, kfa_a, kfb_a, kfs_a;   // seg: spectra of the causal / anti-causal kernel half, shifted
     DevBuf melW0, melW1, melWc, melc;
     DevBuf out;           // activation produced by this layer
     // training path: saved activations, gradient w.r.t. `out`, transposed weights in A-fragment order
@@ -86,6 +88,7 @@ struct Exec {             // one step of Sashimi.forward: out_node = layer(in_no
 struct Stage {
     int H, L, L0 = 0;
     bool rocfft = false;  // some block of this stage needs the rocFFT path
+    bool seg = false;     // stage runs the segmented fused convolution (L > 16384)
     DevBuf U, Uf, Y, g, x1, n2, ffu, y;
     DevBuf d2, dh, dx1, du;  // training path gradients: [B][max(2,FF) H][L], [B][H][L] x 3
 };
@@ -307,6 +310,31 @@ struct SashimiModel : dws_model {
             DWS_TRY(launch_rfft_rows(lg, cK.f(), cKf.f(), t->tw.f(), t->twn.f(), H, s));
             DWS_TRY(launch_kf_permute(cKf.f(), l->kfa.f(), l->kfb.f(), l->kfs.f(), H, lg, s));
             l->log2m = lg;
+            l->seg = false;
+        } else if (stages[l->stage]->seg) {
+            // vocoding lengths: three pair-ordered spectra at M = 16384 -- the two-sided kernel, and its causal and
+            // anti-causal halves alone shifted by half the transform ((-1)^k), see FftConvSegArgs
+            DWS_CHECK(fftconv_seg_supported(L, Lt), DWS_ERR_UNSUPPORTED,
+                      "%s: stage of %d samples with %d kernel taps per direction: more taps than one 16384-sample segment",
+                      k.c_str(), L, Lt);
+            lg = FFTCONV_SEG_LOG2M;
+            const int M = 1 << lg, Nf = 2 * M;
+            FftTables* t;
+            DWS_TRY(get_tables(lg, &t, s));
+            DWS_TRY(cK.ensure((size_t)H * Nf * 4));
+            DWS_TRY(cKf.ensure((size_t)H * (M + 1) * 8));
+            DevBuf* dst[3][3] = {{&l->kfa, &l->kfb, &l->kfs}, {&l->kfa_c, &l->kfb_c, &l->kfs_c}, {&l->kfa_a, &l->kfb_a, &l->kfs_a}};
+            for (int which = 0; which < 3; ++which) {
+                DWS_TRY(dst[which][0]->ensure((size_t)H * (M / 2) * 8));
+                DWS_TRY(dst[which][1]->ensure((size_t)H * (M / 2) * 8));
+                DWS_TRY(dst[which][2]->ensure((size_t)H * 3 * 8));
+                DWS_TRY(launch_s4_twosided_pow2_part(ck.f(), cK.f(), H, Lt, Nf, Lk, which, s));
+                DWS_TRY(launch_rfft_rows(lg, cK.f(), cKf.f(), t->tw.f(), t->twn.f(), H, s));
+                DWS_TRY(launch_kf_permute_signed(cKf.f(), dst[which][0]->f(), dst[which][1]->f(), dst[which][2]->f(), H, lg,
+                                                 which != 0, s));
+            }
+            l->log2m = 0;
+            l->seg = true;
         } else {
             DWS_TRY(cK.ensure((size_t)H * 2 * L * 4));
             DWS_TRY(l->Kf.ensure((size_t)H * (L + 1) * 8));
@@ -315,6 +343,7 @@ struct SashimiModel : dws_model {
             DWS_FFT(hipfftSetStream(plan, s));
             DWS_FFT(hipfftExecR2C(plan, (hipfftReal*)cK.p, (hipfftComplex*)l->Kf.p));
             l->log2m = 0;
+            l->seg = false;
             stages[l->stage]->rocfft = true;
         }
         return DWS_OK;
@@ -408,14 +437,18 @@ struct SashimiModel : dws_model {
                 l->L = (int)((int64_t)l->L0 * nL / d.L);
                 l->Lout = (int)((int64_t)l->Lout0 * nL / d.L);
             }
-            for (auto* st : stages) { st->L = (int)((int64_t)st->L0 * nL / d.L); st->rocfft = false; }
+            for (auto* st : stages) { st->L = (int)((int64_t)st->L0 * nL / d.L); st->rocfft = false; st->seg = false; }
             dirty = true;   // K_f depends on the run length (two-sided assembly, transform size)
         }
         B = nB; L = nL;
         for (auto* st : stages) {
             const size_t rows = (size_t)B * st->H, Ls = st->L;
             int lg = 0;
-            const bool need_rocfft = !fftconv_supported((int)Ls, &lg) || getenv("DWS_SASHIMI_ROCFFT");
+            const bool no_fused = !fftconv_supported((int)Ls, &lg) || getenv("DWS_SASHIMI_ROCFFT");
+            // beyond the largest LDS transform: segmented fused path when the kernels (at most the configured stage
+            // length of taps per direction, s4.py:1387) fit one segment
+            st->seg = no_fused && !getenv("DWS_SASHIMI_ROCFFT") && fftconv_seg_supported((int)Ls, std::min((int)Ls, st->L0));
+            const bool need_rocfft = no_fused && !st->seg;
             if (need_rocfft) {
                 const bool fresh = st->U.bytes < rows * 2 * Ls * 4;
                 DWS_TRY(st->U.ensure(rows * 2 * Ls * 4));
@@ -440,7 +473,7 @@ struct SashimiModel : dws_model {
         // FFT plans allocate: create them here, never inside a stream capture
         for (auto* st : stages) {
             int lg = 0;
-            if (fftconv_supported(st->L, &lg) && !getenv("DWS_SASHIMI_ROCFFT")) continue;
+            if ((fftconv_supported(st->L, &lg) && !getenv("DWS_SASHIMI_ROCFFT")) || st->seg) continue;
             hipfftHandle plan;
             DWS_TRY(fft.get(0, 2 * st->L, (int)B * st->H, &plan));
             DWS_TRY(fft.get(1, 2 * st->L, (int)B * st->H, &plan));
@@ -485,14 +518,23 @@ struct SashimiModel : dws_model {
         return DWS_OK;
     }
 
-    // DiffWaveBlock.forward (sashimi.py:143-184)
-    int run_block(SLayer* l, const float* x, const float* addend, hipStream_t s) {
+    // The tail of `l` can also produce the S4 input of the block that runs next (LN1 + step embedding fused into its
+    // epilogue) when that block sits on the same stage and both run the fused paths.
+    bool feeds_next(const SLayer* l, const SLayer* next) const {
+        return next && l->kind == L_BLOCK && next->kind == L_BLOCK && next->stage == l->stage && l->mfma &&
+               (next->log2m > 0 || next->seg) && !getenv("DWS_SASHIMI_NO_LN_FUSION");
+    }
+
+    // DiffWaveBlock.forward (sashimi.py:143-184).  y_ready: the previous block's tail already wrote this block's S4 input
+    // into the stage's y buffer; next: the block whose S4 input this block's tail should write (or null).
+    int run_block(SLayer* l, const float* x, const float* addend, bool y_ready, SLayer* next, hipStream_t s) {
         Stage* st = stages[l->stage];
         const int H = l->H, Ls = l->L, nB = (int)B;
         const std::string& p = l->prefix;
         if (l->log2m > 0) {
-            DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->y.f(), nB, H,
-                              Ls, (size_t)Ls, s));
+            if (!y_ready)
+                DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->y.f(), nB,
+                                  H, Ls, (size_t)Ls, s));
             FftTables* t = tables[l->log2m];
             FftConvArgs fa{};
             fa.u = st->y.f(); fa.g = st->g.f(); fa.D = P(p + ".layer.D");
@@ -500,7 +542,22 @@ struct SashimiModel : dws_model {
             fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
             fa.B = nB; fa.H = H; fa.L = Ls;
             DWS_TRY(launch_fftconv(l->log2m, fa, s));
-            return run_tail(l, st, x, addend, s);
+            return run_tail(l, st, x, addend, next, s);
+        }
+        if (l->seg) {
+            if (!y_ready)
+                DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->y.f(), nB,
+                                  H, Ls, (size_t)Ls, s));
+            FftTables* t = tables[FFTCONV_SEG_LOG2M];
+            FftConvSegArgs fa{};
+            fa.u = st->y.f(); fa.g = st->g.f(); fa.D = P(p + ".layer.D");
+            fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
+            fa.kfa[0] = (const float2*)l->kfa.p; fa.kfb[0] = (const float2*)l->kfb.p; fa.kfs[0] = (const float2*)l->kfs.p;
+            fa.kfa[1] = (const float2*)l->kfa_c.p; fa.kfb[1] = (const float2*)l->kfb_c.p; fa.kfs[1] = (const float2*)l->kfs_c.p;
+            fa.kfa[2] = (const float2*)l->kfa_a.p; fa.kfb[2] = (const float2*)l->kfb_a.p; fa.kfs[2] = (const float2*)l->kfs_a.p;
+            fa.B = nB; fa.H = H; fa.L = Ls;
+            DWS_TRY(launch_fftconv_seg(fa, s));
+            return run_tail(l, st, x, addend, next, s);
         }
         DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->U.f(), nB, H, Ls,
                           (size_t)2 * Ls, s));
@@ -519,11 +576,11 @@ struct SashimiModel : dws_model {
             DWS_FFT(hipfftExecC2R(plan, (hipfftComplex*)st->Uf.p, (hipfftReal*)st->Y.p));
         }
         DWS_TRY(launch_s4_post(st->Y.f(), st->U.f(), P(p + ".layer.D"), st->g.f(), nB, H, Ls, s));
-        return run_tail(l, st, x, addend, s);
+        return run_tail(l, st, x, addend, next, s);
     }
 
     // everything of the block after the S4 convolution (sashimi.py:177-184, s4.py:1435)
-    int run_tail(SLayer* l, Stage* st, const float* x, const float* addend, hipStream_t s) {
+    int run_tail(SLayer* l, Stage* st, const float* x, const float* addend, SLayer* next, hipStream_t s) {
         const int H = l->H, Ls = l->L, nB = (int)B;
         const std::string& p = l->prefix;
         if (l->mfma) {
@@ -534,6 +591,11 @@ struct SashimiModel : dws_model {
             t.A1 = l->A1.f(); t.b1 = P(p + ".ff.ff.0.conv.bias"); t.rs1 = l->rs1.f();
             t.A2 = l->A2.f(); t.b2 = P(p + ".ff.ff.2.conv.bias");
             t.addend = addend; t.out = l->out.f(); t.B = nB; t.L = Ls;
+            if (next) {     // feeds_next(l, next) holds: the stage's y buffer is free once this block's convolution ran
+                t.ynext = st->y.f();
+                t.n1_m = P(next->prefix + ".norm1.m"); t.n1_s = P(next->prefix + ".norm1.s");
+                t.e_next = part_t.f() + next->pt_off; t.e_stride = pt_total;
+            }
             return launch_s4_tail_mfma(H, t, s);
         }
         DWS_TRY(launch_pw_glu_res(st->g.f(), P(p + ".layer.output_linear.0.weight"), P(p + ".layer.output_linear.0.bias"),
@@ -545,8 +607,8 @@ struct SashimiModel : dws_model {
         return DWS_OK;
     }
 
-    int run_layer(SLayer* l, const float* x, const float* addend, hipStream_t s) {
-        if (l->kind == L_BLOCK) return run_block(l, x, addend, s);
+    int run_layer(SLayer* l, const float* x, const float* addend, hipStream_t s, bool y_ready = false, SLayer* next = nullptr) {
+        if (l->kind == L_BLOCK) return run_block(l, x, addend, y_ready, next, s);
         if (l->mfma) {
             PwMfmaArgs a{};
             a.in = x; a.A = l->Ap.f(); a.bias = P(l->prefix + ".linear.conv.bias"); a.out = l->out.f();
@@ -595,22 +657,35 @@ struct SashimiModel : dws_model {
         DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), (int)B, Eout, pt_total, 0, s));
         std::vector<const float*> stack;  // LIFO skip stack (sashimi.py:293-307)
         const float* x = x_init.f();
+        // execution order; a block whose successor is a fused block of the same stage also writes that block's S4 input
+        std::vector<SLayer*> order(d_layers);
+        order.insert(order.end(), c_layers.begin(), c_layers.end());
+        order.insert(order.end(), u_layers.begin(), u_layers.end());
+        size_t oi = 0;
+        bool y_ready = false;
+        auto run = [&](SLayer* l, const float* add) -> int {
+            SLayer* nx = (oi + 1 < order.size() && feeds_next(l, order[oi + 1])) ? order[oi + 1] : nullptr;
+            const int st_ = run_layer(l, x, add, s, y_ready, nx);
+            y_ready = nx != nullptr;
+            ++oi;
+            return st_;
+        };
         for (auto* l : d_layers) {
             stack.push_back(x);
-            DWS_TRY(run_layer(l, x, nullptr, s));
+            DWS_TRY(run(l, nullptr));
             x = l->out.f();
         }
         stack.push_back(x);
         for (size_t i = 0; i < c_layers.size(); ++i) {
             const float* add = nullptr;
             if (i + 1 == c_layers.size()) { add = stack.back(); stack.pop_back(); }
-            DWS_TRY(run_layer(c_layers[i], x, add, s));
+            DWS_TRY(run(c_layers[i], add));
             x = c_layers[i]->out.f();
         }
         for (auto* l : u_layers) {
             const float* add = nullptr;
             if (l->kind == L_UP || unet) { add = stack.back(); stack.pop_back(); }
-            DWS_TRY(run_layer(l, x, add, s));
+            DWS_TRY(run(l, add));
             x = l->out.f();
         }
         last_x = x;

@@ -2,6 +2,8 @@
 // (`models/sashimi.py:17-20,36-58,143-184`, `models/s4.py:704-807,1391-1437`).
 // The GEMMs run on tapconv_mfma / wgrad_mfma (wavenet_backward_mfma.hip), the FFT
 // convolution adjoints on fftconv_kernels.hip.
+#include <cstdlib>
+
 #include "sashimi_train.h"
 
 namespace dws {
@@ -177,7 +179,8 @@ int launch_ln_bwd(const float* x, const float* dy, const float* m_p, const float
 #define DWS_LN_BWD(RP, PARTS)                                                                                         \
     hipLaunchKernelGGL((ln_bwd_reg_kernel<RP, PARTS>), grid, dim3(64 * PARTS), 0, s, x, dy, m_p, s_p, base, out, accumulate, \
                        partial, L)
-    switch (H) {
+    static const bool old_path = getenv("DWS_LN_BWD_OLD") != nullptr;
+    switch (old_path ? 0 : H) {
         case 32: DWS_LN_BWD(8, 4); return DWS_OK;
         case 64: DWS_LN_BWD(16, 4); return DWS_OK;
         case 128: DWS_LN_BWD(32, 4); return DWS_OK;

@@ -47,16 +47,19 @@ def compare(got, ref, truth64, fp32_impls=(), label=""):
     """`got` vs `ref` per tensor: 1e-3, or 3x the fp32 noise of that tensor measured as the distance of the given fp32
     implementations (always including `ref`) from `truth64`.  Returns (worst error, its key)."""
     gmax = max(float(v.abs().max()) for v in truth64.values())
-    bad, worst, worst_k = [], 0.0, None
+    bad, worst, worst_k, rows = [], 0.0, None, []
     for k, r in ref.items():
         sc = _scale(truth64[k], gmax)
         noise = max(float((impl[k].double() - truth64[k]).abs().max()) / sc for impl in (ref, *fp32_impls))
         err = float((got[k].double() - r.double()).abs().max()) / sc
         tol = max(TOL, 3.0 * noise)
+        rows.append((err / tol, err, tol, noise, k))
         if err > worst:
             worst, worst_k = err, k
         if not err < tol:
             bad.append(f"{k}: err {err:.2e} >= tol {tol:.2e} (fp32 noise {noise:.2e})")
+    rows.sort(reverse=True)
+    print(f"{label}: closest to their bound: " + "; ".join(f"{k} {e:.1e}/{t:.1e}" for _, e, t, _, k in rows[:6]))
     assert not bad, f"{label}: {len(bad)} of {len(ref)} gradients off:\n" + "\n".join(bad[:30])
     return worst, worst_k
 

@@ -136,6 +136,63 @@ static void conv_row(const float* u, int L, const float* tw_, const float* twp_,
     }
 }
 
+// One row of fftconv_seg_kernel: inputs longer than the transform (L > M): output segment j (S = M samples... the real
+// transform has Nf = 2M points, a segment S = Nf/2 = M samples) = first S points of
+//   IFFT( A_j K_f + A_{j-1} Kc' + A_{j+1} Ka' ),   Kc' / Ka' = (-1)^k x spectrum of the causal / anti-causal half alone.
+// Tables per spectrum in pair order: (kfa, kfb, kfs) x {full, causal, anti}.
+template <int LOG2M>
+static void conv_long_row(const float* u, int L, const float* tw_, const float* twp_, const float* const* kfa_,
+                          const float* const* kfb_, const float* const* kfs_, float* out) {
+    constexpr int M = 1 << LOG2M, S = M;                 // S real samples = M/2 packed complex points
+    const float2 *tw = reinterpret_cast<const float2*>(tw_), *twp = reinterpret_cast<const float2*>(twp_);
+    const int nseg = (L + S - 1) / S;
+    std::vector<float2> X(M + M / 16), ya(M / 2), yb(M / 2);
+    for (int j = 0; j < nseg; ++j) {
+        float y0 = 0.f, yM = 0.f;
+        float2 yh = make_float2(0.f, 0.f);
+        for (int q = 0; q < M / 2; ++q) ya[q] = yb[q] = make_float2(0.f, 0.f);
+        for (int t = 0; t < 3; ++t) {                    // source segments j, j-1, j+1 with spectra full, causal', anti'
+            const int sj = j + (t == 0 ? 0 : t == 1 ? -1 : 1);
+            if (sj < 0 || sj >= nseg) continue;
+            const float2 *kfa = reinterpret_cast<const float2*>(kfa_[t]), *kfb = reinterpret_cast<const float2*>(kfb_[t]);
+            const float2* kfs = reinterpret_cast<const float2*>(kfs_[t]);
+            for (int i = 0; i < M; ++i) {                // packed complex point i = samples (2i, 2i+1) of the segment
+                const int s0 = sj * S + 2 * i;
+                const float re = (i < S / 2 && s0 < L) ? u[s0] : 0.f, im = (i < S / 2 && s0 + 1 < L) ? u[s0 + 1] : 0.f;
+                X[pidx(i)] = make_float2(re, im);
+            }
+            forward_lds<LOG2M>(X.data(), tw);
+            for (int q = 0; q < M / 2; ++q) {
+                if (q == 0) {
+                    const float2 z0 = X[pidx(0)];
+                    y0 += (z0.x + z0.y) * kfs[0].x;
+                    yM += (z0.x - z0.y) * kfs[1].x;
+                    yh = cadd(yh, cmul_(cconj(X[pidx(1)]), kfs[2]));
+                    continue;
+                }
+                const int p = 2 * q, pm = brev_bits(M - brev_bits(p, LOG2M), LOG2M);
+                float2 ak, am;
+                pair_bins(X[pidx(p)], X[pidx(pm)], twp[q], ak, am);
+                ya[q] = cadd(ya[q], cmul_(ak, kfa[q]));
+                yb[q] = cadd(yb[q], cmul_(am, kfb[q]));
+            }
+        }
+        X[pidx(0)] = make_float2(0.5f * (y0 + yM), 0.5f * (y0 - yM));
+        X[pidx(1)] = cconj(yh);
+        for (int q = 1; q < M / 2; ++q) {
+            const int p = 2 * q, pm = brev_bits(M - brev_bits(p, LOG2M), LOG2M);
+            pair_repack(ya[q], yb[q], twp[q], X[pidx(p)], X[pidx(pm)]);
+        }
+        inverse_lds<LOG2M>(X.data(), tw);
+        const float scale = 1.f / (float)M;
+        for (int i = 0; i < S / 2; ++i) {
+            const int s0 = j * S + 2 * i;
+            if (s0 < L) out[s0] = X[pidx(i)].x * scale;
+            if (s0 + 1 < L) out[s0 + 1] = X[pidx(i)].y * scale;
+        }
+    }
+}
+
 #define DISPATCH(FN, ...)                      \
     switch (log2m) {                           \
         case 6: FN<6>(__VA_ARGS__); return 0;  \
@@ -154,4 +211,9 @@ extern "C" int dws_host_fft(int log2m, float* data, const float* tw, int inverse
 extern "C" int dws_host_conv_row(int log2m, const float* u, int L, const float* tw, const float* twp, const float* kfa,
                                  const float* kfb, const float* kfs, float csign, float* out) {
     DISPATCH(conv_row, u, L, tw, twp, kfa, kfb, kfs, csign, out);
+}
+
+extern "C" int dws_host_conv_long_row(int log2m, const float* u, int L, const float* tw, const float* twp,
+                                      const float* const* kfa, const float* const* kfb, const float* const* kfs, float* out) {
+    DISPATCH(conv_long_row, u, L, tw, twp, kfa, kfb, kfs, out);
 }

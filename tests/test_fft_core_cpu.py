@@ -24,6 +24,8 @@ def host():
     fp = ctypes.POINTER(ctypes.c_float)
     lib.dws_host_fft.argtypes = [ctypes.c_int, fp, fp, ctypes.c_int]
     lib.dws_host_conv_row.argtypes = [ctypes.c_int, fp, ctypes.c_int, fp, fp, fp, fp, fp, ctypes.c_float, fp]
+    fpp = ctypes.POINTER(fp)
+    lib.dws_host_conv_long_row.argtypes = [ctypes.c_int, fp, ctypes.c_int, fp, fp, fpp, fpp, fpp, fp]
     return lib
 
 
@@ -97,5 +99,48 @@ def test_convolution_row_matches_the_definition(host, lg, L, csign):
         k0d, k1d, ud = k0.astype(np.float64), k1.astype(np.float64), u.astype(np.float64)
         direct = np.array([np.dot(k0d[:i + 1][::-1], ud[:i + 1]) + np.dot(k1d[:L - 1 - i], ud[i + 1:]) for i in range(L)])
         assert np.abs(direct - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err < 5e-6, err
+
+
+@pytest.mark.parametrize("lg,L,Lt", [(8, 1000, 256), (8, 1000, 100), (8, 513, 256), (10, 2500, 1000), (14, 40000, 16000)])
+def test_segmented_convolution_of_rows_longer_than_the_transform(host, lg, L, Lt):
+    """`fftconv_seg_kernel`'s sequence (inputs longer than 16384 samples, `generate.py:156` / `s4.py:1387`): segments of
+    S = Nf/2 samples; output segment j = first half of IFFT(A_j K_f + A_{j-1} Kc' + A_{j+1} Ka') with Kc' / Ka' the
+    spectra of the causal / anti-causal kernel half alone times (-1)^k (a shift by S).  Against the definition with
+    Lt <= S taps per direction, in float64."""
+    M, Nf = 1 << lg, 2 << lg
+    S = M
+    rng = np.random.default_rng(7 * lg + L + Lt)
+    u = rng.standard_normal(L).astype(np.float32)
+    decay = np.exp(-np.arange(Lt) / (Lt / 5.0))
+    k0 = (rng.standard_normal(Lt) * decay).astype(np.float32)
+    k1 = (rng.standard_normal(Lt) * decay).astype(np.float32)
+    Kc, Ka = np.zeros(Nf), np.zeros(Nf)
+    Kc[:Lt] = k0
+    Ka[Nf - Lt:] = k1[::-1]
+    sign = (-1.0) ** np.arange(M + 1)
+    specs = [np.fft.rfft(Kc + Ka), sign * np.fft.rfft(Kc), sign * np.fft.rfft(Ka)]
+    tw, twp, kk = _tables(lg)
+    keep, kfa, kfb, kfs = [], [], [], []
+    for Kf in specs:
+        a, b = Kf[kk].astype(np.complex64), Kf[M - kk].astype(np.complex64)
+        a[0], b[0] = Kf[0], Kf[M]
+        c = np.array([Kf[0], Kf[M], Kf[M // 2]]).astype(np.complex64)
+        arrs = [_c2f(a), _c2f(b), _c2f(c)]
+        keep.append(arrs)
+        kfa.append(_p(arrs[0])); kfb.append(_p(arrs[1])); kfs.append(_p(arrs[2]))
+    fp = ctypes.POINTER(ctypes.c_float)
+    arr3 = lambda ps: (fp * 3)(*ps)
+    out = np.zeros(L, dtype=np.float32)
+    assert host.dws_host_conv_long_row(lg, _p(u), L, _p(_c2f(tw)), _p(_c2f(twp)), arr3(kfa), arr3(kfb), arr3(kfs), _p(out)) == 0
+    # definition: y[i] = sum_{j<Lt} k0[j] u[i-j] + sum_{1<=m<=Lt} k1[m-1] u[i+m], via one big float64 FFT
+    n = 1
+    while n < L + 2 * Lt:
+        n *= 2
+    K = np.zeros(n)
+    K[:Lt] = k0
+    K[n - Lt:] = k1[::-1]
+    ref = np.fft.irfft(np.fft.rfft(np.concatenate([u.astype(np.float64), np.zeros(n - L)])) * np.fft.rfft(K), n=n)[:L]
     err = np.abs(out - ref).max() / np.abs(ref).max()
     assert err < 5e-6, err

@@ -175,10 +175,11 @@ def test_variable_length_calls_match_reference_sequence(gpu):
         assert Ls == list(g[f"call{i}/L"])
 
 
-@pytest.mark.parametrize("L_in", [4000, 20000, 40000])
+@pytest.mark.parametrize("L_in", [4000, 20000, 40000, 212992])
 def test_long_and_short_utterances_against_oracle(gpu, L_in):
-    """Vocoder-style lengths around l_max = 16000 on the config-4 channel counts: 4000 (kernel truncated), 20000 and
-    40000 (l_max taps; top stage beyond the fused FFT's 16384 -> rocFFT n = 2L path), vs the CPU oracle."""
+    """Vocoder-style lengths around l_max = 16000 on the config-4 channel counts: 4000 (kernel truncated); 20000, 40000
+    and 212992 = 832 mel frames, an LJSpeech utterance (`generate.py:156`): l_max taps, stages beyond the largest LDS
+    transform (16384) run the segmented fused convolution (`fftconv_seg_kernel`); vs the CPU oracle."""
     cfg = cases.ss_cfg(d_model=32, n_layers=1, L=16000)
     net = cases.build_ours(cfg, 77).to(gpu)
     gen = torch.Generator().manual_seed(78)
@@ -188,3 +189,41 @@ def test_long_and_short_utterances_against_oracle(gpu, L_in):
     with torch.no_grad():
         ref = osa.sashimi_forward(sd, cfg, audio, steps)
     assert rel_err(out.cpu(), ref) < REL_TOL
+
+
+def test_segmented_long_rows_agree_with_the_rocfft_path(gpu):
+    """Same engine, same weights, L = 40000 (top stage 40000 > 16384): the segmented fused path against the rocFFT
+    n = 2L path (DWS_SASHIMI_ROCFFT=1), B = 3, two blocks per level."""
+    import os
+    cfg = cases.ss_cfg(d_model=32, n_layers=2, L=16000)
+    net = cases.build_ours(cfg, 79).to(gpu)
+    gen = torch.Generator().manual_seed(80)
+    audio, steps = torch.randn(3, 1, 40000, generator=gen), torch.tensor([[3.0], [120.0], [199.0]])
+    got = _run(net, gpu, audio, steps)
+    os.environ["DWS_SASHIMI_ROCFFT"] = "1"
+    try:
+        net2 = cases.build_ours(cfg, 79).to(gpu)
+        net2.load_state_dict(net.state_dict())
+        ref = _run(net2, gpu, audio, steps)
+    finally:
+        del os.environ["DWS_SASHIMI_ROCFFT"]
+    assert rel_err(got, ref) < 1e-4
+    assert not torch.equal(got, ref)            # two different code paths really ran
+
+
+@pytest.mark.parametrize("name", ["ss_d64_short", "ss_d128_short"])
+def test_fused_next_block_layernorm_agrees_with_the_separate_pass(gpu, name):
+    """A block's tail kernel also writes the next block's S4 input (LN1 + step embedding, `sashimi.py:148-152`) when
+    both sit on one stage; DWS_SASHIMI_NO_LN_FUSION=1 runs the separate LayerNorm pass instead.  Same weights, both ways."""
+    import os
+    cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES[name]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    fused = _run(net, gpu, audio, steps)
+    os.environ["DWS_SASHIMI_NO_LN_FUSION"] = "1"
+    try:
+        plain = _run(net, gpu, audio, steps)
+    finally:
+        del os.environ["DWS_SASHIMI_NO_LN_FUSION"]
+    assert rel_err(fused, plain) < 1e-5
+    assert torch.equal(fused, _run(net, gpu, audio, steps))
