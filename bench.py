@@ -116,6 +116,22 @@ def sashimi_tail_work(cfg):
     return flops, bytes_, len(blocks)
 
 
+def forward_gemm_flops(cfg, B):
+    """Algorithmic flops of the dense contractions of ONE forward over a batch of B: WaveNet
+    B L [n (14 C^2 + 2 C S) + 2 S^2]; SaShiMi: 12 H^2 per position per block + 4 H_in H_out-style pool GEMMs + the final
+    D x D conv.  A training step (forward, data gradients, weight gradients) is 3x this."""
+    m, L = cfg["model"], cfg["L"]
+    if m["_name_"] == "wavenet":
+        C, S, n = m["res_channels"], m["skip_channels"], m["num_res_layers"]
+        return B * L * (n * (14 * C * C + 2 * C * S) + 2 * S * S)
+    flops, _, _ = sashimi_tail_work(dict(cfg, B=B))
+    H, Ls = m["d_model"], L
+    for p in m["pool"]:      # DownPool (H p -> H e) at L/p positions, UpPool (H e -> H p) at L/p positions
+        flops += 2 * 2 * (H * p) * (H * m["expand"]) * (Ls // p) * B
+        H, Ls = H * m["expand"], Ls // p
+    return flops + 2 * m["d_model"] ** 2 * L * B
+
+
 def cpu_baseline(cfg, seconds_budget=25.0):
     """The oracle (reference-equivalent PyTorch-CPU graph: conv1d per layer, weight-norm
     per call, no hoisting) timed on this box's host cores at B=1; bounded sample.
@@ -239,8 +255,31 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
     elapsed = ddist.max_over_ranks(mine, red_dev)
     per_rank_ms = [t / args.steps * 1e3 for t in ddist.gather_over_ranks(mine, red_dev)]
     ms = elapsed / args.steps * 1e3
+    roofline = None
+    if world == 1 and not args.no_roofline:     # (an extra step on one rank only would hang the other ranks' all-reduce)
+        # the MFMA GEMM kernels of one step (forward layer / 1x1 GEMMs, data gradients, weight gradients), timed with
+        # HIP events on their launch stream; algorithmic flops = 3 x the forward's dense contractions
+        import ctypes
+        from diffwave_sashimi_amd import _lib
+        lib = _lib.load()
+        _lib.check(lib.dws_profile_enable(b"mfma"))
+        step()
+        torch.cuda.synchronize()
+        n_launch, tot_ms = ctypes.c_int64(), ctypes.c_double()
+        _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
+        lib.dws_profile_disable()
+        flops = 3 * forward_gemm_flops(cfg, B)
+        if n_launch.value > 0:
+            ach = flops / (tot_ms.value * 1e-3) / 1e12
+            roofline = {"kernel": "all MFMA GEMM launches of one training step (tapconv_mfma / wgrad_mfma / forward layer): "
+                                  "%d launches" % n_launch.value,
+                        "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "ms_per_step_in_kernels": tot_ms.value,
+                        "algorithmic_flops_per_step": flops,
+                        "whole_step_frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
     if rank == 0:
         print(json.dumps({
+            **({"roofline": roofline} if roofline else {}),
             "metric": "training audio samples/sec (train.py-style DP step: fwd + bwd + grad all-reduce + Adam)",
             "value": ddist.aggregate_throughput(B * L, world, ms * 1e-3), "unit": "audio samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
