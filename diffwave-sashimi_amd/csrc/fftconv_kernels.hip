@@ -94,6 +94,37 @@ __device__ __forceinline__ void fft_inverse(float2* X, const float2* tw, const F
     }
 }
 
+// Forward transform of a zero-padded row straight from global memory: `src` holds n_valid (<= M/2) packed complex points,
+// the rest of the M-point row is zero.  Even sizes: the top radix-16 pass runs on registers (a thread's 16 points are
+// g + (M/16) r, of which r >= 8 are padding and never loaded) and only its result goes to LDS; odd sizes stage the row
+// in LDS first.  The caller must have passed a barrier since the last read of X.
+template <int LOG2M, int NG>
+__device__ __forceinline__ void fft_forward_global(float2* X, const float2* __restrict__ src, int n_valid, const float2* tw,
+                                                   const FftTw<LOG2M, NG>& W, int tid) {
+    constexpr int M = 1 << LOG2M, G = M / 16, THREADS = G / NG;
+    if constexpr (!FftPlan<LOG2M>::ODD) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            if (i) __builtin_amdgcn_sched_barrier(0);
+            const int g = tid + i * THREADS;
+            float2 x[16];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = (g + G * r < n_valid) ? src[g + G * r] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int r = 8; r < 16; ++r) x[r] = make_float2(0.f, 0.f);
+            fft16<false, true, true>(x, W.theta[0][i]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[pidx(g + G * r)] = x[r];
+        }
+        __syncthreads();
+        fft_forward_from<LOG2M, NG, 1>(X, W, tid);
+    } else {
+        for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < n_valid) ? src[j] : make_float2(0.f, 0.f);
+        __syncthreads();
+        fft_forward<LOG2M, NG>(X, tw, W, tid);
+    }
+}
+
 // Pointwise stage in bit-reversed order (fft_core.h: pointwise_pair / pointwise_self), M/2 pairs over the workgroup.
 template <int LOG2M, int THREADS>
 __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const float2* __restrict__ twp,
@@ -151,48 +182,15 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     W.load(a.tw, tid);
     const float scale = 1.f / (float)M, csign = a.conj_k ? -1.f : 1.f;
     const RowSchedule sch(a.B * a.H);
-    // rows of one channel h are adjacent (the kernel spectrum is shared by the batch)
-    auto row_u = [&](int row) {
-        const int h = row / a.B, b = row % a.B;
-        return reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
-    };
-    // fetching the next row's points before the last pass of the current one was measured SLOWER (99 vs 88 us at
-    // M = 16384: 16 more live registers at the 128-VGPR limit of a 1024-thread workgroup): off, kept for wider budgets
-    constexpr bool PREFETCH = false;
-    float2 xin[DIRECT ? 8 : 1];     // the next row's input points, fetched while the current row is finished
-    auto fetch = [&](int row) {
-        if constexpr (DIRECT) {
-            const float2* __restrict__ u2 = row_u(row);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = tid + THREADS * r;
-                xin[r] = (i < Lc) ? u2[i] : make_float2(0.f, 0.f);
-            }
-        }
-    };
-    if (PREFETCH && sch.first < sch.end) fetch(sch.first);
+    // (fetching the next row's points before the last pass of the current one was measured SLOWER: 99 vs 88 us at
+    // M = 16384 -- 16 more live registers at the 128-VGPR limit of a 1024-thread workgroup)
 #pragma unroll 1
     for (int row = sch.first; row < sch.end; row += sch.step) {
+        // rows of one channel h are adjacent (the kernel spectrum is shared by the batch)
         const int h = row / a.B, b = row % a.B;
         const size_t off = ((size_t)b * a.H + h) * L;
         const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + off);
-        if constexpr (DIRECT) {
-            if (!PREFETCH) fetch(row);
-            float2 x[16];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) x[r] = xin[r];
-#pragma unroll
-            for (int r = 8; r < 16; ++r) x[r] = make_float2(0.f, 0.f);
-            fft16<false, true, true>(x, W.theta[0][0]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) X[pidx(tid + THREADS * r)] = x[r];
-            __syncthreads();
-            fft_forward_from<LOG2M, 1, 1>(X, W, tid);
-        } else {
-            for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
-            __syncthreads();
-            fft_forward<LOG2M, NG>(X, a.tw, W, tid);
-        }
+        fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid);
         pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
                                         a.kfs + (size_t)h * 3, tid, csign);
         __syncthreads();
@@ -206,8 +204,6 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
         };
         if constexpr (DIRECT) {
             fft_inverse_to<LOG2M, 1, 1>(X, W, tid);
-            // the next row's input is in flight during the last pass and the GELU epilogue
-            if (PREFETCH && row + sch.step < sch.end) fetch(row + sch.step);
             float2 x[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = X[pidx(tid + THREADS * r)];
@@ -267,9 +263,7 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
         int tid = opaque(tid0);
         const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
         const float2* __restrict__ d2 = reinterpret_cast<const float2*>(a.da + ((size_t)b * a.H + h) * L);
-        for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
-        __syncthreads();
-        fft_forward<LOG2M, NG>(X, a.tw, W, tid);
+        fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid);
         tid = opaque(tid0);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -289,9 +283,7 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
         }
         __syncthreads();
         tid = opaque(tid0);
-        for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < Lc) ? d2[j] : make_float2(0.f, 0.f);
-        __syncthreads();
-        fft_forward<LOG2M, NG>(X, a.tw, W, tid);
+        fft_forward_global<LOG2M, NG>(X, d2, Lc, a.tw, W, tid);
         tid = opaque(tid0);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -354,9 +346,7 @@ __global__ __launch_bounds__(THREADS) void fftconv_seg_kernel(FftConvSegArgs a) 
         if (sj < 0 || sj >= nseg) continue;        // uniform over the block
         int tid = opaque(tid0);
         const int c0 = sj * (S / 2), cn = min(S / 2, L / 2 - c0);   // packed points of this segment that exist
-        for (int i = tid; i < M; i += THREADS) X[pidx(i)] = (i < cn) ? u2[c0 + i] : make_float2(0.f, 0.f);
-        __syncthreads();
-        fft_forward<LOG2M, NG>(X, a.tw, W, tid);
+        fft_forward_global<LOG2M, NG>(X, u2 + c0, cn, a.tw, W, tid);
         tid = opaque(tid0);
         const float2* __restrict__ kfa = a.kfa[t] + (size_t)h * (M / 2);
         const float2* __restrict__ kfb = a.kfb[t] + (size_t)h * (M / 2);

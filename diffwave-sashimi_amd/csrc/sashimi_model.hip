@@ -872,9 +872,14 @@ struct SashimiModel : dws_model {
                 fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
                 fa.B = nB; fa.H = H; fa.L = Ls;
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
-                DWS_TRY(gemm(l->tAo.f(), 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"), nullptr,
-                             nullptr, nullptr, nullptr, s));
-                DWS_TRY(launch_glu_res(l->t_o.f(), x, melBm ? l->melc.f() : nullptr, l->t_x1.f(), nB, H, Ls, s));
+                if (tapconv_glu_supported(2 * H, H, Ls)) {   // o and x1 = x + GLU(o) (+ mel) from one kernel
+                    DWS_TRY(gemm(l->tAo.f(), 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 6, P(p + ".layer.output_linear.0.bias"), x,
+                                 nullptr, melBm ? l->melc.f() : nullptr, l->t_x1.f(), s));
+                } else {
+                    DWS_TRY(gemm(l->tAo.f(), 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"),
+                                 nullptr, nullptr, nullptr, nullptr, s));
+                    DWS_TRY(launch_glu_res(l->t_o.f(), x, melBm ? l->melc.f() : nullptr, l->t_x1.f(), nB, H, Ls, s));
+                }
                 DWS_TRY(launch_ln(l->t_x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, l->t_n2.f(), nB, H, Ls,
                                   (size_t)Ls, s));
                 DWS_TRY(gemm(l->tA1.f(), FF * H, H, l->t_n2.f(), l->t_f1.f(), Ls, 3, P(p + ".ff.ff.0.conv.bias"), nullptr,

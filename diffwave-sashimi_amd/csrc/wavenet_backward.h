@@ -31,7 +31,8 @@ struct TapConvArgs {
     const float* A;              // A fragments of the [M][nkg_total*8] transposed weight (pack_a_frag order)
     int nkg_total;               // k-groups per fragment row in A (the launch may use a prefix of them)
     int M, T, dil, sign;         // tap t reads position l + sign * (t - T/2) * dil
-    int epi;                     // see the kernel: 0 add, 1 gate adjoint, 2 bias, 3 bias+gelu (pre and act), 4 bias+res, 5 gelu'
+    int epi;                     // see the kernel: 0 add, 1 gate adjoint, 2 bias, 3 bias+gelu (pre and act), 4 bias+res, 5 gelu',
+                                 // 6 bias + GLU + residual (out = o, out2 = x1 = res + o_a sigmoid(o_b) (+ aux))
     float* out;
     const float* addin; float addscale;
     const float* H; float* dH; float* g;
@@ -39,6 +40,7 @@ struct TapConvArgs {
     int B, L;
 };
 bool tapconv_mfma_supported(int M, int K0, int K1, int T);
+bool tapconv_glu_supported(int M, int K, int L);   // epilogue 6 (GLU + residual fused into the 2H x H GEMM)
 int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s);
 int launch_tapconv_pack_transposed(const float* W, float* out, int O, int C, int T, int ldo, int coff, float scale,
                                    hipStream_t s);

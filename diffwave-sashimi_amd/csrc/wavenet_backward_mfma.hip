@@ -36,6 +36,9 @@ __device__ __forceinline__ float gelu_grad_b(float x) { return dws_gelu_grad(x);
 //   0  out = acc (+ addin * addscale)                       1  gate adjoint (WaveNet)
 //   2  out = acc + bias[m]                                   3  out = acc + bias (pre-activation), out2 = gelu(out)
 //   4  out = acc + bias + res (+ addend)                     5  out = acc * gelu'(aux)
+//   6  GLU + residual (`s4.py:1435`, `sashimi.py:177`), M = 2H, MT = 2: a wave owns the 32-row tiles q and q + H/32
+//      (the two GLU halves of the same channels): out = o = acc + bias [B,2H,L] and
+//      out2 = x1 = res + o_a sigmoid(o_b) (+ aux)  [B,H,L]
 template <int MT, int T, int EPI>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void tapconv_mfma_kernel(TapConvArgs a) {
     constexpr int P = 64, NT = 2, KC = 32;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int lane16 = lane * 16;
     int mt[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) mt[m] = mt0 + wave * MT + m;
+    for (int m = 0; m < MT; ++m) mt[m] = (EPI == 6) ? blockIdx.y * 4 + wave + m * (a.M / 64) : mt0 + wave * MT + m;
     // rows beyond M (M not a multiple of the M-block): the wave only helps staging; A loads are OOB -> 0
     const bool wave_live = mt[0] * 32 < a.M;
 
@@ -143,6 +146,42 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int lrow = lane >> 4, p4 = (lane & 15) * 4;
         const int voff = (l0 + p4 < L) ? (lrow * L + l0 + p4) * 4 : OOB;
         const bool has_bias = a.bias != nullptr, has_addin = a.addin != nullptr, has_addend = a.addend != nullptr;
+        if constexpr (EPI == 6) {
+            static_assert(MT == 2, "the GLU epilogue pairs two M-tiles per wave");
+            const int Hh = M / 2;
+            const size_t boff2 = (size_t)b * Hh * L;
+            const int HL4 = Hh * L * 4;
+            __amdgpu_buffer_rsrc_t rX1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out2 + boff2), 0, HL4, 0x00020000);
+            __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res + boff2), 0, HL4, 0x00020000);
+            __amdgpu_buffer_rsrc_t rMel = __builtin_amdgcn_make_buffer_rsrc((void*)((a.aux ? a.aux : a.res) + boff2), 0, HL4, 0x00020000);
+            const bool has_mel = a.aux != nullptr;
+            f32x4 va[8];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * lhi) * P + n * 32 + l31] = acc[m][n][r];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row0 = mt[m] * 32 + it * 4;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(wl + (it * 4 + lrow) * P + p4);
+                    if (has_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, lrow * 4, row0 * 4, 0));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rOut, voff, row0 * L4, 0);
+                    if (m == 0) {
+                        va[it] = v;
+                    } else {
+                        const int soff2 = (mt[0] * 32 + it * 4) * L4;      // the channel rows in the [B,H,L] tensors
+                        f32x4 x1 = buf_load4(rRes, voff, soff2);
+                        if (has_mel) x1 += buf_load4(rMel, voff, soff2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x1[j] += va[it][j] * sigm_b(v[j]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x1), rX1, voff, soff2, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -253,13 +292,22 @@ bool tapconv_mfma_supported(int M, int K0, int K1, int T) {
     return M % 32 == 0 && M > 0 && K0 % 32 == 0 && K1 % 32 == 0 && (K0 + K1) > 0 && (T == 1 || T == 3);
 }
 
+// epilogue 6 exists for MT = 2 only (M % 256 == 0) and needs the float4 epilogue (L % 4 == 0)
+bool tapconv_glu_supported(int M, int K, int L) {
+    return tapconv_mfma_supported(M, K, 0, 1) && M % 256 == 0 && (L & 3) == 0;
+}
+
 template <int T, int EPI>
 static int launch_tc(const TapConvArgs& a, hipStream_t s) {
     const int nt = a.B * ceil_div(a.L, 64);
-    if (a.M % 256 == 0)   // M-blocks are always full with MT = 2; with MT = 1 a partial block idles whole waves
-        hipLaunchKernelGGL((tapconv_mfma_kernel<2, T, EPI>), dim3(nt, ceil_div(a.M, 256)), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((tapconv_mfma_kernel<1, T, EPI>), dim3(nt, ceil_div(a.M, 128)), dim3(256), 0, s, a);
+    if constexpr (EPI == 6) {
+        hipLaunchKernelGGL((tapconv_mfma_kernel<2, T, EPI>), dim3(nt, a.M / 256), dim3(256), 0, s, a);
+    } else {
+        if (a.M % 256 == 0)   // M-blocks are always full with MT = 2; with MT = 1 a partial block idles whole waves
+            hipLaunchKernelGGL((tapconv_mfma_kernel<2, T, EPI>), dim3(nt, ceil_div(a.M, 256)), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((tapconv_mfma_kernel<1, T, EPI>), dim3(nt, ceil_div(a.M, 128)), dim3(256), 0, s, a);
+    }
     return DWS_OK;
 }
 
@@ -278,6 +326,10 @@ int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s) {
         case 3: return launch_tc<1, 3>(a, s);
         case 4: return launch_tc<1, 4>(a, s);
         case 5: return launch_tc<1, 5>(a, s);
+        case 6:
+            DWS_CHECK(tapconv_glu_supported(a.M, a.K0, a.L) && a.K1 == 0 && a.out2 && a.res, DWS_ERR_UNSUPPORTED,
+                      "tapconv_mfma: GLU epilogue needs M %% 256 == 0, L %% 4 == 0 (M=%d L=%d)", a.M, a.L);
+            return launch_tc<1, 6>(a, s);
     }
     return set_error(DWS_ERR_INVALID, "tapconv_mfma: epilogue %d", a.epi);
 }
