@@ -4,6 +4,7 @@
 // the 1x1 conv's two GEMMs run on the MFMA adjoint kernels (80 mel bands padded to 96 rows for the data gradient).
 #include "conditioner.h"
 #include "wavenet.h"
+#include "sashimi_train.h"
 #include "wavenet_backward.h"
 
 namespace dws {
@@ -13,7 +14,6 @@ int conditioner_backward(CondTrainWs& ws, const float* mel, int B, int MB, int T
                          const float* dmelc, float* gW0f, float* gb0, float* gW1f, float* gb1, float* gWcf, hipStream_t s) {
     const int T0 = mel_upsampled_len(Tmel, s0), T1 = mel_upsampled_len(T0, s1);
     const int MP = ceil_div(MB, 32) * 32;   // mel bands padded to whole MFMA tiles
-    DWS_CHECK(O % 32 == 0, DWS_ERR_UNSUPPORTED, "conditioner training needs channel counts that are multiples of 32 (got %d)", O);
     DWS_TRY(ws.u0.ensure((size_t)B * MB * T0 * 4));
     DWS_TRY(ws.u1.ensure((size_t)B * MB * T1 * 4));
     DWS_TRY(ws.du0.ensure((size_t)B * MB * T0 * 4));
@@ -35,11 +35,17 @@ int conditioner_backward(CondTrainWs& ws, const float* mel, int B, int MB, int T
     {
         DWS_HIP(hipMemsetAsync(ws.tmp.p, 0, (size_t)MP * O * 4, s));
         DWS_TRY(launch_tapconv_pack_transposed(Wcf, ws.tmp.f(), O, MB, 1, O, 0, 1.f, s));
+        if (O % 32 != 0) {   // test-sized models: plain-FMA GEMM on the row-major transpose [MP][O]
+            GemmRowsArgs g{};
+            g.W = ws.tmp.f(); g.src = dmelc; g.out = ws.du1.f(); g.B = B; g.M = MP; g.K = O; g.L = L; g.epi = 2;
+            DWS_TRY(launch_gemm_rows_generic(g, s));
+        } else {
         DWS_TRY(launch_pack_a_frag(ws.tmp.f(), ws.AT.f(), MP, O, s));
         TapConvArgs q{};
         q.src0 = dmelc; q.K0 = O; q.A = ws.AT.f(); q.nkg_total = O / 8; q.M = MP; q.T = 1; q.dil = 1; q.sign = 1; q.epi = 2;
         q.out = ws.du1.f(); q.B = B; q.L = L;
         DWS_TRY(launch_tapconv_mfma(q, s));
+        }
     }
     DWS_TRY(launch_mel_upsample_bwd(ws.u0.f(), ws.u1.f(), ws.du1.f(), W1f, ws.du0.f(), gW1f, gb1, B, MB, T0, T1, s1, L, MP * L,
                                     L, 0.4f, s));

@@ -727,18 +727,33 @@ struct SashimiModel : dws_model {
         return (l->kind == L_BLOCK) ? (size_t)B * l->H * l->L : (size_t)B * l->Hout * l->Lout;
     }
 
-    // A-fragment pack of W [O][K] and of its transpose (the adjoint GEMM), optionally scaled
+    // Row-major weights behind the packed operands handed to gemm(): shapes the MFMA position-tile GEMM does not tile
+    // (rows or contraction not a multiple of 32: test-sized models) run the plain-FMA GEMM on these instead.
+    struct RowMajor { const float* w; int M, K; };
+    std::map<const float*, RowMajor> row_major;
+    DevBuf rAfT;
+    std::vector<DevBuf*> row_major_bufs;   // owned transposes
+
+    // A-fragment pack of W [O][K] and of its transpose (the adjoint GEMM)
     int pack_pair(const float* W, int O, int K, DevBuf& A, DevBuf& AT, hipStream_t s) {
         DWS_TRY(tmp_pack.ensure((size_t)O * K * 4));
         DWS_TRY(A.ensure((size_t)O * K * 4));
         DWS_TRY(AT.ensure((size_t)O * K * 4));
-        DWS_TRY(launch_pack_a_frag(W, A.f(), O, K, s));
-        DWS_TRY(launch_tapconv_pack_transposed(W, tmp_pack.f(), O, K, 1, O, 0, 1.f, s));
-        DWS_TRY(launch_pack_a_frag(tmp_pack.f(), AT.f(), K, O, s));
+        if (tapconv_mfma_supported(O, K, 0, 1) && tapconv_mfma_supported(K, O, 0, 1)) {
+            DWS_TRY(launch_pack_a_frag(W, A.f(), O, K, s));
+            DWS_TRY(launch_tapconv_pack_transposed(W, tmp_pack.f(), O, K, 1, O, 0, 1.f, s));
+            DWS_TRY(launch_pack_a_frag(tmp_pack.f(), AT.f(), K, O, s));
+            return DWS_OK;
+        }
+        // generic: A / AT only serve as keys; AT's storage holds the row-major transpose itself
+        DWS_TRY(launch_tapconv_pack_transposed(W, AT.f(), O, K, 1, O, 0, 1.f, s));
+        row_major[A.f()] = RowMajor{W, O, K};
+        row_major[AT.f()] = RowMajor{AT.f(), K, O};
         return DWS_OK;
     }
 
     int pack_train(hipStream_t s) {
+        row_major.clear();
         for (auto* l : all) {
             if (l->kind == L_BLOCK) {
                 const int H = l->H;
@@ -753,8 +768,13 @@ struct SashimiModel : dws_model {
         }
         DWS_TRY(tmp_pack.ensure((size_t)D * D * 4));
         DWS_TRY(tAfT.ensure((size_t)D * D * 4));
-        DWS_TRY(launch_tapconv_pack_transposed(Wf.f(), tmp_pack.f(), D, D, 1, D, 0, 1.f, s));
-        DWS_TRY(launch_pack_a_frag(tmp_pack.f(), tAfT.f(), D, D, s));
+        if (tapconv_mfma_supported(D, D, 0, 1)) {
+            DWS_TRY(launch_tapconv_pack_transposed(Wf.f(), tmp_pack.f(), D, D, 1, D, 0, 1.f, s));
+            DWS_TRY(launch_pack_a_frag(tmp_pack.f(), tAfT.f(), D, D, s));
+        } else {
+            DWS_TRY(launch_tapconv_pack_transposed(Wf.f(), tAfT.f(), D, D, 1, D, 0, 1.f, s));
+            row_major[tAfT.f()] = RowMajor{tAfT.f(), D, D};
+        }
         train_pack_version = commit_version;
         return DWS_OK;
     }
@@ -762,6 +782,15 @@ struct SashimiModel : dws_model {
     // out[b, m, l] = epi(sum_k A[m, k] src[b, k, l])   (tapconv_mfma, T = 1)
     int gemm(const float* A, int M, int K, const float* src, float* out, int Lx, int epi, const float* bias,
              const float* res, const float* addend, const float* aux, float* out2, hipStream_t s) {
+        auto it = row_major.find(A);
+        if (it != row_major.end()) {
+            DWS_CHECK(it->second.M == M && it->second.K == K, DWS_ERR_STATE, "gemm: operand registered as %d x %d, used as %d x %d",
+                      it->second.M, it->second.K, M, K);
+            GemmRowsArgs g{};
+            g.W = it->second.w; g.src = src; g.out = out; g.bias = bias; g.res = res; g.addend = addend; g.aux = aux;
+            g.addin = (epi == 0) ? aux : nullptr; g.out2 = out2; g.B = (int)B; g.M = M; g.K = K; g.L = Lx; g.epi = epi;
+            return launch_gemm_rows_generic(g, s);
+        }
         TapConvArgs q{};
         q.src0 = src; q.K0 = K; q.A = A; q.nkg_total = K / 8; q.M = M; q.T = 1; q.dil = 1; q.sign = 1; q.epi = epi;
         q.out = out; q.bias = bias; q.res = res; q.addend = addend; q.aux = aux; q.out2 = out2;
@@ -799,11 +828,9 @@ struct SashimiModel : dws_model {
                           "sashimi training needs the fused FFT convolution (L even, <= 16384 per stage); stage L=%d", l->L);
                 DWS_CHECK(l->Lk == l->L, DWS_ERR_UNSUPPORTED,
                           "sashimi training runs at the kernels' own length (stage runs at %d, kernel length %d)", l->L, l->Lk);
-                DWS_CHECK(l->H % 32 == 0, DWS_ERR_UNSUPPORTED, "sashimi training needs channel counts that are multiples of 32 (H=%d)", l->H);
             }
         }
-        DWS_CHECK(D % 32 == 0, DWS_ERR_UNSUPPORTED, "sashimi training needs d_model %% 32 == 0");
-        return DWS_OK;
+        return DWS_OK;   // channel counts that are not multiples of 32 train on the plain-FMA GEMM (row_major)
     }
 
     int ensure_train_buffers() {

@@ -11,6 +11,14 @@ int launch_glu_bwd(const float* dx1, const float* o, float* dout, int B, int H, 
 int launch_pool_rearrange(const float* in, float* out, const float* addend, int dir, int accumulate, int B, int H,
                           int p, int Lp, hipStream_t s);
 int launch_add_into(const float* a, float* out, int accumulate, size_t n, hipStream_t s);
+// Plain-FMA 1x1 GEMM with the epilogues 0, 2, 3, 4, 5 of tapconv_mfma_kernel, for channel counts its 32-row tiles do not
+// cover (test-sized models):  out[b, m, l] = epi(sum_k W[m, k] src[b, k, l]),  W row-major [M][K].
+struct GemmRowsArgs {
+    const float* W; const float* src; float* out;
+    const float* bias; const float* res; const float* addend; const float* aux; const float* addin; float* out2;
+    int B, M, K, L, epi;
+};
+int launch_gemm_rows_generic(const GemmRowsArgs& a, hipStream_t s);
 int launch_s4_twosided_pow2_bwd(const float* dK, float* dkt, float* dD, int H, int L, int Nf, float sc, float scD,
                                 hipStream_t s);
 int launch_s4_woodbury_bwd(const float* r, const float* omega, const float* dt, const float* dkf, float* gr,

@@ -224,6 +224,37 @@ int launch_sum_leading(const float* partial, float* out, size_t n, int k, float 
 }
 
 // ---------------------------------------------------------------------------
+// Plain-FMA 1x1 GEMM (GemmRowsArgs): thread = position, block = (64 positions, one output row, one batch element).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gemm_rows_generic_kernel(GemmRowsArgs a) {
+    const int l = blockIdx.x * 64 + threadIdx.x, m = blockIdx.y, b = blockIdx.z;
+    if (l >= a.L) return;
+    const float* __restrict__ w = a.W + (size_t)m * a.K;
+    const float* __restrict__ x = a.src + (size_t)b * a.K * a.L + l;
+    float acc = 0.f;
+    for (int k = 0; k < a.K; ++k) acc = fmaf(w[k], x[(size_t)k * a.L], acc);
+    const size_t i = ((size_t)b * a.M + m) * a.L + l;
+    switch (a.epi) {
+        case 0: a.out[i] = acc + (a.addin ? a.addin[i] : 0.f); break;
+        case 2: a.out[i] = acc + (a.bias ? a.bias[m] : 0.f); break;
+        case 3: {
+            const float v = acc + (a.bias ? a.bias[m] : 0.f);
+            a.out[i] = v;
+            a.out2[i] = dws_gelu(v);
+            break;
+        }
+        case 4: a.out[i] = acc + a.bias[m] + a.res[i] + (a.addend ? a.addend[i] : 0.f); break;
+        default: a.out[i] = acc * dws_gelu_grad(a.aux[i]); break;   // 5
+    }
+}
+
+int launch_gemm_rows_generic(const GemmRowsArgs& a, hipStream_t s) {
+    DWS_CHECK(a.epi == 0 || (a.epi >= 2 && a.epi <= 5), DWS_ERR_INVALID, "gemm_rows_generic: epilogue %d", a.epi);
+    hipLaunchKernelGGL(gemm_rows_generic_kernel, dim3(ceil_div(a.L, 64), a.M, a.B), dim3(64), 0, s, a);
+    return DWS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // GLU + residual (`s4.py:1435`, `sashimi.py:177`): x1 = x + o_a * sigmoid(o_b), o = [o_a; o_b] [B, 2H, L]
 // ---------------------------------------------------------------------------
 __global__ void glu_res_kernel(const float* __restrict__ o, const float* __restrict__ x, const float* __restrict__ mel,

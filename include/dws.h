@@ -151,7 +151,8 @@ int dws_model_set_condition(dws_model* m, const float* mel, int64_t Bm, int64_t 
 int dws_model_forward(dws_model* m, const float* audio, const float* steps, float* out, void* stream);
 
 /* Training path (`train.py:198-222`): both backbones, unconditional and mel-conditional, fp32 precision
- * (precision=bf16x3 and SaShiMi channel counts that are not multiples of 32 return DWS_ERR_UNSUPPORTED).
+ * (precision=bf16x3 returns DWS_ERR_UNSUPPORTED; SaShiMi channel counts that are not multiples of 32 train on a
+ * plain-FMA GEMM instead of the MFMA adjoints).
  * forward_train == forward but keeps the activations backward needs inside the model -- of ONE forward:
  * every forward_train must be followed by its backward before the next forward_train.  backward takes dLoss/d(eps)[B, out_channels, L] and produces the gradient of every RAW
  * state-dict tensor (weight_g / weight_v / bias ...), fetched with get_grad (device copy).  The

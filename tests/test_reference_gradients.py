@@ -57,16 +57,27 @@ def test_oracle_autograd_matches_reference_gradients(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ss", "ss_cond"])
 def test_engine_backward_matches_reference_gradients(gpu, name):
-    """The tiny SaShiMi fixtures run on the engine's generic forward kernels but need H % 32 == 0 for the MFMA adjoints:
-    they are expected to raise; the channel counts the engine trains at are checked against the oracle (which the test
-    above pins to these reference gradients) in test_*_training_gpu.py."""
+    """The tiny SaShiMi fixtures (d_model = 8: channel counts 8 / 32 / 128 that the MFMA adjoints only partly tile) train
+    on the engine too -- the 1x1 GEMMs of such stages run the plain-FMA kernel -- and are compared with the REFERENCE's
+    gradients, unconditional and mel-conditional."""
+    from diffwave_sashimi_amd.models import construct_model
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from tests import gradcheck
     g = load_golden("grads")
     cfg, B, L, sd0, ref, audio, mel, ref_loss = _case(g, name)
-    from diffwave_sashimi_amd.models import construct_model
     net = construct_model(dict(cfg)).to(gpu).train()
     net.load_state_dict({k: v.to(gpu) for k, v in sd0.items()})
-    with pytest.raises(NotImplementedError):
-        _loss(net, audio.to(gpu), None if mel is None else mel.to(gpu)).backward()
+    loss = _loss(net, audio.to(gpu), None if mel is None else mel.to(gpu))
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    assert set(got) == set(ref)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}     # after the in-place _setup_C
+    loss_of = gradcheck.mse_training_loss(audio, calc_diffusion_hyperparams(50, 1e-4, 0.05), mel, seed=314)
+    _, truth = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float64)
+    _, o32 = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
+    worst, k = gradcheck.compare(got, ref, {k: truth[k] for k in ref}, fp32_impls=({k: o32[k] for k in ref},), label=name)
+    print(f"engine vs reference ({name}): worst {worst:.2e} at {k}")
 
 
 @pytest.mark.gpu
