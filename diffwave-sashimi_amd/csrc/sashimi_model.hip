@@ -71,6 +71,10 @@ struct SLayer {
     DevBuf kfa, kfb, kfs; // fused path: pair-ordered spectrum at the power-of-two size (fftconv.h)
     int log2m = 0;        // > 0: fused LDS FFT convolution is used for this block
     bool seg = false;     // stage longer than the largest LDS transform: segmented fused path (fftconv_seg_kernel)
+    // training: the Cauchy products of the kernel generation (v, w dt, dt, r: `s4.py:740-775`) are kept per block so the
+    // backward does not regenerate them (one Cauchy forward per block and step less); valid for commit cache_version
+    DevBuf t_cv, t_cwdt, t_cdt, t_cr;
+    uint64_t cache_version = ~0ull;
     DevBuf kfa_c, kfb_c, kfs_c, kfa_a, kfb_a, kfs_a;   // seg: spectra of the causal / anti-causal kernel half, shifted
     DevBuf melW0, melW1, melWc, melc;
     DevBuf out;           // activation produced by this layer
@@ -116,6 +120,7 @@ struct SashimiModel : dws_model {
     DevBuf dx_init, ty, ta1, ta2, tAfT, tmp_pack, wpart, dWfold, lnpart, pool_scr, dpt, dh2, dh1, dWt_all, dbt_all;
     DevBuf bpart, fpart, dKf, dKt, dkt, dkf, cgr, cgv, cgw, cpdt, dyb, dnf;
     uint64_t commit_version = 0, train_pack_version = ~0ull;
+    bool keep_cauchy = false;         // set by the first forward_train: build_kernel then fills the per-block caches
     bool trained_fwd = false;
     const float* train_audio = nullptr;
     DevBuf mel_in;                    // copy of the installed mel [Bm][MB][Tmel] (conditioner adjoint)
@@ -280,16 +285,22 @@ struct SashimiModel : dws_model {
         const std::string zname = "__z." + std::to_string(Lk), oname = "__omega." + std::to_string(Lk);
         DWS_CHECK(P(zname) && P(oname), DWS_ERR_STATE, "FFT nodes %s / %s were not handed to the engine", zname.c_str(),
                   oname.c_str());
-        DWS_TRY(cv.ensure((size_t)6 * H * N * 8));
-        DWS_TRY(cwdt.ensure((size_t)H * N * 8));
-        DWS_TRY(cdt.ensure((size_t)H * 4));
-        DWS_TRY(cr.ensure((size_t)6 * H * Lh * 8));
+        // training keeps the Cauchy products per block (kernel_backward reads them); sampling shares one scratch
+        DevBuf& bv = keep_cauchy ? l->t_cv : cv;
+        DevBuf& bw = keep_cauchy ? l->t_cwdt : cwdt;
+        DevBuf& bd = keep_cauchy ? l->t_cdt : cdt;
+        DevBuf& br = keep_cauchy ? l->t_cr : cr;
+        DWS_TRY(bv.ensure((size_t)6 * H * N * 8));
+        DWS_TRY(bw.ensure((size_t)H * N * 8));
+        DWS_TRY(bd.ensure((size_t)H * 4));
+        DWS_TRY(br.ensure((size_t)6 * H * Lh * 8));
         DWS_TRY(ckf.ensure((size_t)2 * H * Lh * 8));
         DWS_TRY(ck.ensure((size_t)2 * H * Lk * 4));
         DWS_TRY(launch_s4_prep(P(k + ".C"), P(k + ".B"), P(k + ".P"), P(k + ".inv_w_real"), P(k + ".w_imag"),
-                               P(k + ".log_dt"), cv.f(), cwdt.f(), cdt.f(), H, N, s));
-        DWS_TRY(launch_cauchy_sym_fwd_bcast(cv.f(), P(zname), cwdt.f(), cr.f(), 6 * H, N, Lh, H, s));
-        DWS_TRY(launch_s4_woodbury(cr.f(), P(oname), cdt.f(), ckf.f(), H, Lh, (Lk % 2) == 0, s));
+                               P(k + ".log_dt"), bv.f(), bw.f(), bd.f(), H, N, s));
+        DWS_TRY(launch_cauchy_sym_fwd_bcast(bv.f(), P(zname), bw.f(), br.f(), 6 * H, N, Lh, H, s));
+        DWS_TRY(launch_s4_woodbury(br.f(), P(oname), bd.f(), ckf.f(), H, Lh, (Lk % 2) == 0, s));
+        l->cache_version = keep_cauchy ? commit_version + 1 : ~0ull;   // commit() bumps commit_version when it is done
         hipfftHandle plan;
         DWS_TRY(fft.get(1, Lk, 2 * H, &plan));
         DWS_FFT(hipfftSetStream(plan, s));
@@ -871,6 +882,7 @@ struct SashimiModel : dws_model {
 
     int forward_train(const float* audio, const float* steps, float* out, hipStream_t s) override {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
+        keep_cauchy = true;
         if (dirty) DWS_TRY(commit(s));
         DWS_TRY(train_supported());
         DWS_TRY(ensure_train_buffers());
@@ -960,23 +972,30 @@ struct SashimiModel : dws_model {
         DWS_TRY(fft.get(0, Ls, 2 * H, &plan_));
         DWS_FFT(hipfftSetStream(plan_, s));
         DWS_FFT(hipfftExecR2C(plan_, (hipfftReal*)dkt.p, (hipfftComplex*)dkf.p));
-        // regenerate v, w dt, r of this block (commit shares one scratch between the blocks)
-        DWS_TRY(cv.ensure((size_t)6 * H * N * 8));
-        DWS_TRY(cwdt.ensure((size_t)H * N * 8));
-        DWS_TRY(cdt.ensure((size_t)H * 4));
-        DWS_TRY(cr.ensure((size_t)6 * H * Lh * 8));
+        // v, w dt, dt, r of this block: kept by build_kernel when this commit already ran in training mode, else regenerated
+        const bool cached = l->cache_version == commit_version && l->t_cr.p;
+        DevBuf& bv = cached ? l->t_cv : cv;
+        DevBuf& bw = cached ? l->t_cwdt : cwdt;
+        DevBuf& bd = cached ? l->t_cdt : cdt;
+        DevBuf& br = cached ? l->t_cr : cr;
         DWS_TRY(cgr.ensure((size_t)6 * H * Lh * 8));
         DWS_TRY(cgv.ensure((size_t)6 * H * N * 8));
         DWS_TRY(cgw.ensure((size_t)6 * H * N * 8));
         const int nparts = ceil_div(Lh, 256);
         DWS_TRY(cpdt.ensure((size_t)H * nparts * 4));
         const float* z = P("__z." + std::to_string(Ls));
-        DWS_TRY(launch_s4_prep(P(k + ".C"), P(k + ".B"), P(k + ".P"), P(k + ".inv_w_real"), P(k + ".w_imag"),
-                               P(k + ".log_dt"), cv.f(), cwdt.f(), cdt.f(), H, N, s));
-        DWS_TRY(launch_cauchy_sym_fwd_bcast(cv.f(), z, cwdt.f(), cr.f(), 6 * H, N, Lh, H, s));
-        DWS_TRY(launch_s4_woodbury_bwd(cr.f(), P("__omega." + std::to_string(Ls)), cdt.f(), dkf.f(), cgr.f(), cpdt.f(), H,
+        if (!cached) {
+            DWS_TRY(bv.ensure((size_t)6 * H * N * 8));
+            DWS_TRY(bw.ensure((size_t)H * N * 8));
+            DWS_TRY(bd.ensure((size_t)H * 4));
+            DWS_TRY(br.ensure((size_t)6 * H * Lh * 8));
+            DWS_TRY(launch_s4_prep(P(k + ".C"), P(k + ".B"), P(k + ".P"), P(k + ".inv_w_real"), P(k + ".w_imag"),
+                                   P(k + ".log_dt"), bv.f(), bw.f(), bd.f(), H, N, s));
+            DWS_TRY(launch_cauchy_sym_fwd_bcast(bv.f(), z, bw.f(), br.f(), 6 * H, N, Lh, H, s));
+        }
+        DWS_TRY(launch_s4_woodbury_bwd(br.f(), P("__omega." + std::to_string(Ls)), bd.f(), dkf.f(), cgr.f(), cpdt.f(), H,
                                        Lh, (Ls % 2) == 0, s));
-        DWS_TRY(launch_cauchy_sym_bwd_bcast(cv.f(), z, cwdt.f(), cgr.f(), cgv.f(), cgw.f(), 6 * H, N, Lh, H, s));
+        DWS_TRY(launch_cauchy_sym_bwd_bcast(bv.f(), z, bw.f(), cgr.f(), cgv.f(), cgw.f(), 6 * H, N, Lh, H, s));
         DWS_TRY(launch_s4_prep_bwd(P(k + ".C"), P(k + ".B"), P(k + ".P"), P(k + ".inv_w_real"), P(k + ".w_imag"),
                                    P(k + ".log_dt"), cgv.f(), cgw.f(), cpdt.f(), nparts, G(k + ".C"), G(k + ".B"), G(k + ".P"),
                                    G(k + ".inv_w_real"), G(k + ".w_imag"), G(k + ".log_dt"), H, N, s));

@@ -113,11 +113,18 @@ __global__ __launch_bounds__(64 * PARTS) void ln_bwd_reg_kernel(const float* __r
     const size_t off = (size_t)b * H * L + (ok ? l : 0);
     const float* __restrict__ xb = x + off;
     const float* __restrict__ db = dy + off;
-    float xv[RP], dv[RP];
+    constexpr bool PRE = RP <= 16;        // 3 x 32 values per thread do not fit the 128 VGPRs of a 1024-thread block
+    float xv[RP], dv[RP], bv[PRE ? RP : 1];
+    const float* __restrict__ bb = base ? base + off : nullptr;
 #pragma unroll
     for (int r = 0; r < RP; ++r) {
         xv[r] = xb[(size_t)(part + PARTS * r) * L];
         dv[r] = db[(size_t)(part + PARTS * r) * L];
+    }
+    // the residual gradient added at the end is fetched with the operands: all of the block's loads in flight at once
+    if (PRE) {
+#pragma unroll
+        for (int r = 0; r < RP; ++r) bv[PRE ? r : 0] = bb ? bb[(size_t)(part + PARTS * r) * L] : 0.f;
     }
     float sx = 0.f, sd = 0.f;
 #pragma unroll
@@ -150,12 +157,10 @@ __global__ __launch_bounds__(64 * PARTS) void ln_bwd_reg_kernel(const float* __r
     const float sc = s * rs;
     if (ok) {
         float* __restrict__ ob = out + off;
-        const float* __restrict__ bb = base ? base + off : nullptr;
 #pragma unroll
         for (int r = 0; r < RP; ++r) {
             const size_t ho = (size_t)(part + PARTS * r) * L;
-            float v = sc * (dv[r] - mdy - (xv[r] * rs) * c2);
-            if (bb) v += bb[ho];
+            float v = sc * (dv[r] - mdy - (xv[r] * rs) * c2) + (PRE ? bv[PRE ? r : 0] : (bb ? bb[ho] : 0.f));
             if (accumulate) v += ob[ho];
             ob[ho] = v;
         }
@@ -183,9 +188,9 @@ int launch_ln_bwd(const float* x, const float* dy, const float* m_p, const float
     switch (old_path ? 0 : H) {
         case 32: DWS_LN_BWD(8, 4); return DWS_OK;
         case 64: DWS_LN_BWD(16, 4); return DWS_OK;
-        case 128: DWS_LN_BWD(32, 4); return DWS_OK;
-        case 256: DWS_LN_BWD(32, 8); return DWS_OK;
-        case 512: DWS_LN_BWD(32, 16); return DWS_OK;
+        case 128: DWS_LN_BWD(16, 8); return DWS_OK;
+        case 256: DWS_LN_BWD(16, 16); return DWS_OK;
+        // H = 512: 2 x 32 values per thread spill at the 128 VGPRs of a 1024-thread block: the three-pass kernel below
     }
 #undef DWS_LN_BWD
     hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(256), 0, s, x, dy, m_p, s_p, base, out, accumulate, partial, H, L);
