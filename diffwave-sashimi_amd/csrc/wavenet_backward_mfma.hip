@@ -92,6 +92,55 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // rows beyond M (M not a multiple of the M-block): the wave only helps staging; A loads are OOB -> 0
     const bool wave_live = mt[0] * 32 < a.M;
 
+    if constexpr (T == 1) {
+        // VMEM returns in order: an A-fragment load issued AFTER a chunk's LDS-DMA cannot be waited on without waiting
+        // for the DMA too.  With the fragments fetched one k-group ahead (as in the T = 3 loop below) the DMA of the
+        // next chunk had to land within one k-group (16 MFMAs, ~0.4 us) of being issued -- less than an HBM round trip --
+        // and these 1x1 GEMMs sat at ~3 TB/s.  Here ALL of the next chunk's fragments (ROWS/8 k-groups x MT tiles) are
+        // requested first, then its DMA, and nothing waits on VMEM until the end-of-chunk barrier: the DMA has the whole
+        // chunk (64 MFMAs per wave) to land.
+        constexpr int NKGC = ROWS / 8;
+        f32x4 a_c[NKGC][MT], a_n[NKGC][MT];
+#pragma unroll
+        for (int it = 0; it < NKGC; ++it)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a_c[it][m] = buf_load4(rA, lane16, (mt[m] * a.nkg_total + it) * 1024);
+        stage_dma(0, 0);
+        __syncthreads();
+        for (int cb = 0; cb < ncb; ++cb) {
+            if (cb + 1 < ncb) {
+#pragma unroll
+                for (int it = 0; it < NKGC; ++it)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        a_n[it][m] = buf_load4(rA, lane16, (mt[m] * a.nkg_total + (cb + 1) * NKGC + it) * 1024);
+                stage_dma(cb + 1, (cb + 1) & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* xs = lds + (cb & 1) * (ROWS * P);
+#pragma unroll
+            for (int it = 0; it < NKGC; ++it) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int krow = it * 8 + j * 2 + lhi;
+                    float bf[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bf[n] = xs[krow * P + n * 32 + l31];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[it][m][j], bf[n], acc[m][n], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < NKGC; ++it)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a_c[it][m] = a_n[it][m];
+            __syncthreads();   // the next chunk's fragments and DMA have landed (vmcnt(0) before the barrier)
+        }
+    } else {
     stage_dma(0, 0);
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
@@ -124,6 +173,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
         }
         __syncthreads();
+    }
+
     }
 
     const int M = a.M;
@@ -550,97 +601,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
 }
 
 
-// wgrad_dma_kernel with a 256 x 128 (or 128 x 256) output tile per workgroup: with 128 x 128 tiles a 2H x H weight
-// gradient reads X twice (once per o-tile) -- 1.05 GB per launch at H = 128 against 0.79 GB algorithmic, and the kernel
-// sat at 3.3 TB/s, i.e. HBM-bound.  8 waves = (TO/64) x (TC/64), a wave owns 64 x 64 (four MFMA tiles: every LDS
-// operand read feeds two MFMAs).  Chunks of 32 positions; an LDS-DMA instruction moves two rows (lanes 0-31 / 32-63),
-// so rows are 32 floats without padding and the bank spread comes from a swizzle applied on the GLOBAL side: slot q of
-// row r holds position q ^ (r & 31), which keeps each row's 128-byte segment intact and makes the MFMA operand reads
-// (32 lanes = 32 rows, one position) conflict-free.
-template <int TO, int TC>
-__global__ __launch_bounds__(512, 1) void wgrad_dma2_kernel(WgradArgs a) {
-    constexpr int PC = 32, ROWS = TO + TC, TILE = ROWS * PC, WO = TO / 64;
-    static_assert((TO / 64) * (TC / 64) == 8, "eight waves of 64 x 64");
-    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [2 buffers][dY rows | X rows][32]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int wo = wave % WO, wc = wave / WO;
-    const int o0 = blockIdx.x * TO, c0 = blockIdx.y * TC, split = blockIdx.z;
-    const int L = a.L, xL = a.xL ? a.xL : L;
-    const int chunks_per_b = (L + PC - 1) / PC;
-    const int total_chunks = a.B * chunks_per_b;
-    const int per = (total_chunks + a.nsplit - 1) / a.nsplit;
-    const int ch_begin = split * per, ch_end = min(total_chunks, ch_begin + per);
-    const bool do_bias = a.bias_part != nullptr && blockIdx.y == 0;
-    constexpr int OOB = 0x7ffffff0;
-    __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)((size_t)a.B * a.O * L * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)((size_t)a.B * a.C * xL * 4), 0x00020000);
-
-    auto stage = [&](int ch, int buf) {
-        const int b = ch / chunks_per_b, l0 = (ch % chunks_per_b) * PC;
-        float* base = wlds + buf * TILE;
-#pragma unroll
-        for (int i = 0; i < ROWS / 16; ++i) {     // 8 waves x ROWS/16 row pairs
-            const int pr = wave + 8 * i;          // rows 2 pr, 2 pr + 1: both dY rows or both X rows (TO is even)
-            const int row = 2 * pr + lhi;
-            const int pos = l0 + (l31 ^ (row & 31));
-            if (2 * pr < TO) {
-                const int o = min(o0 + row, a.O - 1);   // rows past O / C feed unstored outputs only
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, base + 2 * pr * PC, 4, pos < L ? ((b * a.O + o) * L + pos) * 4 : OOB, 0, 0, 0);
-            } else {
-                const int c = min(c0 + row - TO, a.C - 1);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, base + 2 * pr * PC, 4, pos < L ? ((b * a.C + c) * xL + pos) * 4 : OOB, 0, 0, 0);
-            }
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum = 0.f;
-
-    if (ch_begin < ch_end) stage(ch_begin, 0);
-    __syncthreads();
-    for (int ch = ch_begin; ch < ch_end; ++ch) {
-        const int buf = (ch - ch_begin) & 1;
-        if (ch + 1 < ch_end) stage(ch + 1, buf ^ 1);
-        const float* sdy = wlds + buf * TILE;
-        const float* sx = sdy + TO * PC;
-        if (do_bias && tid < TO) {
-#pragma unroll 8
-            for (int p = 0; p < PC; ++p) bsum += sdy[tid * PC + ((p + tid) & 31)];   // rotated: conflict-free, order-free
-        }
-        const float* ra = sdy + (wo * 64 + l31) * PC;
-        const float* rb = sx + (wc * 64 + l31) * PC;
-#pragma unroll 4
-        for (int ks = 0; ks < PC / 2; ++ks) {
-            const int q = (ks * 2 + lhi) ^ l31;    // swizzled slot of position ks*2 + lhi in rows r with (r & 31) == l31
-            const float a0 = ra[q], a1 = ra[32 * PC + q], b0 = rb[q], b1 = rb[32 * PC + q];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();   // chunk ch+1 has landed (the barrier waits for the DMA) and buffer `buf` is free again
-    }
-    float* part = a.partial + (size_t)split * a.O * a.C;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + wo * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const int c = c0 + wc * 64 + j * 32 + l31;
-                if (o < a.O && c < a.C) part[(size_t)o * a.C + c] = acc[i][j][r];
-            }
-    if (do_bias && tid < TO && o0 + tid < a.O) a.bias_part[(size_t)split * a.O + o0 + tid] = bsum;
-}
+// (A 256 x 128 / 128 x 256 output tile per workgroup -- no operand fetched twice by the two halves of a 2H dimension,
+// 0.79 GB instead of 1.05 GB per launch at H = 128, 32-position chunks with a swizzle on the global side -- was built and
+// measured SLOWER: 365 us against 316 us.  The kernel is not bound by those bytes.)
 
 // out[i] = scale * sum_k partial[k][i], fixed order.  Four elements per thread (float4) and the k loop unrolled by
 // four keeps 16 independent loads in flight per thread: the first version (one dependent load chain per thread)
@@ -695,21 +658,7 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
     WgradArgs a = a_in;
     const dim3 grid(ceil_div(a.O, 128), ceil_div(a.C, 128), T * a.nsplit);
     static const bool no_dma = getenv("DWS_WGRAD_NO_DMA") != nullptr;
-    static const bool no_wide = getenv("DWS_WGRAD_NO_WIDE") != nullptr;
-    if (T == 1 && !a.xact && !a.addc && !no_dma && !no_wide && (a.O >= 256 || a.C >= 256)) {
-        // wide tiles: no operand is fetched twice by the two halves of a 256-row dimension
-        constexpr int lds = 2 * 384 * 32 * 4;
-        static bool attr2 = false;
-        if (!attr2) {
-            DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma2_kernel<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma2_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr2 = true;
-        }
-        if (a.O >= 256)
-            hipLaunchKernelGGL((wgrad_dma2_kernel<256, 128>), dim3(ceil_div(a.O, 256), ceil_div(a.C, 128), a.nsplit), dim3(512), lds, s, a);
-        else
-            hipLaunchKernelGGL((wgrad_dma2_kernel<128, 256>), dim3(ceil_div(a.O, 128), ceil_div(a.C, 256), a.nsplit), dim3(512), lds, s, a);
-    } else if (T == 1 && !a.xact && !a.addc && !no_dma) {
+    if (T == 1 && !a.xact && !a.addc && !no_dma) {
         constexpr int lds = 2 * 2 * 128 * 66 * 4;
         static bool attr = false;
         if (!attr) {
