@@ -289,9 +289,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     __syncthreads();
 
     for (int cb = 0; cb < T::NCB; ++cb) {
-#if !defined(DWS_WN_DMA_LATE)
         if (cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
-#endif
         const float* xs = lds + (cb & 1) * (3 * KC * P);
 #pragma unroll
         for (int it = 0; it < 3 * KC / 8; ++it) {  // (tap, kg) flattened: 8 consecutive k per iteration
@@ -299,11 +297,6 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
             const int kgn = (kg + 1 < NKG1) ? kg + 1 : kg;
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) a_nxt[m] = buf_load_f4(rA1, lane16, (mt1[m] * NKG1 + kgn) * 1024);
-#if defined(DWS_WN_DMA_LATE)
-            // VMEM returns in order: issued after this k-group's fragment request, the next chunk's DMA only has to land
-            // before the fragments requested in the NEXT k-group are waited on, i.e. it gets two k-groups instead of one
-            if (it == 0 && cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
-#endif
             // keep the prefetch a full k-group (32 MFMAs) ahead of its use: without this fence hipcc sinks
             // the loads below the MFMAs into the registers of a_cur and waits vmcnt(0) right after issuing them
             __builtin_amdgcn_sched_barrier(0);
