@@ -130,12 +130,26 @@ template <int LOG2M, int THREADS>
 __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const float2* __restrict__ twp,
                                                 const float2* __restrict__ kfa, const float2* __restrict__ kfb,
                                                 const float2* __restrict__ kfs, int tid_in, float csign) {
-    constexpr int M = 1 << LOG2M;
+    constexpr int M = 1 << LOG2M, NPW = M / 2 / THREADS;
     // opaque: the pair addresses are invariant over the rows a workgroup walks; hoisted out of that loop they would
     // occupy ~5 VGPRs per pair for the kernel's lifetime
     const int tid = opaque(tid_in);
+    // the spectrum / twiddle entries of ALL of this thread's pairs are requested first: one L2 round trip for the stage
+    // instead of one per pair (every wave of the workgroup is in this stage at the same time, nothing else hides it)
+    float2 wk[NPW], ka[NPW], kb[NPW];
+#if !defined(DWS_FFT_PW_SERIAL)
+#pragma unroll
+    for (int it = 0; it < NPW; ++it) {
+        const int q = tid + it * THREADS;
+        wk[it] = twp[q];
+        ka[it] = kfa[q];
+        kb[it] = kfb[q];
+    }
+#pragma unroll
+#else
 #pragma unroll 1
-    for (int it = 0; it < M / 2 / THREADS; ++it) {
+#endif
+    for (int it = 0; it < NPW; ++it) {
         const int q = tid + it * THREADS;
         if (q == 0) {
             float2 z0 = X[pidx(0)], z1 = X[pidx(1)];
@@ -147,7 +161,11 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
         const int p = 2 * q;
         const int pm = brev(M - brev(p, LOG2M), LOG2M);
         float2 zk = X[pidx(p)], zm = X[pidx(pm)];
+#if defined(DWS_FFT_PW_SERIAL)
         pointwise_pair(zk, zm, twp[q], kfa[q], kfb[q], csign);
+#else
+        pointwise_pair(zk, zm, wk[it], ka[it], kb[it], csign);
+#endif
         X[pidx(p)] = zk;
         X[pidx(pm)] = zm;
     }

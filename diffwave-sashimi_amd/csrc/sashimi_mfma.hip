@@ -176,7 +176,11 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
     // the residual input x of this tile is requested together with the g tile, so both HBM round trips overlap under the
     // barrier below (requested in the GLU epilogue its latency was exposed once per tile; requested after the barrier it
     // would sit in front of the first A fragments: VMEM returns in order); 16 MT NT registers, skipped at 1024 threads
+#if defined(DWS_TAIL_NO_XPRE)
+    constexpr bool XPRE = false;
+#else
     constexpr bool XPRE = THREADS <= 512;
+#endif
     __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
     float xpre[XPRE ? MT : 1][XPRE ? NT : 1][16];
     if (XPRE) {
