@@ -135,9 +135,9 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
     // occupy ~5 VGPRs per pair for the kernel's lifetime
     const int tid = opaque(tid_in);
     // the spectrum / twiddle entries of ALL of this thread's pairs are requested first: one L2 round trip for the stage
-    // instead of one per pair (every wave of the workgroup is in this stage at the same time, nothing else hides it)
+    // instead of one per pair (every wave of the workgroup is in this stage at the same time, nothing else hides it);
+    // same-box A/B: -1 % at M = 16384, -6 % at M = 4096
     float2 wk[NPW], ka[NPW], kb[NPW];
-#if !defined(DWS_FFT_PW_SERIAL)
 #pragma unroll
     for (int it = 0; it < NPW; ++it) {
         const int q = tid + it * THREADS;
@@ -146,9 +146,6 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
         kb[it] = kfb[q];
     }
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
     for (int it = 0; it < NPW; ++it) {
         const int q = tid + it * THREADS;
         if (q == 0) {
@@ -161,11 +158,7 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
         const int p = 2 * q;
         const int pm = brev(M - brev(p, LOG2M), LOG2M);
         float2 zk = X[pidx(p)], zm = X[pidx(pm)];
-#if defined(DWS_FFT_PW_SERIAL)
-        pointwise_pair(zk, zm, twp[q], kfa[q], kfb[q], csign);
-#else
         pointwise_pair(zk, zm, wk[it], ka[it], kb[it], csign);
-#endif
         X[pidx(p)] = zk;
         X[pidx(pm)] = zm;
     }

@@ -173,29 +173,6 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
         mt_a[m] = mt_h[m];
         mt_b[m] = H / 32 + mt_h[m];
     }
-    // the residual input x of this tile is requested together with the g tile, so both HBM round trips overlap under the
-    // barrier below (requested in the GLU epilogue its latency was exposed once per tile; requested after the barrier it
-    // would sit in front of the first A fragments: VMEM returns in order); 16 MT NT registers, skipped at 1024 threads
-#if defined(DWS_TAIL_NO_XPRE)
-    constexpr bool XPRE = false;
-#else
-    constexpr bool XPRE = THREADS <= 512;
-#endif
-    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
-    float xpre[XPRE ? MT : 1][XPRE ? NT : 1][16];
-    if (XPRE) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int pos = l0 + (wn * NT + n) * 32 + l31;
-                const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    xpre[XPRE ? m : 0][XPRE ? n : 0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rX, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
-            }
-    }
     __syncthreads();   // the barrier's release waits for the DMA (vmcnt(0))
 
     const float4* Ao = reinterpret_cast<const float4*>(a.Ao);
@@ -210,7 +187,9 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
         gemm_slab<MT, NT, P>(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane);
         gemm_slab<MT, NT, P>(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane);
         __syncthreads();  // every wave is done reading g
-        // x1 = x + GLU(o) (+ mel) -> tile
+        // x1 = x + GLU(o) (+ mel) -> tile.  (Requesting x together with the g tile, so that its HBM round trip overlaps the
+        // staging barrier, was measured on the same box: 166.5 vs 165.1 us at H = 64 -- no gain, not kept.)
+        __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
         __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.mel ? a.mel + (size_t)(a.mel_bstride ? b : 0) * H * L : a.x), 0, H * L4, 0x00020000);
         __amdgpu_buffer_rsrc_t rBo = __builtin_amdgcn_make_buffer_rsrc((void*)a.bo, 0, 2 * H * 4, 0x00020000);
@@ -233,8 +212,7 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int soff = (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4;
-                    xr[r] = XPRE ? xpre[XPRE ? m : 0][XPRE ? n : 0][r]
-                                 : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, soff, 0));
+                    xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, soff, 0));
                     if (has_mel) xr[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voff, soff, 0));
                 }
 #pragma unroll
