@@ -7,7 +7,13 @@ mathematically identical fp32 evaluation orders differ there by more than 1e-3 -
 the bound is 1e-3 per tensor unless the measured fp32 rounding noise of that tensor is larger: the noise is the distance
 between fp32 implementations (the reference's stored gradients where a fixture holds them, the oracle's fp32 autograd)
 and the oracle's autograd in FLOAT64 on the same weights / inputs / complex64 FFT nodes, and the tolerance then is
-3x that noise.  Errors are `max|a-b| / max(max|b|, 1e-5 * largest gradient of the model)`."""
+3x that noise.  Errors are `max|a-b| / max(max|b|, 1e-5 * largest gradient of the model)`.
+
+The networks contain ReLUs (`init_conv`, `final_conv`): when one pre-activation of the seeded test case lies within fp32
+rounding of zero, WHICH side an implementation lands on is decided by its rounding, and the gradient jumps by a fixed
+amount (observed: the d32 case, 2.8e-3 on `c_layers.0.norm1.s`, identical under every sub-ulp perturbation).  That is a
+property of the input, not an error, so the noise of a tensor also includes `kink_noise`: the change of the float64
+gradient when every parameter is perturbed by 2^-24 .. 2^-20 relative (the size of fp32 rounding in the activations)."""
 import torch
 import torch.nn as nn
 
@@ -34,6 +40,22 @@ def oracle_grads(cfg, sd, loss_of, dtype=torch.float32):
     return float(loss), grads
 
 
+def kink_noise(cfg, sd, loss_of, truth64, rels=(2.0 ** -24, 2.0 ** -22, 2.0 ** -20)):
+    """Per-tensor change of the float64 gradient under relative parameter perturbations of fp32-rounding size, relative
+    to the tensor's scale (see the module docstring): large where the loss has a kink within fp32 resolution of the test
+    point or is otherwise ill-conditioned there."""
+    gmax = max(float(v.abs().max()) for v in truth64.values())
+    out = {k: 0.0 for k in truth64}
+    for i, rel in enumerate(rels):
+        g = torch.Generator().manual_seed(9000 + i)
+        sdp = {k: (v * (1 + (torch.rand(v.shape, generator=g, dtype=torch.float64) * 2 - 1) * rel).to(v.dtype)
+                   if v.is_floating_point() else v) for k, v in sd.items()}
+        _, gp = oracle_grads(cfg, sdp, loss_of, torch.float64)
+        for k in out:
+            out[k] = max(out[k], float((gp[k] - truth64[k]).abs().max()) / _scale(truth64[k], gmax))
+    return out
+
+
 def _scale(ref, gmax):
     return max(float(ref.abs().max()), 1e-5 * gmax)
 
@@ -43,14 +65,17 @@ def errors(got, ref):
     return {k: float((got[k].double() - r.double()).abs().max()) / _scale(r, gmax) for k, r in ref.items()}
 
 
-def compare(got, ref, truth64, fp32_impls=(), label=""):
+def compare(got, ref, truth64, fp32_impls=(), label="", kink=None):
     """`got` vs `ref` per tensor: 1e-3, or 3x the fp32 noise of that tensor measured as the distance of the given fp32
-    implementations (always including `ref`) from `truth64`.  Returns (worst error, its key)."""
+    implementations (always including `ref`) from `truth64` (and `kink`, the output of `kink_noise`, if given).
+    Returns (worst error, its key)."""
     gmax = max(float(v.abs().max()) for v in truth64.values())
     bad, worst, worst_k, rows = [], 0.0, None, []
     for k, r in ref.items():
         sc = _scale(truth64[k], gmax)
         noise = max(float((impl[k].double() - truth64[k]).abs().max()) / sc for impl in (ref, *fp32_impls))
+        if kink is not None:
+            noise = max(noise, kink[k])
         err = float((got[k].double() - r.double()).abs().max()) / sc
         tol = max(TOL, 3.0 * noise)
         rows.append((err / tol, err, tol, noise, k))

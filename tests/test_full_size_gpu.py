@@ -92,3 +92,49 @@ def test_sampler_at_full_size_is_deterministic(gpu):
     c = sampling(net, (16, 1, 16000), dh, seed=6, use_graph=True)
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
     assert abs(float(a.std()) - 1.0) < 0.5
+
+
+def test_config5_training_step_at_full_size(gpu):
+    """BASELINE config 5's per-GPU workload: SaShiMi unet_d128_n6, 32 clips of 16000 samples, one training step
+    (`train.py:198-222`) through the engine (65 GB of saved activations).  Size-independent properties: the step is
+    deterministic (bitwise), every gradient is finite and non-trivial, and -- the loss being a mean over clips -- the
+    gradient of the 32-clip batch is the mean of the gradients of its two 16-clip halves (the same x_t, t, z), which is
+    also what the 8-rank data-parallel exchange computes."""
+    import torch.nn as nn
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from diffwave_sashimi_amd.training import q_sample
+    cfg = bench.CONFIGS["unet_d128_n6_T200"]
+    B, L = 32, cfg["L"]
+    net = cases.build_ours(dict(cfg["model"]), 97).to(gpu).train()
+    dh = calc_diffusion_hyperparams(**cfg["diffusion"])
+    g = torch.Generator().manual_seed(98)
+    audio = (torch.rand(B, 1, L, generator=g) * 2 - 1) * 0.3
+    steps = torch.randint(dh["T"], size=(B, 1, 1), generator=g)
+    z = torch.normal(0, 1, size=audio.shape, generator=g)
+    x_t = q_sample(audio, steps, dh["Alpha_bar"], z).to(gpu)
+    steps, z = steps.to(gpu), z.to(gpu)
+
+    def grads(sl):
+        net.zero_grad(set_to_none=True)
+        loss = nn.MSELoss()(net((x_t[sl], steps[sl].view(-1, 1))), z[sl])
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    l_full, g_full = grads(slice(0, B))
+    l_again, g_again = grads(slice(0, B))
+    assert l_full == l_again and all(torch.equal(g_full[k], g_again[k]) for k in g_full)
+    assert all(torch.isfinite(v).all() for v in g_full.values())
+    assert sum(float(v.abs().max()) > 0 for v in g_full.values()) > 0.95 * len(g_full)
+    l_a, g_a = grads(slice(0, B // 2))
+    l_b, g_b = grads(slice(B // 2, B))
+    assert abs(l_full - 0.5 * (l_a + l_b)) < 1e-5 * abs(l_full)
+    gmax = max(float(v.abs().max()) for v in g_full.values())
+    worst = 0.0
+    for k, v in g_full.items():
+        half = 0.5 * (g_a[k] + g_b[k])
+        scale = max(float(v.abs().max()), 1e-5 * gmax)
+        worst = max(worst, float((v - half).abs().max()) / scale)
+    # fp32 sums over 512 000 vs 2 x 256 000 positions in different orders: 1e-3 of each tensor's largest gradient
+    assert worst < 1e-3, worst
+    print(f"config 5 at full size: loss {l_full:.5f}, batch-additivity of the gradients to {worst:.2e}")

@@ -41,11 +41,12 @@ def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None):
     loss_of = gradcheck.mse_training_loss(audio, dh, mel, generator=torch.Generator().manual_seed(gseed))
     loss32, o32 = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
     _, truth = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float64)
+    kink = gradcheck.kink_noise(cfg, sd, loss_of, truth, rels=(2.0 ** -24, 2.0 ** -21))
     o32 = {k: o32[k] for k in got}
     truth = {k: truth[k] for k in got}
     for k, gk in got.items():
         assert torch.isfinite(gk).all(), k
-    return net, got, o32, truth, float(loss), loss32
+    return net, got, o32, truth, float(loss), loss32, kink
 
 
 @pytest.mark.parametrize("name", list(TRAIN_CASES))
@@ -54,9 +55,11 @@ def test_sashimi_parameter_gradients_match_autograd(gpu, name):
     cancelling sums where the oracle's own fp32 autograd is further than that from its float64 evaluation."""
     from tests import gradcheck
     cfg, B = TRAIN_CASES[name]
-    net, got, o32, truth, loss, ref_loss = _engine_and_oracle(cfg, B, gpu, 15, 19, 23)
+    net, got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, gpu, 15, 19, 23)
     assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
-    worst, worst_k = gradcheck.compare(got, o32, truth, label=name)
+    worst, worst_k = gradcheck.compare(got, o32, truth, label=name, kink=kink)
+    # the widening stays the exception: at most a tenth of the tensors sit on a noisy / kinked spot
+    assert sum(v > gradcheck.TOL / 3 for v in kink.values()) <= max(3, len(kink) // 10), "test point too ill-conditioned"
     e64 = gradcheck.errors(got, truth)
     k64 = max(e64, key=e64.get)
     print(f"{name}: worst parameter-gradient rel err vs oracle fp32 {worst:.3e} ({worst_k}); vs float64 {e64[k64]:.3e} ({k64})")
@@ -93,9 +96,9 @@ def test_conditional_sashimi_gradients_match_autograd(gpu):
                        diffusion_step_embed_dim_mid=64)
     B, Tmel = 2, 4
     mel = torch.cat([cases.mel_inputs(1, Tmel, 41 + i) for i in range(B)])
-    net, got, o32, truth, loss, ref_loss = _engine_and_oracle(cfg, B, gpu, 35, 39, 43, mel=mel)
+    net, got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, gpu, 35, 39, 43, mel=mel)
     assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
-    worst, worst_k = gradcheck.compare(got, o32, truth, label="conditional")
+    worst, worst_k = gradcheck.compare(got, o32, truth, label="conditional", kink=kink)
     seen_cond = sum(("upsample_conv2d" in k or "mel_conv" in k) and float(v.abs().max()) > 0 for k, v in o32.items())
     assert seen_cond >= 9 * 5          # 5 blocks x (2 upsamplers x (bias, g, v) + mel_conv (bias, g, v))
     print(f"conditional: worst parameter-gradient rel err {worst:.3e} ({worst_k})")

@@ -40,7 +40,8 @@ def _engine_and_oracle(cfg, B, L, gpu, wseed, aseed, gseed, mel=None):
     loss_of = gradcheck.mse_training_loss(audio, dh, mel, generator=torch.Generator().manual_seed(gseed))
     loss32, o32 = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
     _, truth = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float64)
-    return got, {k: o32[k] for k in got}, {k: truth[k] for k in got}, float(loss), loss32
+    kink = gradcheck.kink_noise(cfg, sd, loss_of, truth, rels=(2.0 ** -24, 2.0 ** -21))
+    return got, {k: o32[k] for k in got}, {k: truth[k] for k in got}, float(loss), loss32, kink
 
 
 @pytest.mark.parametrize("name", list(TRAIN_CASES))
@@ -48,9 +49,9 @@ def test_wavenet_parameter_gradients_match_autograd(gpu, name):
     """Per tensor 1e-3 of its largest gradient (widened to 3x the measured fp32 noise where that is larger)."""
     from tests import gradcheck
     cfg, B, L = TRAIN_CASES[name]
-    got, o32, truth, loss, ref_loss = _engine_and_oracle(cfg, B, L, gpu, 5, 9, 21)
+    got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, L, gpu, 5, 9, 21)
     assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
-    worst, k = gradcheck.compare(got, o32, truth, label=name)
+    worst, k = gradcheck.compare(got, o32, truth, label=name, kink=kink)
     print(f"{name}: worst parameter-gradient rel err {worst:.3e} ({k})")
 
 
@@ -92,9 +93,9 @@ def test_conditional_wavenet_gradients_match_autograd(gpu, name):
     from tests import gradcheck
     cfg, B, L, Tmel = COND_TRAIN_CASES[name]
     mel = torch.cat([cases.mel_inputs(1, Tmel, 31 + i) for i in range(B)])          # one mel per clip
-    got, o32, truth, loss, ref_loss = _engine_and_oracle(cfg, B, L, gpu, 25, 29, 33, mel=mel)
+    got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, L, gpu, 25, 29, 33, mel=mel)
     assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
-    worst, k = gradcheck.compare(got, o32, truth, label=name)
+    worst, k = gradcheck.compare(got, o32, truth, label=name, kink=kink)
     seen_cond = sum(("upsample_conv2d" in k or "mel_conv" in k) and float(v.abs().max()) > 0 for k, v in o32.items())
     assert seen_cond >= 9 * cfg["num_res_layers"]        # every conditioner tensor of every layer carries gradient
     print(f"{name}: worst parameter-gradient rel err {worst:.3e} ({k})")
