@@ -144,14 +144,7 @@ DWS_HD void fft16(float2 (&x)[16], float2 theta_in) {
     constexpr float RH = 0.70710678118654752440f;
     const float2 t2w[4] = {t2, make_float2(RH * (t2.x + t2.y), RH * (t2.y - t2.x)), mul_neg_i(t2),
                            make_float2(RH * (t2.y - t2.x), -RH * (t2.x + t2.y))};
-    // w2 = w1^2 by an actual squaring: deriving it as theta^2 W_8^{r0} saves ~8 instructions per pass, but on the GPU the
-    // SaShiMi parameter gradients (ill-conditioned through TransposedLN without eps) then drift from 0.9e-3 to 2.8e-3 of
-    // the reference (tests/test_sashimi_training_gpu.py, d32); the transform's own error is the same 4e-7 either way
-#if defined(DWS_FFT_TW_DERIVED)
 #define DWS_W2(R0) t2w[R0]
-#else
-#define DWS_W2(R0) cmul_(w1, w1)
-#endif
 #define DWS_STEP1(R0)                                                                                   \
     {                                                                                                   \
         const float2 w1 = tw16<TW, R0>(theta);                                                          \
