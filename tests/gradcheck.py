@@ -13,7 +13,8 @@ The networks contain ReLUs (`init_conv`, `final_conv`): when one pre-activation 
 rounding of zero, WHICH side an implementation lands on is decided by its rounding, and the gradient jumps by a fixed
 amount (observed: the d32 case, 2.8e-3 on `c_layers.0.norm1.s`, identical under every sub-ulp perturbation).  That is a
 property of the input, not an error, so the noise of a tensor also includes `kink_noise`: the change of the float64
-gradient when every parameter is perturbed by 2^-24 .. 2^-20 relative (the size of fp32 rounding in the activations)."""
+gradient when the ReLU / LeakyReLU gates switch at +-2e-6 instead of 0 (every gate fp32 may decide either way), and when
+every parameter is perturbed by 2^-22 relative (the size of fp32 rounding in the activations)."""
 import torch
 import torch.nn as nn
 
@@ -37,22 +38,48 @@ def oracle_grads(cfg, sd, loss_of, dtype=torch.float32):
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).double()
              for k, v in leaf.items() if v.is_floating_point() and v.requires_grad}
-    return float(loss), grads
+    return float(loss.detach()), grads
 
 
-def kink_noise(cfg, sd, loss_of, truth64, rels=(2.0 ** -24, 2.0 ** -22, 2.0 ** -20)):
-    """Per-tensor change of the float64 gradient under relative parameter perturbations of fp32-rounding size, relative
-    to the tensor's scale (see the module docstring): large where the loss has a kink within fp32 resolution of the test
-    point or is otherwise ill-conditioned there."""
+class _shifted_gates:
+    """Inside the block the oracle's ReLU / LeakyReLU gates switch at `thr` instead of 0 (their value is unchanged away
+    from the kink): two evaluations at +-thr bracket every gate an fp32 implementation may decide either way."""
+
+    def __init__(self, thr):
+        self.thr = thr
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.relu, self.lrelu = F, F.relu, F.leaky_relu
+        thr = self.thr
+        F.relu = lambda x, inplace=False: x * (x > thr).to(x.dtype)
+        F.leaky_relu = lambda x, negative_slope=0.01, inplace=False: torch.where(x > thr, x, x * negative_slope)
+
+    def __exit__(self, *exc):
+        self.F.relu, self.F.leaky_relu = self.relu, self.lrelu
+
+
+def kink_noise(cfg, sd, loss_of, truth64, rels=(2.0 ** -22,), gate_shift=2e-6):
+    """Per-tensor change of the float64 gradient (relative to the tensor's scale, see the module docstring) (a) when the
+    ReLU / LeakyReLU gates switch at +-gate_shift instead of 0 -- deterministic: it brackets every pre-activation within
+    fp32 rounding of its kink -- and (b) under relative parameter perturbations of fp32-rounding size (conditioning)."""
     gmax = max(float(v.abs().max()) for v in truth64.values())
     out = {k: 0.0 for k in truth64}
+
+    def update(gp):
+        for k in out:
+            out[k] = max(out[k], float((gp[k] - truth64[k]).abs().max()) / _scale(truth64[k], gmax))
+
+    for thr in (gate_shift, -gate_shift):
+        with _shifted_gates(thr):
+            _, gp = oracle_grads(cfg, sd, loss_of, torch.float64)
+        update(gp)
     for i, rel in enumerate(rels):
         g = torch.Generator().manual_seed(9000 + i)
         sdp = {k: (v * (1 + (torch.rand(v.shape, generator=g, dtype=torch.float64) * 2 - 1) * rel).to(v.dtype)
                    if v.is_floating_point() else v) for k, v in sd.items()}
         _, gp = oracle_grads(cfg, sdp, loss_of, torch.float64)
-        for k in out:
-            out[k] = max(out[k], float((gp[k] - truth64[k]).abs().max()) / _scale(truth64[k], gmax))
+        update(gp)
     return out
 
 
