@@ -100,3 +100,32 @@ def test_conditional_sashimi_gradients_match_autograd(gpu):
     seen_cond = sum(("upsample_conv2d" in k or "mel_conv" in k) and float(v.abs().max()) > 0 for k, v in o32.items())
     assert seen_cond >= 9 * 5          # 5 blocks x (2 upsamplers x (bias, g, v) + mel_conv (bias, g, v))
     print(f"conditional: worst parameter-gradient rel err {worst:.3e} ({worst_k})")
+
+
+def test_full_length_stage_gradients_match_autograd(gpu):
+    """The training path at the transform size BASELINE config 5 runs at: a top stage of H = 128 channels and L = 16000
+    samples (M = 16384: the persistent `fftconv_kernel<14>` and its adjoint, `fftcorr_kernel<14>` with two 16-point groups
+    per thread and the bins of U parked in its output slab, the Cauchy / Woodbury chain over 8001 frequencies), one block
+    per level, one clip; every parameter gradient against the oracle's autograd (float32, with float64 as the yardstick;
+    ~2 minutes of CPU)."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from diffwave_sashimi_amd.training import training_loss
+    from tests import gradcheck
+    cfg = cases.ss_cfg(d_model=128, n_layers=1, L=16000)
+    B, L = 1, 16000
+    net = cases.build_ours(cfg, 15).to(gpu).train()
+    dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
+    audio = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(19)) * 0.3
+    loss = training_loss(net, nn.MSELoss(), audio.to(gpu), dh, generator=torch.Generator().manual_seed(23))
+    loss.backward()
+    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    loss_of = gradcheck.mse_training_loss(audio, dh, None, generator=torch.Generator().manual_seed(23))
+    loss32, o32 = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
+    _, truth = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float64)
+    assert abs(float(loss) - loss32) < 1e-4 * max(1.0, abs(loss32))
+    o32, truth = {k: o32[k] for k in got}, {k: truth[k] for k in got}
+    worst, worst_k = gradcheck.compare(got, o32, truth, label="L16000")
+    e64 = gradcheck.errors(got, truth)
+    k64 = max(e64, key=e64.get)
+    print(f"L = 16000 stage: worst vs oracle fp32 {worst:.3e} ({worst_k}); vs float64 {e64[k64]:.3e} ({k64})")
