@@ -370,11 +370,7 @@ bool s4_tail_mfma_supported(int H, int ff) {
 
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     switch (H) {
-#if defined(DWS_TAIL32_NT2)
-        case 32: return launch_tail_t<32, 1, 4, 2>(a, s);
-#else
-        case 32: return launch_tail_t<32, 1, 4, 1>(a, s);
-#endif
+        case 32: return launch_tail_t<32, 1, 4, 1>(a, s);   // (256-position tiles, NT = 2: 177 us against 137 us)
         case 64: return launch_tail_t<64, 2, 2, 2>(a, s);
         case 128: return launch_tail_t<128, 4, 1, 2>(a, s);
         case 256: return launch_tail_t<256, 8, 1, 2>(a, s);

@@ -135,10 +135,11 @@ def test_config5_training_step_at_full_size(gpu):
         half = 0.5 * (g_a[k] + g_b[k])
         scale = max(float(v.abs().max()), 1e-5 * gmax)
         err = float((v - half).abs().max()) / scale
-        # the scalar TransposedLN parameters and the 1-input weight_v are sums over all 512 000 positions that cancel to
-        # a small remainder: their fp32 summation noise is measured against float64 in the small gradient tests
-        # (tests/gradcheck.py); here they only have to agree to a few per cent between two summation orders
-        if k.endswith((".m", ".s")) or k == "init_conv.0.conv.weight_v":
+        # the scalar TransposedLN parameters, the 1-input weight_v and the S4 kernel's time scale are sums over all
+        # positions / frequencies that cancel to a small remainder: their fp32 noise is measured against float64 in the
+        # gradient tests (tests/gradcheck.py; `log_dt` of a 16000-sample stage: the oracle's own fp32 autograd is 1.2e-3
+        # off its float64 one for ONE clip); here they only have to agree to a few per cent between two summation orders
+        if k.endswith((".m", ".s", "kernel.log_dt")) or k == "init_conv.0.conv.weight_v":
             worst_c = max(worst_c, (err, k))
         else:
             worst = max(worst, (err, k))
