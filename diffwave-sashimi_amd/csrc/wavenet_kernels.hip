@@ -201,6 +201,15 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // the 1e-3 parity bound); tanh(x) = 1 - 2/(exp(2x)+1) saturates cleanly for |x| large
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+// tanh(t) * sigmoid(s) as ONE quotient: (e^{2t} - 1) / ((e^{2t} + 1)(1 + e^{-s})) -- three quarter-rate transcendentals
+// (two v_exp_f32, one v_rcp_f32) instead of four.  t is clamped to +-30 (tanh(30) = 1 in fp32) so e^{2t} stays finite;
+// e^{-s} may overflow to +inf, which gives the correct limit 0.
+__device__ __forceinline__ float fast_gate(float t, float s) {
+    const float tc = __builtin_amdgcn_fmed3f(t, -30.f, 30.f);
+    const float e2 = __builtin_amdgcn_exp2f(tc * 2.8853900817779268f);      // e^{2t}
+    const float en = __builtin_amdgcn_exp2f(s * -1.4426950408889634f);      // e^{-s}
+    return (e2 - 1.f) * __builtin_amdgcn_rcpf((e2 + 1.f) * (1.f + en));
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -377,7 +386,11 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
                         hb[(C + ch) * L + pos] = hs;
                     }
                 }
+#if defined(DWS_WN_GATE_SPLIT)
                 gt[ch * P + col] = fast_tanh(ht) * fast_sigmoid(hs);
+#else
+                gt[ch * P + col] = fast_gate(ht, hs);
+#endif
             }
         }
     }
