@@ -386,11 +386,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
                         hb[(C + ch) * L + pos] = hs;
                     }
                 }
-#if defined(DWS_WN_GATE_SPLIT)
-                gt[ch * P + col] = fast_tanh(ht) * fast_sigmoid(hs);
-#else
-                gt[ch * P + col] = fast_gate(ht, hs);
-#endif
+                gt[ch * P + col] = fast_gate(ht, hs);   // (same box: 71.6 vs 71.9 ms/step for tanh * sigmoid apart)
             }
         }
     }
