@@ -442,7 +442,7 @@ def main():
         avg_ms = tot_ms.value / max(n_launch.value, 1)
         ach = flops / (avg_ms * 1e-3) / 1e12
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_wavenet_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r02_wavenet_traffic.json")
         if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and os.path.exists(tfile):
             # PMC-derived HBM bytes per launch of this kernel (collected with rocprofv3 in
             # separate --pmc passes on the same command; corrected as the guide prescribes)
