@@ -92,54 +92,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // rows beyond M (M not a multiple of the M-block): the wave only helps staging; A loads are OOB -> 0
     const bool wave_live = mt[0] * 32 < a.M;
 
-    // Long contractions (T = 1, K >= 256: eight or more chunks): VMEM returns in order, so with the A fragments fetched
-    // one k-group ahead (the loop further down) the next chunk's LDS-DMA has to land within one k-group (16 MFMAs, ~0.4 us)
-    // of being issued -- less than an HBM round trip.  Here ALL of the next chunk's fragments (ROWS/8 k-groups x MT tiles)
-    // are requested first, then its DMA, and nothing waits on VMEM until the end-of-chunk barrier.  Measured on one box:
-    // -13 % at K = 2H; at K = H (four chunks) the longer prologue costs 5-8 %, hence the runtime choice.
-    if (T == 1 && ncb >= 8) {
-        constexpr int NKGC = ROWS / 8;
-        f32x4 a_c[NKGC][MT], a_n[NKGC][MT];
-#pragma unroll
-        for (int it = 0; it < NKGC; ++it)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a_c[it][m] = buf_load4(rA, lane16, (mt[m] * a.nkg_total + it) * 1024);
-        stage_dma(0, 0);
-        __syncthreads();
-        for (int cb = 0; cb < ncb; ++cb) {
-            if (cb + 1 < ncb) {
-#pragma unroll
-                for (int it = 0; it < NKGC; ++it)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        a_n[it][m] = buf_load4(rA, lane16, (mt[m] * a.nkg_total + (cb + 1) * NKGC + it) * 1024);
-                stage_dma(cb + 1, (cb + 1) & 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float* xs = lds + (cb & 1) * (ROWS * P);
-#pragma unroll
-            for (int it = 0; it < NKGC; ++it) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int krow = it * 8 + j * 2 + lhi;
-                    float bf[NT];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) bf[n] = xs[krow * P + n * 32 + l31];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[it][m][j], bf[n], acc[m][n], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int it = 0; it < NKGC; ++it)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) a_c[it][m] = a_n[it][m];
-            __syncthreads();   // the next chunk's fragments and DMA have landed (vmcnt(0) before the barrier)
-        }
-    } else {
+    // (Requesting ALL of the next chunk's A fragments and its LDS-DMA together at the top of a chunk and not waiting on
+    // VMEM until the end-of-chunk barrier -- VMEM returns in order, so with the fragments fetched one k-group ahead the DMA
+    // has to land within a k-group -- was built for T = 1 and measured: -13 % on the K = 2H GEMMs (8+ chunks), but +5..8 %
+    // on the K = H ones (4 chunks: the longer prologue shows), a wash over a training step.  Not kept.)
     stage_dma(0, 0);
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
@@ -173,7 +129,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         __syncthreads();
     }
-    }
+
 
     const int M = a.M;
     if (!wave_live) return;
