@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // (Requesting ALL of the next chunk's A fragments and its LDS-DMA together at the top of a chunk and not waiting on
     // VMEM until the end-of-chunk barrier -- VMEM returns in order, so with the fragments fetched one k-group ahead the DMA
     // has to land within a k-group -- was built for T = 1 and measured: -13 % on the K = 2H GEMMs (8+ chunks), but +5..8 %
-    // on the K = H ones (4 chunks: the longer prologue shows), a wash over a training step.  Not kept.)
+    // on the K = H ones (4 chunks: the longer prologue shows); choosing per launch by the chunk count kept both gains apart
+    // but the larger kernel slowed its other path by 4 %: a wash over a training step either way.  Not kept.)
     stage_dma(0, 0);
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
@@ -601,7 +602,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
     const int tiles = ceil_div(O, 128) * ceil_div(C, 128) * T;
     const int chunks = B * ceil_div(L, 64);
-    int ns = std::max(1, 512 / tiles);
+    // workgroups to aim for: the single-tap DMA kernel holds one workgroup per CU (135 KB of LDS), so 256 of them do the
+    // work in one round with half the partial sums of 512 to write and reduce; the T = 3 kernel fits two per CU
+    static const int t1_target = getenv("DWS_WGRAD_T1_TARGET") ? atoi(getenv("DWS_WGRAD_T1_TARGET")) : 512;
+    const int target = (T == 1) ? t1_target : 512;
+    int ns = std::max(1, target / tiles);
     return std::min(ns, chunks);
 }
 
