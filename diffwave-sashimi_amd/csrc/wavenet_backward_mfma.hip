@@ -603,8 +603,9 @@ int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
     const int tiles = ceil_div(O, 128) * ceil_div(C, 128) * T;
     const int chunks = B * ceil_div(L, 64);
     // workgroups to aim for: the single-tap DMA kernel holds one workgroup per CU (135 KB of LDS), so 256 of them do the
-    // work in one round with half the partial sums of 512 to write and reduce; the T = 3 kernel fits two per CU
-    static const int t1_target = getenv("DWS_WGRAD_T1_TARGET") ? atoi(getenv("DWS_WGRAD_T1_TARGET")) : 512;
+    // work in one round with half the partial sums of 512 to write and reduce (same box, config-5 step: 161-163 ms
+    // against 165 ms); the T = 3 kernel fits two per CU
+    static const int t1_target = getenv("DWS_WGRAD_T1_TARGET") ? atoi(getenv("DWS_WGRAD_T1_TARGET")) : 256;
     const int target = (T == 1) ? t1_target : 512;
     int ns = std::max(1, target / tiles);
     return std::min(ns, chunks);
