@@ -1060,8 +1060,11 @@ struct SashimiModel : dws_model {
                 DWS_TRY(wgrad(st->d2.f(), l->t_n2.f(), FF * H, H, Ls, 0, dWfold.f(), G(p + ".ff.ff.0.conv.bias"), s));
                 DWS_TRY(wn_bwd(p + ".ff.ff.0.conv", dWfold.f(), FF * H, H, s));
                 // norm2: dx1 = dy + LN'(dn2)
+                // (the GLU adjoint rides on this kernel when it can: d o is written from the d x1 values in registers)
+                const bool glu_fused = ln_bwd_fuses_glu(H);
                 DWS_TRY(launch_ln_bwd(l->t_x1.f(), st->dh.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), dy, st->dx1.f(), 0,
-                                      lnpart.f(), nB, H, Ls, s));
+                                      lnpart.f(), nB, H, Ls, s, glu_fused ? l->t_o.f() : nullptr,
+                                      glu_fused ? st->d2.f() : nullptr));
                 DWS_TRY(ln_scalars(p + ".norm2", nblk, s));
                 if (melBm) {  // x1 = ... + melc: the block's conditioner sees d x1 (`sashimi.py:160-175`)
                     const int s0 = d.mel_upsample[0], s1 = d.mel_upsample[1];
@@ -1077,7 +1080,7 @@ struct SashimiModel : dws_model {
                     DWS_TRY(launch_rowsum(st->dx1.f(), G(p + ".mel_conv.conv.bias"), nB, H, Ls, 1.f, 0, s));
                 }
                 // x1 = x + glu(o), o = Wo gelu(a) + bo
-                DWS_TRY(launch_glu_bwd(st->dx1.f(), l->t_o.f(), st->d2.f(), nB, H, Ls, s));
+                if (!glu_fused) DWS_TRY(launch_glu_bwd(st->dx1.f(), l->t_o.f(), st->d2.f(), nB, H, Ls, s));
                 DWS_TRY(gemm(l->tAoT.f(), H, 2 * H, st->d2.f(), st->dh.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_a.f(), nullptr, s));
                 DWS_TRY(wgrad(st->d2.f(), l->t_g.f(), 2 * H, H, Ls, 0, G(p + ".layer.output_linear.0.weight"),
                               G(p + ".layer.output_linear.0.bias"), s));

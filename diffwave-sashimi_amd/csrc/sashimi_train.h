@@ -3,8 +3,12 @@
 #include "dws_common.h"
 
 namespace dws {
+// glu_o / glu_do (optional, H in {32, 64, 128, 256, 512}: ln_bwd_fuses_glu): also apply the GLU adjoint to the gradient
+// just produced:  glu_do[b, :2H, l] = [out sg(o_b); out o_a sg(o_b)(1 - sg(o_b))]  with o = glu_o [B, 2H, L]
+bool ln_bwd_fuses_glu(int H);
 int launch_ln_bwd(const float* x, const float* dy, const float* m_p, const float* s_p, const float* base, float* out,
-                  int accumulate, float* partial, int B, int H, int L, hipStream_t s);
+                  int accumulate, float* partial, int B, int H, int L, hipStream_t s, const float* glu_o = nullptr,
+                  float* glu_do = nullptr);
 int launch_sum_leading(const float* partial, float* out, size_t n, int k, float scale, hipStream_t s);
 int launch_glu_res(const float* o, const float* x, const float* mel, float* x1, int B, int H, int L, hipStream_t s);
 int launch_glu_bwd(const float* dx1, const float* o, float* dout, int B, int H, int L, hipStream_t s);

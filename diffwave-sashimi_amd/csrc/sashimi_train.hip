@@ -103,7 +103,8 @@ template <int RP, int PARTS>
 __global__ __launch_bounds__(64 * PARTS) void ln_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const float* __restrict__ m_p, const float* __restrict__ s_p,
                                                               const float* __restrict__ base, float* __restrict__ out,
-                                                              int accumulate, float* __restrict__ partial, int L) {
+                                                              int accumulate, float* __restrict__ partial, int L,
+                                                              const float* __restrict__ glu_o, float* __restrict__ glu_do) {
     constexpr int H = RP * PARTS;
     __shared__ float red[4][PARTS][64];
     __shared__ float cs[2][64];
@@ -163,6 +164,12 @@ __global__ __launch_bounds__(64 * PARTS) void ln_bwd_reg_kernel(const float* __r
             float v = sc * (dv[r] - mdy - (xv[r] * rs) * c2) + (PRE ? bv[PRE ? r : 0] : (bb ? bb[ho] : 0.f));
             if (accumulate) v += ob[ho];
             ob[ho] = v;
+            if (glu_o) {   // the GLU adjoint of `s4.py:1435` on the gradient just produced: d o = [v sg; v o_a sg (1 - sg)]
+                const size_t ia = (size_t)b * 2 * H * L + (ok ? l : 0) + ho, ib = ia + (size_t)H * L;
+                const float oa = glu_o[ia], sg = sigm_t(glu_o[ib]);
+                glu_do[ia] = v * sg;
+                glu_do[ib] = v * oa * sg * (1.f - sg);
+            }
         }
     }
     if (part == 0) {
@@ -177,13 +184,19 @@ __global__ __launch_bounds__(64 * PARTS) void ln_bwd_reg_kernel(const float* __r
     }
 }
 
+bool ln_bwd_fuses_glu(int H) {
+    static const bool old_path = getenv("DWS_LN_BWD_OLD") != nullptr;
+    return !old_path && (H == 32 || H == 64 || H == 128 || H == 256 || H == 512);
+}
+
 int launch_ln_bwd(const float* x, const float* dy, const float* m_p, const float* s_p, const float* base, float* out,
-                  int accumulate, float* partial, int B, int H, int L, hipStream_t s) {
+                  int accumulate, float* partial, int B, int H, int L, hipStream_t s, const float* glu_o, float* glu_do) {
     ProfileScope ps("ln_bwd", s);
+    DWS_CHECK(glu_o == nullptr || ln_bwd_fuses_glu(H), DWS_ERR_INVALID, "ln_bwd: the fused GLU adjoint needs H in {32..512}");
     const dim3 grid(ceil_div(L, 64), B);
 #define DWS_LN_BWD(RP, PARTS)                                                                                         \
     hipLaunchKernelGGL((ln_bwd_reg_kernel<RP, PARTS>), grid, dim3(64 * PARTS), 0, s, x, dy, m_p, s_p, base, out, accumulate, \
-                       partial, L)
+                       partial, L, glu_o, glu_do)
     static const bool old_path = getenv("DWS_LN_BWD_OLD") != nullptr;
     switch (old_path ? 0 : H) {
         case 32: DWS_LN_BWD(8, 4); return DWS_OK;
