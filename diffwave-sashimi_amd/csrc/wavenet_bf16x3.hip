@@ -68,6 +68,32 @@ struct Bx3Tile {
 template <int MT, int NT, int P>
 __device__ __forceinline__ void kblock(f32x16 (&acc)[MT][NT], const bf16x8 (&ahi)[MT], const bf16x8 (&alo)[MT],
                                        const u32x4* __restrict__ xhi, const u32x4* __restrict__ xlo, int item0) {
+#ifdef BX3_ABL_NOMFMA
+#pragma unroll
+    for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ahi[m]), "v"(alo[m]));
+    return;
+#endif
+#ifdef BX3_ORDER2
+    // the three products of one accumulator are spread over the k-block: consecutive MFMAs never share an accumulator
+    bf16x8 bhi[NT], blo[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        bhi[n] = __builtin_bit_cast(bf16x8, xhi[item0 + n * 32]);
+        blo[n] = __builtin_bit_cast(bf16x8, xlo[item0 + n * 32]);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[m], bhi[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[m], blo[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[m], bhi[n], acc[m][n], 0, 0, 0);
+#else
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const bf16x8 bhi = __builtin_bit_cast(bf16x8, xhi[item0 + n * 32]);
@@ -79,6 +105,7 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[MT][NT], const bf16x8 (&ahi
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[m], bhi, acc[m][n], 0, 0, 0);
         }
     }
+#endif
 }
 
 template <int C, int S, int PP, int WV, bool VEC>
@@ -129,6 +156,9 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     // item, items of one octet contiguous over positions -> conflict-free ds_read_b128 / ds_write_b128.
     // The conv's zero padding is applied here (an octet never straddles two taps: KC % 8 == 0).
     auto convert = [&](int buf) {
+#ifdef BX3_ABL_NOCONV
+        return;
+#endif
         const float* xs = lds + buf * (3 * KC * P);
 #pragma unroll
         for (int i = 0; i < OCT * P / THREADS; ++i) {
@@ -193,8 +223,12 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
             const int kbn = (kb + 1 < NKB1) ? kb + 1 : kb;
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) {
+#ifdef BX3_ABL_NOA
+                nhi[m] = ahi[m]; nlo[m] = alo[m];
+#else
                 nhi[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1 + kbn) * 2048);
                 nlo[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1 + kbn) * 2048 + 1024);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the A prefetch one k-block ahead (see wavenet_kernels.hip)
             kblock<2 * MP, NT, P>(acc, ahi, alo, xhi, xlo, (it * 2 + lhi) * P + col0);
@@ -250,7 +284,11 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
                             hs += melb[(size_t)(C + ch) * L + pos];
                         }
                     }
+#ifdef BX3_ABL_NOGATE
+                    const float g = ht * hs;
+#else
                     const float g = fast_tanh3(ht) * fast_sigmoid3(hs);
+#endif
                     const __bf16 hh = (__bf16)g;
                     h4[e] = hh;
                     l4[e] = (__bf16)(g - (float)hh);
@@ -320,6 +358,15 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
         }
         __syncthreads();  // every wave is done with the gate tile
         float* ot = lds;  // [rows][P] fp32 transpose buffer
+#ifdef BX3_ABL_NOEPI
+        if (a.L != 12345) {
+            float t = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) t += accR[0][n][0] + accS[0][n][0];
+            if (t == 1.2345f) ot[tid] = t;
+            return;
+        }
+#endif
         if (!last) {
             // residual x tile as row-major float4; its latency overlaps the LDS transpose below
             // (holding it across the GEMMs as well would push the kernel past 256 VGPRs)
