@@ -5,6 +5,7 @@
 namespace dws {
 
 constexpr int WN_LAYER_KC = 32;  // channels per staged K chunk of the fused layer kernel
+constexpr int WN_BX3_KC = 16;    // same for the bf16x3 kernel (one k-block of 16 per tap)
 
 struct WnLayerArgs {
     const float* x_in;     // [B, C, L]
@@ -25,6 +26,7 @@ struct WnLayerArgs {
     float* gate_ws;        // generic path scratch [B, C, L]
     float* hsave;          // nullable (training): pre-gate activations H of this layer [B, 2C, L]
     int B, L, dilation, first_layer, last_layer;
+    int stagger;           // start skew units (dws_common.h stagger_start); set by the launchers
 };
 
 struct WnFinalArgs {

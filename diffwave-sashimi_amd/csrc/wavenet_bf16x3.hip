@@ -17,6 +17,18 @@
 
 namespace dws {
 
+// ablation switches of the epilogue (timing experiments only)
+#ifdef BX3_ABL_NOST
+#define BX3_ST(ok, v) ((ok) && (v) == 1.2345e-30f)
+#else
+#define BX3_ST(ok, v) (ok)
+#endif
+#ifdef BX3_ABL_NOLD
+#define BX3_LD(p) make_float4(1.f, 2.f, 3.f, 4.f)
+#else
+#define BX3_LD(p) (*reinterpret_cast<const float4*>(p))
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -34,6 +46,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
     }
 }
 
+// tanh(t) * sigmoid(s) with a single quotient (same as wavenet_kernels.hip fast_gate)
+__device__ __forceinline__ float fast_gate3(float t, float s) {
+    const float tc = __builtin_amdgcn_fmed3f(t, -30.f, 30.f);
+    const float e2 = __builtin_amdgcn_exp2f(tc * 2.8853900817779268f);      // e^{2t}
+    const float en = __builtin_amdgcn_exp2f(s * -1.4426950408889634f);      // e^{-s}
+    return (e2 - 1.f) * __builtin_amdgcn_rcpf((e2 + 1.f) * (1.f + en));
+}
 __device__ __forceinline__ float fast_sigmoid3(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh3(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
@@ -48,18 +67,22 @@ struct Bx3Tile {
     static constexpr int MP = C / 32 / WM;   // (tanh, sigmoid) tile pairs per wave
     static constexpr int MR = C / 32 / WM;
     static constexpr int MS = S / 32 / WM;
-    static constexpr int KC = WN_LAYER_KC;
+    static constexpr int KC = WN_BX3_KC;
     static constexpr int NCB = C / KC;
+    static constexpr int NKBC = 3 * KC / 16;             // k-blocks per chunk
     static constexpr int OCT = 3 * KC / 8;               // k-octets per chunk
-    // LDS map (float units): F = 2 fp32 DMA buffers; X = (hi, lo) bf16x8 items [octet][pos] of the
-    // current chunk; IND = indicator items (2 octets).  The gate tile (hi, lo items [C/8][pos])
-    // aliases everything from offset 0 once GEMM1 is done.
-    static constexpr int F_FLOATS = 2 * 3 * KC * P;
-    static constexpr int X_FLOATS = 2 * OCT * P * 4;
+    // LDS map (float units): F = 2 fp32 DMA buffers; X = 2 buffers of (hi, lo) bf16x8 items [octet][pos]; IND = indicator
+    // items (2 octets).  The gate tile (hi, lo items [C/8][pos]) aliases everything from offset 0 once GEMM1 is done.
+    static constexpr int FB_FLOATS = 3 * KC * P;
+    static constexpr int XB_FLOATS = 2 * OCT * P * 4;
+    static constexpr int F_FLOATS = 2 * FB_FLOATS;
+    static constexpr int X_FLOATS = 2 * XB_FLOATS;
     static constexpr int IND_FLOATS = 2 * P * 4;
     static constexpr int G_FLOATS = 2 * (C / 8) * P * 4;
     static constexpr int GEMM1_FLOATS = F_FLOATS + X_FLOATS + IND_FLOATS;
     static constexpr int LDS_FLOATS = GEMM1_FLOATS > G_FLOATS ? GEMM1_FLOATS : G_FLOATS;
+    // one convert slice per k-block: 4-channel half items, one per thread
+    static_assert(2 * OCT * P == NKBC * THREADS, "convert slices");
     static_assert(WN * NT * 32 == P && C % (32 * WM) == 0 && S % (32 * WM) == 0 && C % KC == 0, "tiling");
 };
 
@@ -121,6 +144,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     const int wm = wave % T::WM, wn = wave / T::WM;
     const int l31 = lane & 31, lhi = lane >> 5;
 
+    stagger_start(a.stagger, 256);
     const int ntl = (a.L + P - 1) / P;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int b = tile / ntl;
@@ -128,19 +152,18 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     const int L = a.L, dil = a.dilation;
     const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
 
-    u32x4* xhi = reinterpret_cast<u32x4*>(lds + T::F_FLOATS);
-    u32x4* xlo = xhi + OCT * P;
     u32x4* indi = reinterpret_cast<u32x4*>(lds + T::F_FLOATS + T::X_FLOATS);
 
-    // ---- staging by LDS-DMA: 3*KC rows x P floats per chunk, two 256-byte pieces per row, all through ONE
+    // ---- staging by LDS-DMA: 3*KC rows x P floats per chunk, P/64 256-byte pieces per row, all through ONE
     // descriptor for this batch element (row = wave-uniform soffset; per-row descriptors as in
     // wn_layer_mfma_kernel cost 4 SGPRs each and spill here).  A tap position outside [0, L) then reads a
     // neighbouring row (or 0 beyond the tensor) -- it is zeroed by the mask of the convert pass below.
     constexpr int PIECES = 3 * KC * (P / 64);
     constexpr int PPW = PIECES / T::WAVES;
+    static_assert(PIECES % T::WAVES == 0, "DMA pieces per wave");
     __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
     auto stage_dma = [&](int cb, int buf) {
-        float* xs = lds + buf * (3 * KC * P);
+        float* xs = lds + buf * T::FB_FLOATS;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = wave + T::WAVES * i;
@@ -151,29 +174,33 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, xs + row * P + half * 64, 4, voff, c * L * 4, 0, 0);
         }
     };
-    // One cooperative fp32 -> (hi, lo) bf16 split per chunk: every element is converted ONCE (not once
-    // per consuming wave) and laid out as the MFMA B fragment wants it: 8 consecutive k per 16-byte
-    // item, items of one octet contiguous over positions -> conflict-free ds_read_b128 / ds_write_b128.
-    // The conv's zero padding is applied here (an octet never straddles two taps: KC % 8 == 0).
-    auto convert = [&](int buf) {
+    // fp32 -> (hi, lo) bf16 split, laid out as the MFMA B fragment wants it: 8 consecutive k per 16-byte item, items of
+    // one octet contiguous over positions -> conflict-free ds_read_b128.  The split runs ONE CHUNK AHEAD of the MFMAs
+    // and in slices, one per k-block of the chunk being multiplied (slice `it` = tap `it`: KC = 16 makes a k-block one
+    // tap), so its VALU/LDS work issues between the MFMAs instead of in a phase of its own.  A thread converts a
+    // 4-channel half item per slice.  The conv's zero padding is applied here.
+    const int cv_pos = tid % P, cv_oh = tid / P;
+    static_assert(KC == 16 && THREADS / P == 4, "slice == tap");
+    auto convert_slice = [&](int fbuf, int xbuf, int it) {
 #ifdef BX3_ABL_NOCONV
         return;
 #endif
-        const float* xs = lds + buf * (3 * KC * P);
+        const float* xs = lds + fbuf * T::FB_FLOATS;
+        unsigned long long* xh = reinterpret_cast<unsigned long long*>(lds + T::F_FLOATS + xbuf * T::XB_FLOATS);
+        unsigned long long* xl = xh + OCT * P * 2;
+        const int oct = (cv_oh >> 1) + 2 * it, h = cv_oh & 1;
+        const float mask = ((unsigned)(l0 + cv_pos + (it - 1) * dil) < (unsigned)L) ? 1.f : 0.f;
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 h4, l4;
 #pragma unroll
-        for (int i = 0; i < OCT * P / THREADS; ++i) {
-            const int idx = tid + THREADS * i;
-            const int oct = idx / P, pos = idx % P;
-            const int tap = (oct * 8) / KC;
-            const float mask = ((unsigned)(l0 + pos + (tap - 1) * dil) < (unsigned)L) ? 1.f : 0.f;
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = xs[(oct * 8 + e) * P + pos] * mask;
-            bf16x8 h, l;
-            split8(x, h, l);
-            xhi[idx] = __builtin_bit_cast(u32x4, h);
-            xlo[idx] = __builtin_bit_cast(u32x4, l);
+        for (int e = 0; e < 4; ++e) {
+            const float x = xs[(oct * 8 + 4 * h + e) * P + cv_pos] * mask;
+            const __bf16 hh = (__bf16)x;
+            h4[e] = hh;
+            l4[e] = (__bf16)(x - (float)hh);
         }
+        xh[(oct * P + cv_pos) * 2 + h] = __builtin_bit_cast(unsigned long long, h4);
+        xl[(oct * P + cv_pos) * 2 + h] = __builtin_bit_cast(unsigned long long, l4);
     };
 
     // indicator items: octet 0 = {tap0, tap1, tap2 in range, 0...}, octet 1 = 0 (exact in bf16)
@@ -205,21 +232,26 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     const int col0 = wn * NT * 32 + l31;
 
     stage_dma(0, 0);
+    if (T::NCB > 1) stage_dma(1, 1);
     bf16x8 ahi[2 * MP], alo[2 * MP], nhi[2 * MP], nlo[2 * MP];
 #pragma unroll
     for (int m = 0; m < 2 * MP; ++m) {
         ahi[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1) * 2048);
         alo[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1) * 2048 + 1024);
     }
+    __syncthreads();                           // DMA(0), DMA(1) landed
+#pragma unroll
+    for (int it = 0; it < T::NKBC; ++it) convert_slice(0, 0, it);
 
     for (int cb = 0; cb < T::NCB; ++cb) {
-        __syncthreads();                       // DMA(cb) landed; MFMAs of chunk cb-1 are done with X
-        if (cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
-        convert(cb & 1);
+        // X(cb) complete, DMA(cb+1) landed; every wave is done with X(cb-1) and with the fp32 buffer of chunk cb
         __syncthreads();
-#pragma unroll 1
-        for (int it = 0; it < 3 * KC / 16; ++it) {
-            const int kb = cb * (3 * KC / 16) + it;
+        if (cb + 2 < T::NCB) stage_dma(cb + 2, cb & 1);
+        const u32x4* xhi = reinterpret_cast<const u32x4*>(lds + T::F_FLOATS + (cb & 1) * T::XB_FLOATS);
+        const u32x4* xlo = xhi + OCT * P;
+#pragma unroll
+        for (int it = 0; it < T::NKBC; ++it) {
+            const int kb = cb * T::NKBC + it;
             const int kbn = (kb + 1 < NKB1) ? kb + 1 : kb;
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) {
@@ -231,6 +263,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the A prefetch one k-block ahead (see wavenet_kernels.hip)
+            if (cb + 1 < T::NCB) convert_slice((cb + 1) & 1, (cb + 1) & 1, it);
             kblock<2 * MP, NT, P>(acc, ahi, alo, xhi, xlo, (it * 2 + lhi) * P + col0);
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) { ahi[m] = nhi[m]; alo[m] = nlo[m]; }
@@ -287,7 +320,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
 #ifdef BX3_ABL_NOGATE
                     const float g = ht * hs;
 #else
-                    const float g = fast_tanh3(ht) * fast_sigmoid3(hs);
+                    const float g = fast_gate3(ht, hs);
 #endif
                     const __bf16 hh = (__bf16)g;
                     h4[e] = hh;
@@ -373,7 +406,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
             float4 x4[C / ROWS_PASS];
 #pragma unroll
             for (int i = 0; i < C / ROWS_PASS; ++i)
-                x4[i] = *reinterpret_cast<const float4*>(xb + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
+                x4[i] = BX3_LD(xb + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -390,7 +423,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
                 const float4 v = *reinterpret_cast<const float4*>(ot + row * P + f4 * 4);
                 const float4 o = make_float4((x4[i].x + v.x) * rs, (x4[i].y + v.y) * rs, (x4[i].z + v.z) * rs,
                                              (x4[i].w + v.w) * rs);
-                if (ok4) *reinterpret_cast<float4*>(xo + (size_t)row * L + pos4) = o;
+                if (BX3_ST(ok4, o.x)) *reinterpret_cast<float4*>(xo + (size_t)row * L + pos4) = o;
             }
             __syncthreads();
         }
@@ -398,7 +431,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
         if (!first) {
 #pragma unroll
             for (int i = 0; i < S / ROWS_PASS; ++i)
-                s4[i] = *reinterpret_cast<const float4*>(sk + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
+                s4[i] = BX3_LD(sk + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
         } else {
 #pragma unroll
             for (int i = 0; i < S / ROWS_PASS; ++i) s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -418,7 +451,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
             const int row = i * ROWS_PASS + rsub;
             const float4 v = *reinterpret_cast<const float4*>(ot + row * P + f4 * 4);
             const float4 o = make_float4(s4[i].x + v.x, s4[i].y + v.y, s4[i].z + v.z, s4[i].w + v.w);
-            if (ok4) *reinterpret_cast<float4*>(sk + (size_t)row * L + pos4) = o;
+            if (BX3_ST(ok4, o.x)) *reinterpret_cast<float4*>(sk + (size_t)row * L + pos4) = o;
         }
     } else {
     // Scalar path (L not a multiple of 4: rows are not 16-byte aligned): loads of the residual x /
@@ -575,7 +608,10 @@ int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, void* Abt,
 }
 
 template <int C, int S, int PP, int WV>
-static int launch_bx3_t(const WnLayerArgs& a, hipStream_t s) {
+static int launch_bx3_t(const WnLayerArgs& a_, hipStream_t s) {
+    static const int stagger = getenv("DWS_BX3_STAGGER") ? atoi(getenv("DWS_BX3_STAGGER")) : 0;
+    WnLayerArgs a = a_;
+    a.stagger = (a.B * ceil_div(a.L, PP) > 256) ? stagger : 0;
     using T = Bx3Tile<C, S, PP, WV>;
     ProfileScope ps("wn_layer_bf16x3", s);
     const size_t lds = (size_t)T::LDS_FLOATS * 4;

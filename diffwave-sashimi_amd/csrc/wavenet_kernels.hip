@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     const int wm = wave % T::WM, wn = wave / T::WM;
     const int l31 = lane & 31, lhi = lane >> 5;
 
+    stagger_start(a.stagger, 512);
     const int ntl = (a.L + P - 1) / P;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     // readfirstlane: the integer divisions run on the VALU, and without it hipcc treats everything derived from b
@@ -537,9 +538,12 @@ int launch_wn_bias_tap(const float* Wd_all, const float* part_t, float* Abt, int
 }
 
 template <int C, int S>
-static int launch_layer_t(const WnLayerArgs& a, hipStream_t s) {
+static int launch_layer_t(const WnLayerArgs& a_, hipStream_t s) {
     ProfileScope ps("wn_layer_mfma", s);
-    const int ntl = ceil_div(a.L, WnTile<C, S>::P);
+    const int ntl = ceil_div(a_.L, WnTile<C, S>::P);
+    static const int stagger = getenv("DWS_WN_STAGGER") ? atoi(getenv("DWS_WN_STAGGER")) : 0;
+    WnLayerArgs a = a_;
+    a.stagger = (a.B * ntl > 512) ? stagger : 0;
     if (a.melc || a.hsave) hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, true>), dim3(a.B * ntl), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, false>), dim3(a.B * ntl), dim3(256), 0, s, a);
     return DWS_OK;

@@ -135,7 +135,7 @@ struct WaveNetModel : dws_model {
             DWS_HIP(hipMemcpyAsync(bias2[n].f() + C, P(p + ".skip_conv.bias"), (size_t)S * 4, hipMemcpyDeviceToDevice, s));
             if (mfma_layer) {
                 DWS_TRY(A1[n].ensure((size_t)2 * C * 3 * C * 4));
-                DWS_TRY(launch_permute_dconv(Wd(n), tmp_pack.f(), C, WN_LAYER_KC, s));
+                DWS_TRY(launch_permute_dconv(Wd(n), tmp_pack.f(), C, bf16x3 ? WN_BX3_KC : WN_LAYER_KC, s));
                 DWS_TRY(A2[n].ensure((size_t)(C + S) * C * 4));
                 if (bf16x3) {
                     DWS_TRY(launch_pack_a_bf16x3(tmp_pack.f(), A1[n].p, 2 * C, 3 * C, s));
