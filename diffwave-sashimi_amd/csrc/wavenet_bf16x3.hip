@@ -80,7 +80,9 @@ struct Bx3Tile {
     static constexpr int IND_FLOATS = 2 * P * 4;
     static constexpr int G_FLOATS = 2 * (C / 8) * P * 4;
     static constexpr int GEMM1_FLOATS = F_FLOATS + X_FLOATS + IND_FLOATS;
-    static constexpr int LDS_FLOATS = GEMM1_FLOATS > G_FLOATS ? GEMM1_FLOATS : G_FLOATS;
+    static constexpr int OT_FLOATS = (C > S ? C : S) * P;  // fp32 transpose buffer of the epilogue (after GEMM2)
+    static constexpr int LDS_FLOATS0 = GEMM1_FLOATS > G_FLOATS ? GEMM1_FLOATS : G_FLOATS;
+    static constexpr int LDS_FLOATS = LDS_FLOATS0 > OT_FLOATS ? LDS_FLOATS0 : OT_FLOATS;
     // one convert slice per k-block: 4-channel half items, one per thread
     static_assert(2 * OCT * P == NKBC * THREADS, "convert slices");
     static_assert(WN * NT * 32 == P && C % (32 * WM) == 0 && S % (32 * WM) == 0 && C % KC == 0, "tiling");
@@ -343,17 +345,25 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     float* __restrict__ sk = a.skip + (size_t)b * S * L;
     const bool first = a.first_layer, last = a.last_layer;
 
-    auto gemm2 = [&](auto& acc2, const int (&mt2)[1]) {
-        bf16x8 chi[1], clo[1], dhi[1], dlo[1];
-        chi[0] = buf_load_bf8(rA2, lane16, (mt2[0] * NKB2) * 2048);
-        clo[0] = buf_load_bf8(rA2, lane16, (mt2[0] * NKB2) * 2048 + 1024);
+    auto gemm2 = [&](auto& acc2, const auto& mt2) {
+        constexpr int MT = sizeof(mt2) / sizeof(int);
+        bf16x8 chi[MT], clo[MT], dhi[MT], dlo[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            chi[m] = buf_load_bf8(rA2, lane16, (mt2[m] * NKB2) * 2048);
+            clo[m] = buf_load_bf8(rA2, lane16, (mt2[m] * NKB2) * 2048 + 1024);
+        }
         for (int kb = 0; kb < NKB2; ++kb) {
             const int kbn = (kb + 1 < NKB2) ? kb + 1 : kb;
-            dhi[0] = buf_load_bf8(rA2, lane16, (mt2[0] * NKB2 + kbn) * 2048);
-            dlo[0] = buf_load_bf8(rA2, lane16, (mt2[0] * NKB2 + kbn) * 2048 + 1024);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                dhi[m] = buf_load_bf8(rA2, lane16, (mt2[m] * NKB2 + kbn) * 2048);
+                dlo[m] = buf_load_bf8(rA2, lane16, (mt2[m] * NKB2 + kbn) * 2048 + 1024);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            kblock<1, NT, P>(acc2, chi, clo, g_hi, g_lo, (kb * 2 + lhi) * P + col0);
-            chi[0] = dhi[0]; clo[0] = dlo[0];
+            kblock<MT, NT, P>(acc2, chi, clo, g_hi, g_lo, (kb * 2 + lhi) * P + col0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { chi[m] = dhi[m]; clo[m] = dlo[m]; }
         }
     };
 
@@ -368,27 +378,21 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
         const int pos4 = l0 + f4 * 4;
         const bool ok4 = pos4 < L;                    // L % 4 == 0: a float4 is entirely inside or outside
         const int pos4c = ok4 ? pos4 : 0;
-        f32x16 accR[MR][NT], accS[MS][NT];
-        if (!last) {
+        // one pass over the gate tile for the wave's res AND skip output tiles (each B fragment feeds MR + MS tiles;
+        // the last layer's unused res rows ride along)
+        f32x16 acc2[MR + MS][NT];
+        int mt2[MR + MS];
 #pragma unroll
-            for (int m = 0; m < MR; ++m) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accR[m][n][r] = 0.f;
-                const int mt2[1] = {wm * MR + m};
-                gemm2(*reinterpret_cast<f32x16(*)[1][NT]>(&accR[m]), mt2);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MS; ++m) {
+        for (int m = 0; m < MR + MS; ++m) {
+            mt2[m] = (m < MR) ? wm * MR + m : C / 32 + wm * MS + (m - MR);
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accS[m][n][r] = 0.f;
-            const int mt2[1] = {C / 32 + wm * MS + m};
-            gemm2(*reinterpret_cast<f32x16(*)[1][NT]>(&accS[m]), mt2);
+                for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
         }
+        gemm2(acc2, mt2);
+        f32x16 (&accR)[MR][NT] = *reinterpret_cast<f32x16(*)[MR][NT]>(&acc2[0]);
+        f32x16 (&accS)[MS][NT] = *reinterpret_cast<f32x16(*)[MS][NT]>(&acc2[MR]);
         __syncthreads();  // every wave is done with the gate tile
         float* ot = lds;  // [rows][P] fp32 transpose buffer
 #ifdef BX3_ABL_NOEPI
