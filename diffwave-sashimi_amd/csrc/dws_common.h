@@ -108,5 +108,12 @@ __device__ __forceinline__ void stagger_start(int units, int first_round_blocks)
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
     }
 }
+// Same idea inside a CU that holds two workgroups: the second round-0 workgroup of every CU (blocks [ncu, 2 ncu) --
+// the dispatcher fills one slot per CU first) starts `units` x 512 cycles late, so the pair runs in anti-phase and one's
+// epilogue overlaps the other's MFMA phase.
+__device__ __forceinline__ void stagger_second(int units, int ncu) {
+    if (units > 0 && (int)blockIdx.x >= ncu && (int)blockIdx.x < 2 * ncu)
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);
+}
 
 }  // namespace dws
