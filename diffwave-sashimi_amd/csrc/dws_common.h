@@ -99,21 +99,4 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-// Start skew for the first round of workgroups (the ones that start together when the launch fills the chip): the CUs
-// of an XCD wait 0..31 x `units` x 512 cycles, so equal-length tiles on different CUs stop reaching their HBM-heavy
-// epilogues at the same instant (all 256 CUs storing at once is fabric-bound; spread out it overlaps other CUs' MFMA phases).
-__device__ __forceinline__ void stagger_start(int units, int first_round_blocks) {
-    if (units > 0 && (int)blockIdx.x < first_round_blocks) {
-        const int n = ((blockIdx.x >> 3) & 31) * units;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-}
-// Same idea inside a CU that holds two workgroups: the second round-0 workgroup of every CU (blocks [ncu, 2 ncu) --
-// the dispatcher fills one slot per CU first) starts `units` x 512 cycles late, so the pair runs in anti-phase and one's
-// epilogue overlaps the other's MFMA phase.
-__device__ __forceinline__ void stagger_second(int units, int ncu) {
-    if (units > 0 && (int)blockIdx.x >= ncu && (int)blockIdx.x < 2 * ncu)
-        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);
-}
-
 }  // namespace dws

@@ -26,7 +26,6 @@ struct WnLayerArgs {
     float* gate_ws;        // generic path scratch [B, C, L]
     float* hsave;          // nullable (training): pre-gate activations H of this layer [B, 2C, L]
     int B, L, dilation, first_layer, last_layer;
-    int stagger;           // start skew units (dws_common.h stagger_start); set by the launchers
 };
 
 struct WnFinalArgs {
@@ -59,7 +58,8 @@ bool wn_final_mfma_supported(int S);
 bool wn_layer_bf16x3_supported(int C, int S);
 int launch_wn_layer_bf16x3(int C, int S, const WnLayerArgs& a, hipStream_t s);
 int launch_pack_a_bf16x3(const float* w, void* out, int M, int K, hipStream_t s);
-int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, void* Abt, int NL, int B, int C, hipStream_t s);
+int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, const float* bias1_all, void* Abt, int NL, int B, int C,
+                            hipStream_t s);
 int launch_wn_final(int S, const WnFinalArgs& a, hipStream_t s);
 
 }  // namespace dws

@@ -17,18 +17,6 @@
 
 namespace dws {
 
-// ablation switches of the epilogue (timing experiments only)
-#ifdef BX3_ABL_NOST
-#define BX3_ST(ok, v) ((ok) && (v) == 1.2345e-30f)
-#else
-#define BX3_ST(ok, v) (ok)
-#endif
-#ifdef BX3_ABL_NOLD
-#define BX3_LD(p) make_float4(1.f, 2.f, 3.f, 4.f)
-#else
-#define BX3_LD(p) (*reinterpret_cast<const float4*>(p))
-#endif
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -80,9 +68,15 @@ struct Bx3Tile {
     static constexpr int IND_FLOATS = 2 * P * 4;
     static constexpr int G_FLOATS = 2 * (C / 8) * P * 4;
     static constexpr int GEMM1_FLOATS = F_FLOATS + X_FLOATS + IND_FLOATS;
-    static constexpr int OT_FLOATS = (C > S ? C : S) * P;  // fp32 transpose buffer of the epilogue (after GEMM2)
+    // epilogue: the skip rows are transposed through the LDS beside the gate tile in pieces of PIECE_ROWS rows
+    // (largest power of two that fits in 160 KB), the res rows through [C][P] floats from offset 0 (gate tile dead)
+    static constexpr int FREE_ROWS = (40960 - G_FLOATS) / P;
+    static constexpr int PIECE_ROWS0 = FREE_ROWS >= 256 ? 256 : FREE_ROWS >= 128 ? 128 : FREE_ROWS >= 64 ? 64 : 32;
+    static constexpr int PIECE_ROWS = PIECE_ROWS0 < S ? PIECE_ROWS0 : S;
+    static constexpr int EPI_FLOATS = (G_FLOATS + PIECE_ROWS * P) > C * P ? (G_FLOATS + PIECE_ROWS * P) : C * P;
     static constexpr int LDS_FLOATS0 = GEMM1_FLOATS > G_FLOATS ? GEMM1_FLOATS : G_FLOATS;
-    static constexpr int LDS_FLOATS = LDS_FLOATS0 > OT_FLOATS ? LDS_FLOATS0 : OT_FLOATS;
+    static constexpr int LDS_FLOATS = LDS_FLOATS0 > EPI_FLOATS ? LDS_FLOATS0 : EPI_FLOATS;
+    static_assert(LDS_FLOATS <= 40960 && FREE_ROWS >= 32 && S % PIECE_ROWS == 0 && PIECE_ROWS % 32 == 0, "LDS budget");
     // one convert slice per k-block: 4-channel half items, one per thread
     static_assert(2 * OCT * P == NKBC * THREADS, "convert slices");
     static_assert(WN * NT * 32 == P && C % (32 * WM) == 0 && S % (32 * WM) == 0 && C % KC == 0, "tiling");
@@ -93,32 +87,6 @@ struct Bx3Tile {
 template <int MT, int NT, int P>
 __device__ __forceinline__ void kblock(f32x16 (&acc)[MT][NT], const bf16x8 (&ahi)[MT], const bf16x8 (&alo)[MT],
                                        const u32x4* __restrict__ xhi, const u32x4* __restrict__ xlo, int item0) {
-#ifdef BX3_ABL_NOMFMA
-#pragma unroll
-    for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ahi[m]), "v"(alo[m]));
-    return;
-#endif
-#ifdef BX3_ORDER2
-    // the three products of one accumulator are spread over the k-block: consecutive MFMAs never share an accumulator
-    bf16x8 bhi[NT], blo[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        bhi[n] = __builtin_bit_cast(bf16x8, xhi[item0 + n * 32]);
-        blo[n] = __builtin_bit_cast(bf16x8, xlo[item0 + n * 32]);
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[m], bhi[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[m], blo[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[m], bhi[n], acc[m][n], 0, 0, 0);
-#else
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const bf16x8 bhi = __builtin_bit_cast(bf16x8, xhi[item0 + n * 32]);
@@ -130,7 +98,6 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[MT][NT], const bf16x8 (&ahi
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[m], bhi, acc[m][n], 0, 0, 0);
         }
     }
-#endif
 }
 
 template <int C, int S, int PP, int WV, bool VEC>
@@ -146,7 +113,6 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     const int wm = wave % T::WM, wn = wave / T::WM;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    stagger_start(a.stagger, 256);
     const int ntl = (a.L + P - 1) / P;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int b = tile / ntl;
@@ -184,9 +150,6 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     const int cv_pos = tid % P, cv_oh = tid / P;
     static_assert(KC == 16 && THREADS / P == 4, "slice == tap");
     auto convert_slice = [&](int fbuf, int xbuf, int it) {
-#ifdef BX3_ABL_NOCONV
-        return;
-#endif
         const float* xs = lds + fbuf * T::FB_FLOATS;
         unsigned long long* xh = reinterpret_cast<unsigned long long*>(lds + T::F_FLOATS + xbuf * T::XB_FLOATS);
         unsigned long long* xl = xh + OCT * P * 2;
@@ -205,14 +168,14 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
         xl[(oct * P + cv_pos) * 2 + h] = __builtin_bit_cast(unsigned long long, l4);
     };
 
-    // indicator items: octet 0 = {tap0, tap1, tap2 in range, 0...}, octet 1 = 0 (exact in bf16)
+    // indicator items: octet 0 = {tap0, tap1, tap2 in range, 1 (bias row), 0...}, octet 1 = 0 (exact in bf16)
     for (int i = tid; i < 2 * P; i += THREADS) {
         const int oct = i / P, col = i % P;
         bf16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int pos = l0 + col + (e - 1) * dil;
-            v[e] = (__bf16)((oct == 0 && e < 3 && (unsigned)pos < (unsigned)L) ? 1.f : 0.f);
+            v[e] = (__bf16)((oct == 0 && (e == 3 || (e < 3 && (unsigned)pos < (unsigned)L))) ? 1.f : 0.f);
         }
         indi[i] = __builtin_bit_cast(u32x4, v);
     }
@@ -257,12 +220,8 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
             const int kbn = (kb + 1 < NKB1) ? kb + 1 : kb;
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) {
-#ifdef BX3_ABL_NOA
-                nhi[m] = ahi[m]; nlo[m] = alo[m];
-#else
                 nhi[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1 + kbn) * 2048);
                 nlo[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1 + kbn) * 2048 + 1024);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the A prefetch one k-block ahead (see wavenet_kernels.hip)
             if (cb + 1 < T::NCB) convert_slice((cb + 1) & 1, (cb + 1) & 1, it);
@@ -290,6 +249,21 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
             }
         }
     }
+    // row-major float4 view of the tile for the vector epilogue; the running skip tile is fetched here so that its HBM
+    // latency passes under the gate stage (which issues no global loads: the conv bias came in with the correction rows)
+    constexpr int F4_ROW = P / 4;                 // float4 per tile row
+    constexpr int ROWS_PASS = THREADS / F4_ROW;   // rows covered by one pass of the workgroup
+    const int f4 = tid % F4_ROW, rsub = tid / F4_ROW;
+    const int pos4 = l0 + f4 * 4;
+    const bool ok4 = pos4 < L;                    // VEC: L % 4 == 0, a float4 is entirely inside or outside
+    const int pos4c = ok4 ? pos4 : 0;
+    float4 v4s[VEC ? S / ROWS_PASS : 1];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int i = 0; i < S / ROWS_PASS; ++i)
+            v4s[i] = a.first_layer ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                   : *reinterpret_cast<const float4*>(a.skip + ((size_t)b * S + i * ROWS_PASS + rsub) * L + pos4c);
+    }
     __syncthreads();
 
     // ---- gate -> (hi, lo) bf16 items [C/8][P] in LDS (aliases the GEMM1 buffers).  A lane's four
@@ -310,8 +284,8 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
                 for (int e = 0; e < 4; ++e) {
                     const int r = q * 4 + e;
                     const int ch = (wm * MP + m) * 32 + 8 * q + 4 * lhi + e;
-                    float ht = acc[m][n][r] + a.bias1[ch];
-                    float hs = acc[MP + m][n][r] + a.bias1[C + ch];
+                    float ht = acc[m][n][r];      // bias1 came in through the correction rows
+                    float hs = acc[MP + m][n][r];
                     if (melb) {
                         const int pos = l0 + col;
                         if (pos < L) {
@@ -319,11 +293,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
                             hs += melb[(size_t)(C + ch) * L + pos];
                         }
                     }
-#ifdef BX3_ABL_NOGATE
-                    const float g = ht * hs;
-#else
                     const float g = fast_gate3(ht, hs);
-#endif
                     const __bf16 hh = (__bf16)g;
                     h4[e] = hh;
                     l4[e] = (__bf16)(g - (float)hh);
@@ -368,49 +338,70 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     };
 
     if constexpr (VEC) {
-        // Vector path (L % 4 == 0, chosen at launch): per-lane dword loads/stores in the accumulator layout are store-ISSUE bound
-        // (131 KB of x' + 131 KB of skip per tile, 4 B per lane per instruction).  Instead: prefetch the
-        // residual x tile as row-major float4 (its latency overlaps the transpose), transpose the accumulators
-        // through LDS (the gate tile is dead by then) and move every output with dwordx4 per lane.
-        constexpr int F4_ROW = P / 4;                 // float4 per tile row
-        constexpr int ROWS_PASS = THREADS / F4_ROW;   // rows covered by one pass of the workgroup
-        const int f4 = tid % F4_ROW, rsub = tid / F4_ROW;
-        const int pos4 = l0 + f4 * 4;
-        const bool ok4 = pos4 < L;                    // L % 4 == 0: a float4 is entirely inside or outside
-        const int pos4c = ok4 ? pos4 : 0;
-        // one pass over the gate tile for the wave's res AND skip output tiles (each B fragment feeds MR + MS tiles;
-        // the last layer's unused res rows ride along)
-        f32x16 acc2[MR + MS][NT];
-        int mt2[MR + MS];
+        // Vector path (L % 4 == 0, chosen at launch).  Per-lane dword loads/stores in the accumulator layout are
+        // store-ISSUE bound, so outputs are transposed through LDS and moved as row-major dwordx4; and a CU sustains only
+        // ~8 B/clk to/from HBM (131 KB each of x, x', skip in, skip out per tile), so that traffic is spread under the
+        // MFMA phases instead of following them:
+        //   skip tile loaded BEFORE the gate stage (v4s: 16 float4 per thread) -> lands under it;
+        //   GEMM2 for the skip rows -> transposed through the LDS left beside the gate tile, piece by piece ->
+        //   skip stores drain under GEMM2 for the res rows (whose residual x tile is loaded just before it);
+        //   only the x' stores are left at the end of the tile.
+        f32x16 accS[MS][NT];
+        int mtS[MS];
 #pragma unroll
-        for (int m = 0; m < MR + MS; ++m) {
-            mt2[m] = (m < MR) ? wm * MR + m : C / 32 + wm * MS + (m - MR);
+        for (int m = 0; m < MS; ++m) {
+            mtS[m] = C / 32 + wm * MS + m;
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
+                for (int r = 0; r < 16; ++r) accS[m][n][r] = 0.f;
         }
-        gemm2(acc2, mt2);
-        f32x16 (&accR)[MR][NT] = *reinterpret_cast<f32x16(*)[MR][NT]>(&acc2[0]);
-        f32x16 (&accS)[MS][NT] = *reinterpret_cast<f32x16(*)[MS][NT]>(&acc2[MR]);
-        __syncthreads();  // every wave is done with the gate tile
-        float* ot = lds;  // [rows][P] fp32 transpose buffer
-#ifdef BX3_ABL_NOEPI
-        if (a.L != 12345) {
-            float t = 0.f;
+        gemm2(accS, mtS);
+        constexpr int PR = T::PIECE_ROWS, NPIECE = S / PR;
+        float* otp = lds + T::G_FLOATS;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) t += accR[0][n][0] + accS[0][n][0];
-            if (t == 1.2345f) ot[tid] = t;
-            return;
+        for (int p = 0; p < NPIECE; ++p) {
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                if (((wm * MS + m) * 32) / PR == p) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                            otp[(sc - p * PR) * P + col0 + n * 32] = accS[m][n][r] + a.bias2[C + sc];
+                        }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PR / ROWS_PASS; ++i) {
+                const int rl = i * ROWS_PASS + rsub;
+                const float4 v = *reinterpret_cast<const float4*>(otp + rl * P + f4 * 4);
+                const float4 w = v4s[p * (PR / ROWS_PASS) + i];
+                const float4 o = make_float4(w.x + v.x, w.y + v.y, w.z + v.z, w.w + v.w);
+                if (ok4) *reinterpret_cast<float4*>(sk + (size_t)(p * PR + rl) * L + pos4) = o;
+            }
+            if (p + 1 < NPIECE) __syncthreads();
         }
-#endif
         if (!last) {
-            // residual x tile as row-major float4; its latency overlaps the LDS transpose below
-            // (holding it across the GEMMs as well would push the kernel past 256 VGPRs)
             float4 x4[C / ROWS_PASS];
 #pragma unroll
             for (int i = 0; i < C / ROWS_PASS; ++i)
-                x4[i] = BX3_LD(xb + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
+                x4[i] = *reinterpret_cast<const float4*>(xb + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
+            f32x16 accR[MR][NT];
+            int mtR[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                mtR[m] = wm * MR + m;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accR[m][n][r] = 0.f;
+            }
+            gemm2(accR, mtR);
+            __syncthreads();  // every wave is done with the gate tile
+            float* ot = lds;  // [C][P] fp32 transpose buffer
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -427,35 +418,8 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
                 const float4 v = *reinterpret_cast<const float4*>(ot + row * P + f4 * 4);
                 const float4 o = make_float4((x4[i].x + v.x) * rs, (x4[i].y + v.y) * rs, (x4[i].z + v.z) * rs,
                                              (x4[i].w + v.w) * rs);
-                if (BX3_ST(ok4, o.x)) *reinterpret_cast<float4*>(xo + (size_t)row * L + pos4) = o;
+                if (ok4) *reinterpret_cast<float4*>(xo + (size_t)row * L + pos4) = o;
             }
-            __syncthreads();
-        }
-        float4 s4[S / ROWS_PASS];
-        if (!first) {
-#pragma unroll
-            for (int i = 0; i < S / ROWS_PASS; ++i)
-                s4[i] = BX3_LD(sk + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
-        } else {
-#pragma unroll
-            for (int i = 0; i < S / ROWS_PASS; ++i) s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int m = 0; m < MS; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int sc = (wm * MS + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    ot[sc * P + col0 + n * 32] = accS[m][n][r] + a.bias2[C + sc];
-                }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < S / ROWS_PASS; ++i) {
-            const int row = i * ROWS_PASS + rsub;
-            const float4 v = *reinterpret_cast<const float4*>(ot + row * P + f4 * 4);
-            const float4 o = make_float4(s4[i].x + v.x, s4[i].y + v.y, s4[i].z + v.z, s4[i].w + v.w);
-            if (BX3_ST(ok4, o.x)) *reinterpret_cast<float4*>(sk + (size_t)row * L + pos4) = o;
         }
     } else {
     // Scalar path (L not a multiple of 4: rows are not 16-byte aligned): loads of the residual x /
@@ -560,9 +524,11 @@ int launch_pack_a_bf16x3(const float* w, void* out, int M, int K, hipStream_t s)
     return DWS_OK;
 }
 
-// bf16x3 variant of wn_bias_tap_kernel: Abt[n][b][mt][part][lane][8] with k = t in lanes 0..31
+// bf16x3 variant of wn_bias_tap_kernel: Abt[n][b][mt][part][lane][8] with k = t in lanes 0..31; k = 3 carries the
+// dilated conv's bias (its indicator row is 1 at every position), so the gate stage has no bias loads
 __global__ void wn_bias_tap_bf16_kernel(const float* __restrict__ Wd_all, const float* __restrict__ part_t,
-                                        unsigned short* __restrict__ Abt, int NL, int B, int C) {
+                                        const float* __restrict__ bias1_all, unsigned short* __restrict__ Abt, int NL, int B,
+                                        int C) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= NL * 2 * C) return;
@@ -594,9 +560,10 @@ __global__ void wn_bias_tap_bf16_kernel(const float* __restrict__ Wd_all, const 
         if (lane == 0) {
             unsigned short* dst = Abt + ((((size_t)n * B + b) * (2 * C / 32) + o / 32) * 2) * 512;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const __bf16 h = (__bf16)s[t];
-                const __bf16 l = (__bf16)(s[t] - (float)h);
+            for (int t = 0; t < 4; ++t) {
+                const float v = (t < 3) ? s[t] : bias1_all[row];
+                const __bf16 h = (__bf16)v;
+                const __bf16 l = (__bf16)(v - (float)h);
                 dst[(o % 32) * 8 + t] = __builtin_bit_cast(unsigned short, h);
                 dst[512 + (o % 32) * 8 + t] = __builtin_bit_cast(unsigned short, l);
             }
@@ -604,18 +571,16 @@ __global__ void wn_bias_tap_bf16_kernel(const float* __restrict__ Wd_all, const 
     }
 }
 
-int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, void* Abt, int NL, int B, int C, hipStream_t s) {
+int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, const float* bias1_all, void* Abt, int NL, int B, int C,
+                            hipStream_t s) {
     DWS_CHECK(C <= 512, DWS_ERR_UNSUPPORTED, "wn_bias_tap: C=%d > 512", C);
     hipLaunchKernelGGL(wn_bias_tap_bf16_kernel, dim3(ceil_div((int64_t)NL * 2 * C, 4)), dim3(256), 0, s, Wd_all, part_t,
-                       (unsigned short*)Abt, NL, B, C);
+                       bias1_all, (unsigned short*)Abt, NL, B, C);
     return DWS_OK;
 }
 
 template <int C, int S, int PP, int WV>
-static int launch_bx3_t(const WnLayerArgs& a_, hipStream_t s) {
-    static const int stagger = getenv("DWS_BX3_STAGGER") ? atoi(getenv("DWS_BX3_STAGGER")) : 0;
-    WnLayerArgs a = a_;
-    a.stagger = (a.B * ceil_div(a.L, PP) > 256) ? stagger : 0;
+static int launch_bx3_t(const WnLayerArgs& a, hipStream_t s) {
     using T = Bx3Tile<C, S, PP, WV>;
     ProfileScope ps("wn_layer_bf16x3", s);
     const size_t lds = (size_t)T::LDS_FLOATS * 4;

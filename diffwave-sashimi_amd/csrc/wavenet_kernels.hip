@@ -234,8 +234,6 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     const int wm = wave % T::WM, wn = wave / T::WM;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    stagger_start(a.stagger & 0xffff, 512);
-    stagger_second(a.stagger >> 16, 256);
     const int ntl = (a.L + P - 1) / P;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     // readfirstlane: the integer divisions run on the VALU, and without it hipcc treats everything derived from b
@@ -539,13 +537,11 @@ int launch_wn_bias_tap(const float* Wd_all, const float* part_t, float* Abt, int
 }
 
 template <int C, int S>
-static int launch_layer_t(const WnLayerArgs& a_, hipStream_t s) {
+static int launch_layer_t(const WnLayerArgs& a, hipStream_t s) {
+    // (Start skews were measured and dropped: delaying the round-0 workgroups per CU, or the second workgroup of each
+    // CU by up to half a tile time so the pair runs in anti-phase, left the step at 72.0-72.1 ms or made it slower.)
     ProfileScope ps("wn_layer_mfma", s);
-    const int ntl = ceil_div(a_.L, WnTile<C, S>::P);
-    static const int stagger = (getenv("DWS_WN_STAGGER") ? atoi(getenv("DWS_WN_STAGGER")) : 0) |
-                               ((getenv("DWS_WN_STAGGER2") ? atoi(getenv("DWS_WN_STAGGER2")) : 0) << 16);
-    WnLayerArgs a = a_;
-    a.stagger = (a.B * ntl > 512) ? stagger : 0;
+    const int ntl = ceil_div(a.L, WnTile<C, S>::P);
     if (a.melc || a.hsave) hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, true>), dim3(a.B * ntl), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, false>), dim3(a.B * ntl), dim3(256), 0, s, a);
     return DWS_OK;

@@ -21,6 +21,7 @@ struct WaveNetModel : dws_model {
     DevBuf Wd_all;                   // folded dilated-conv weights of all layers [NL][2C][C][3]
     DevBuf Abt;                      // per-step embedding correction fragments [NL][B][2C/32][64][4]
     DevBuf Wt_all, bt_all;           // stacked fc_t [NL*C][Eout], [NL*C]
+    DevBuf b1_all;                   // stacked dilated-conv biases [NL][2C] (bf16x3: folded into the correction rows)
     DevBuf Wf, Af;                   // final_conv[0]
     DevBuf freq;                     // embedding frequencies [Ein/2]
     DevBuf tmp_pack;                 // scratch for permute -> pack
@@ -118,6 +119,7 @@ struct WaveNetModel : dws_model {
         DWS_TRY(fold("init_conv.0.conv", Wi.f(), C, Cin, s));
         DWS_TRY(Wt_all.ensure((size_t)NL * C * Eout * 4));
         DWS_TRY(bt_all.ensure((size_t)NL * C * 4));
+        DWS_TRY(b1_all.ensure((size_t)NL * 2 * C * 4));
         DWS_TRY(Wd_all.ensure((size_t)NL * 2 * C * C * 3 * 4));
         if (mfma_layer) DWS_TRY(tmp_pack.ensure((size_t)2 * C * 3 * C * 4));
         for (int n = 0; n < NL; ++n) {
@@ -125,6 +127,8 @@ struct WaveNetModel : dws_model {
             DWS_HIP(hipMemcpyAsync(Wt_all.f() + (size_t)n * C * Eout, P(p + ".fc_t.weight"), (size_t)C * Eout * 4,
                                    hipMemcpyDeviceToDevice, s));
             DWS_HIP(hipMemcpyAsync(bt_all.f() + (size_t)n * C, P(p + ".fc_t.bias"), (size_t)C * 4,
+                                   hipMemcpyDeviceToDevice, s));
+            DWS_HIP(hipMemcpyAsync(b1_all.f() + (size_t)n * 2 * C, P(p + ".dilated_conv_layer.conv.bias"), (size_t)2 * C * 4,
                                    hipMemcpyDeviceToDevice, s));
             DWS_TRY(fold(p + ".dilated_conv_layer.conv", Wd(n), 2 * C, C * 3, s));
             DWS_TRY(Wrs[n].ensure((size_t)(C + S) * C * 4));
@@ -317,7 +321,7 @@ struct WaveNetModel : dws_model {
         DWS_TRY(launch_linear_rows(h1.f(), P("residual_layer.fc_t2.weight"), P("residual_layer.fc_t2.bias"), h2.f(),
                                    (int)B, Emid, Eout, 1, s, train ? ta2.f() : nullptr));
         DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), (int)B, Eout, NL * C, 0, s));
-        if (mfma_layer && bf16x3) DWS_TRY(launch_wn_bias_tap_bf16(Wd_all.f(), part_t.f(), Abt.p, NL, (int)B, C, s));
+        if (mfma_layer && bf16x3) DWS_TRY(launch_wn_bias_tap_bf16(Wd_all.f(), part_t.f(), b1_all.f(), Abt.p, NL, (int)B, C, s));
         else if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
