@@ -17,6 +17,23 @@
 
 namespace dws {
 
+#ifdef BX3_NT
+typedef float bx3_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bx3_nt_store(float4* p, const float4& v) {
+    bx3_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<bx3_f4*>(p));
+}
+__device__ __forceinline__ float4 bx3_nt_load(const float4* p) {
+    const bx3_f4 t = __builtin_nontemporal_load(reinterpret_cast<const bx3_f4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+#define BX3_STORE(p, v) bx3_nt_store(p, v)
+#define BX3_LOAD(p) bx3_nt_load(p)
+#else
+#define BX3_STORE(p, v) (*(p) = (v))
+#define BX3_LOAD(p) (*(p))
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
 #pragma unroll
         for (int i = 0; i < S / ROWS_PASS; ++i)
             v4s[i] = a.first_layer ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                   : *reinterpret_cast<const float4*>(a.skip + ((size_t)b * S + i * ROWS_PASS + rsub) * L + pos4c);
+                                   : BX3_LOAD(reinterpret_cast<const float4*>(a.skip + ((size_t)b * S + i * ROWS_PASS + rsub) * L + pos4c));
     }
     __syncthreads();
 
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
                 const float4 v = *reinterpret_cast<const float4*>(otp + rl * P + f4 * 4);
                 const float4 w = v4s[p * (PR / ROWS_PASS) + i];
                 const float4 o = make_float4(w.x + v.x, w.y + v.y, w.z + v.z, w.w + v.w);
-                if (ok4) *reinterpret_cast<float4*>(sk + (size_t)(p * PR + rl) * L + pos4) = o;
+                if (ok4) BX3_STORE(reinterpret_cast<float4*>(sk + (size_t)(p * PR + rl) * L + pos4), o);
             }
             if (p + 1 < NPIECE) __syncthreads();
         }
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
             float4 x4[C / ROWS_PASS];
 #pragma unroll
             for (int i = 0; i < C / ROWS_PASS; ++i)
-                x4[i] = *reinterpret_cast<const float4*>(xb + (size_t)(i * ROWS_PASS + rsub) * L + pos4c);
+                x4[i] = BX3_LOAD(reinterpret_cast<const float4*>(xb + (size_t)(i * ROWS_PASS + rsub) * L + pos4c));
             f32x16 accR[MR][NT];
             int mtR[MR];
 #pragma unroll
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
                 const float4 v = *reinterpret_cast<const float4*>(ot + row * P + f4 * 4);
                 const float4 o = make_float4((x4[i].x + v.x) * rs, (x4[i].y + v.y) * rs, (x4[i].z + v.z) * rs,
                                              (x4[i].w + v.w) * rs);
-                if (ok4) *reinterpret_cast<float4*>(xo + (size_t)row * L + pos4) = o;
+                if (ok4) BX3_STORE(reinterpret_cast<float4*>(xo + (size_t)row * L + pos4), o);
             }
         }
     } else {
