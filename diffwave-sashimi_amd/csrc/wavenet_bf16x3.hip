@@ -17,7 +17,8 @@
 
 namespace dws {
 
-#ifdef BX3_NT
+// The epilogue's tile-sized streams (running skip in/out, residual x in, x' out: each touched once per layer and far larger
+// than the caches together) go with the nontemporal hint: 719 vs 737 us per launch on the same box.
 typedef float bx3_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void bx3_nt_store(float4* p, const float4& v) {
     bx3_f4 t = {v.x, v.y, v.z, v.w};
@@ -29,10 +30,6 @@ __device__ __forceinline__ float4 bx3_nt_load(const float4* p) {
 }
 #define BX3_STORE(p, v) bx3_nt_store(p, v)
 #define BX3_LOAD(p) bx3_nt_load(p)
-#else
-#define BX3_STORE(p, v) (*(p) = (v))
-#define BX3_LOAD(p) (*(p))
-#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
