@@ -116,11 +116,20 @@ __device__ __forceinline__ void column_stats(float* __restrict__ tile, float* __
 }
 
 // two waves per SIMD at least: without the bound hipcc spends > 256 registers per lane on one resident workgroup
-template <int H, int WM, int WN, int NT, int FFE>
+//
+// VEC (L % 4 == 0, chosen at launch): every tile-sized stream moves 16 bytes per lane -- g and the block input x are
+// staged by dwordx4 LDS-DMA (x into the still unused u buffer), the output and the next block's S4 input leave through
+// a row-major float4 pass over the tile in LDS.  In the accumulator layout (a lane owns single positions of 16 rows)
+// the same traffic takes four times the VMEM instructions, and their issue was the larger part of the kernel's
+// non-MFMA time.
+template <int H, int WM, int WN, int NT, int FFE, bool VEC>
 __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64 * WM * WN) : 1)) void s4_tail_mfma_kernel(
     S4TailArgs a) {
     using T = TailCfg<H, WM, WN, NT, FFE>;
     constexpr int P = T::P, MT = T::MT, THREADS = T::THREADS, PARTS = T::PARTS;
+    // row-major float4 view of an [H][P] tile: F4_ROW float4 per row, ROWS_PASS rows per pass of the workgroup
+    constexpr int F4_ROW = P / 4, ROWS_PASS = THREADS / F4_ROW, NPASS = H / ROWS_PASS;
+    static_assert(THREADS % F4_ROW == 0 && H % ROWS_PASS == 0, "row-major passes");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* tile = lds;                 // [H][P]: g, then x1 centred
     float* ut = lds + H * P;           // [H][P]: one H-row chunk of u
@@ -144,7 +153,25 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
     // kernel is MFMA time lost: all global traffic goes through buffer instructions whose row part is a scalar
     // offset (no per-lane 64-bit address math), and the g tile is staged by LDS-DMA (no VALU, no VGPRs).
     // ---- stage g tile: row r of the tile = P/64 DMA instructions of 64 positions
-    {
+    if constexpr (VEC) {
+        // one dwordx4 DMA instruction fills 256 consecutive floats of the tile = 256/P whole rows
+        constexpr int RPI = 256 / P, NI = H / RPI / (THREADS / 64);
+        static_assert(H % (RPI * (THREADS / 64)) == 0, "DMA split");
+        __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rXs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        const int pos = l0 + 4 * (lane % F4_ROW);
+        const int voff = pos < L ? ((lane / F4_ROW) * L + pos) * 4 : OOB;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row0 = (wave + (THREADS / 64) * i) * RPI;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, tile + row0 * P, 16, voff, row0 * L4, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row0 = (wave + (THREADS / 64) * i) * RPI;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rXs, ut + row0 * P, 16, voff, row0 * L4, 0, 0);
+        }
+    } else {
         __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + (size_t)b * H * L), 0, H * L4, 0x00020000);
         if constexpr (P >= 64) {
             constexpr int SEG = P / 64, NI = H * SEG / (THREADS / 64);
@@ -212,7 +239,8 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int soff = (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4;
-                    xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, soff, 0));
+                    if constexpr (VEC) xr[r] = ut[(mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P + col];
+                    else xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, soff, 0));
                     if (has_mel) xr[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voff, soff, 0));
                 }
 #pragma unroll
@@ -281,70 +309,140 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
     }
 
     // ---- out = x1 + f (+ addend);  x1 = centred tile + mean
-    __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.addend ? a.addend + (size_t)b * H * L : a.out), 0, H * L4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, H * 4, 0x00020000);
-    const bool has_add = a.addend != nullptr;
+    if constexpr (VEC) {
+        __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.addend ? a.addend + (size_t)b * H * L : a.out), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, H * 4, 0x00020000);
+        const bool has_add = a.addend != nullptr;
+        const int f4 = tid % F4_ROW, rsub = tid / F4_ROW;
+        const int pos4 = l0 + 4 * f4;
+        const int voff4 = pos4 < L ? (rsub * L + pos4) * 4 : OOB;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        // the U-Net skip rows of this thread's row-major float4s: requested before the accumulator pass
+        f32x4 ad4[NPASS];
+        if (has_add) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        float b2v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            b2v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int col = (wn * NT + n) * 32 + l31;
-            const int pos = l0 + col;
-            const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
-            const float mean = colmean[col];
-            float ad[16];
-            if (has_add) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ad[r] = 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const float v = (tile[h * P + col] + mean) + (acc2[m][n][r] + b2v[r]) + ad[r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0);
-                if (a.ynext) tile[h * P + col] = v;    // this thread's own element: the block output stays in LDS
-            }
+            for (int i = 0; i < NPASS; ++i)
+                ad4[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff4, i * ROWS_PASS * L4, 0));
         }
-    }
-    if (a.ynext == nullptr) return;   // uniform
-
-    // ---- the next block's S4 input: LN1_next down the columns of the output tile + its step-embedding projection
-    __syncthreads();
-    column_stats<H, P, PARTS>(tile, red, colmean, colalpha, a.n1_s[0], tid);
-    {
-        __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e_next + (size_t)b * a.e_stride), 0, H * 4, 0x00020000);
-        const float n1m = a.n1_m[0];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            float ev[16];
+            float b2v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                ev[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rE, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+                b2v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
 #pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = (wn * NT + n) * 32 + l31;
+                const float mean = colmean[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    tile[h * P + col] = (tile[h * P + col] + mean) + (acc2[m][n][r] + b2v[r]);   // own element
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            float* tp = tile + (i * ROWS_PASS + rsub) * P + 4 * f4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(tp);
+            if (has_add) {
+                v += ad4[i];
+                if (a.ynext) *reinterpret_cast<f32x4*>(tp) = v;   // own float4: the block output stays in LDS
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rO, voff4, i * ROWS_PASS * L4, 0);
+        }
+        if (a.ynext == nullptr) return;   // uniform
+
+        // ---- the next block's S4 input: LN1_next down the columns of the output tile + its step-embedding projection
+        __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e_next + (size_t)b * a.e_stride), 0, H * 4, 0x00020000);
+        float ev[NPASS];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i)
+            ev[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rE, rsub * 4, i * ROWS_PASS * 4, 0));
+        __syncthreads();
+        column_stats<H, P, PARTS>(tile, red, colmean, colalpha, a.n1_s[0], tid);
+        const float n1m = a.n1_m[0];
+        const f32x4 al = *reinterpret_cast<const f32x4*>(colalpha + 4 * f4);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (i * ROWS_PASS + rsub) * P + 4 * f4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaf(al[e], t[e] + n1m, ev[i]);     // (s/sd)(x - mu + m) + fc_t(e)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rY, voff4, i * ROWS_PASS * L4, 0);
+        }
+    } else {
+        __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.addend ? a.addend + (size_t)b * H * L : a.out), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, H * 4, 0x00020000);
+        const bool has_add = a.addend != nullptr;
+    #pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float b2v[16];
+    #pragma unroll
+            for (int r = 0; r < 16; ++r)
+                b2v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+    #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int col = (wn * NT + n) * 32 + l31;
                 const int pos = l0 + col;
                 const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
-                const float al = colalpha[col];
-#pragma unroll
+                const float mean = colmean[col];
+                float ad[16];
+                if (has_add) {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
+                } else {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) ad[r] = 0.f;
+                }
+    #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const float y = fmaf(al, tile[h * P + col] + n1m, ev[r]);      // (s/sd)(x - mu + m) + fc_t(e)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rY, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0);
+                    const float v = (tile[h * P + col] + mean) + (acc2[m][n][r] + b2v[r]) + ad[r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0);
+                    if (a.ynext) tile[h * P + col] = v;    // this thread's own element: the block output stays in LDS
                 }
             }
         }
+        if (a.ynext == nullptr) return;   // uniform
+
+        // ---- the next block's S4 input: LN1_next down the columns of the output tile + its step-embedding projection
+        __syncthreads();
+        column_stats<H, P, PARTS>(tile, red, colmean, colalpha, a.n1_s[0], tid);
+        {
+            __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
+            __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e_next + (size_t)b * a.e_stride), 0, H * 4, 0x00020000);
+            const float n1m = a.n1_m[0];
+    #pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float ev[16];
+    #pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ev[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rE, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+    #pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = (wn * NT + n) * 32 + l31;
+                    const int pos = l0 + col;
+                    const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
+                    const float al = colalpha[col];
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int h = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        const float y = fmaf(al, tile[h * P + col] + n1m, ev[r]);      // (s/sd)(x - mu + m) + fc_t(e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rY, voff, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0);
+                    }
+                }
+            }
+        }
+
     }
 }
 
@@ -354,13 +452,19 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     ProfileScope ps("s4_tail_mfma", s);
     const int ntl = ceil_div(a.L, T::P);
     const size_t lds = (size_t)T::LDS_FLOATS * 4;
-    auto kern = s4_tail_mfma_kernel<H, WM, WN, NT, 2>;
+    static const bool no_vec = getenv("DWS_TAIL_NO_VEC") != nullptr;
     static bool attr_set = false;
     if (!attr_set) {
-        DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+    if ((a.L & 3) == 0 && !no_vec)
+        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, true>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+    else
+        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, false>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
     return DWS_OK;
 }
 

@@ -18,16 +18,8 @@
 
 #include "wavenet_backward.h"
 
-// cache-policy bits (aux) of the streamed operands: 0 = default, 2 = nontemporal
-#ifndef DWS_TC_IN_AUX
-#define DWS_TC_IN_AUX 0
-#endif
-#ifndef DWS_TC_OUT_AUX
-#define DWS_TC_OUT_AUX 0
-#endif
-#ifndef DWS_WG_AUX
-#define DWS_WG_AUX 0
-#endif
+// (Nontemporal cache policy on the streamed operands -- tapconv input DMA, its output stores, the wgrad DMA -- was
+// measured on the config-5 step: 158-162 ms with and without, no effect.)
 
 namespace dws {
 
@@ -83,7 +75,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int tap = row / KC, cc = row % KC;
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)cc * L), 0, L * 4, 0x00020000);
             const int voff = (l0 + lane + a.sign * (tap - T / 2) * a.dil) * 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 4, voff, 0, 0, DWS_TC_IN_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 4, voff, 0, 0, 0);
         }
     };
 
@@ -184,7 +176,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     const int row0 = mt[m] * 32 + it * 4;
                     f32x4 v = *reinterpret_cast<const f32x4*>(wl + (it * 4 + lrow) * P + p4);
                     if (has_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, lrow * 4, row0 * 4, 0));
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rOut, voff, row0 * L4, DWS_TC_OUT_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rOut, voff, row0 * L4, 0);
                     if (m == 0) {
                         va[it] = v;
                     } else {
@@ -193,7 +185,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                         if (has_mel) x1 += buf_load4(rMel, voff, soff2);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x1[j] += va[it][j] * sigm_b(v[j]);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x1), rX1, voff, soff2, DWS_TC_OUT_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x1), rX1, voff, soff2, 0);
                     }
                 }
             }
@@ -229,12 +221,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     if (has_addend) v += buf_load4(rAdd, voff, soff);
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rOut, voff, soff, DWS_TC_OUT_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rOut, voff, soff, 0);
             if (EPI == 3) {
                 f32x4 gq;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) gq[j] = gelu_b(v[j]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, gq), rOut2, voff, soff, DWS_TC_OUT_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, gq), rOut2, voff, soff, 0);
             }
         }
         }
@@ -521,8 +513,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
         for (int i = 0; i < 16; ++i) {           // 8 waves x 16 rows of each operand
             const int row = wave + 8 * i;
             const int o = min(o0 + row, a.O - 1), c = min(c0 + row, a.C - 1);   // rows past O / C feed unstored outputs only
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, sdy + row * LD, 4, voff, (b * a.O + o) * L * 4, 0, DWS_WG_AUX);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, sx + row * LD, 4, voff, (b * a.C + c) * xL * 4, 0, DWS_WG_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, sdy + row * LD, 4, voff, (b * a.O + o) * L * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, sx + row * LD, 4, voff, (b * a.C + c) * xL * 4, 0, 0);
         }
     };
 
