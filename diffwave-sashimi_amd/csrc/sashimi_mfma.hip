@@ -122,9 +122,8 @@ __device__ __forceinline__ void column_stats(float* __restrict__ tile, float* __
 // a row-major float4 pass over the tile in LDS.  In the accumulator layout (a lane owns single positions of 16 rows)
 // the same traffic takes four times the VMEM instructions, and their issue was the larger part of the kernel's
 // non-MFMA time.
-template <int H, int WM, int WN, int NT, int FFE, bool VEC>
-__global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64 * WM * WN) : 1)) void s4_tail_mfma_kernel(
-    S4TailArgs a) {
+template <int H, int WM, int WN, int NT, int FFE, bool VEC, int OCC = (512 / (64 * WM * WN) > 0 ? 512 / (64 * WM * WN) : 1)>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailArgs a) {
     using T = TailCfg<H, WM, WN, NT, FFE>;
     constexpr int P = T::P, MT = T::MT, THREADS = T::THREADS, PARTS = T::PARTS;
     // row-major float4 view of an [H][P] tile: F4_ROW float4 per row, ROWS_PASS rows per pass of the workgroup
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN) > 0 ? 512 / (64
     }
 }
 
-template <int H, int WM, int WN, int NT>
+template <int H, int WM, int WN, int NT, int OCC = (512 / (64 * WM * WN) > 0 ? 512 / (64 * WM * WN) : 1)>
 static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     using T = TailCfg<H, WM, WN, NT, 2>;
     ProfileScope ps("s4_tail_mfma", s);
@@ -455,16 +454,16 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     static const bool no_vec = getenv("DWS_TAIL_NO_VEC") != nullptr;
     static bool attr_set = false;
     if (!attr_set) {
-        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true>,
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, false>,
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, false, OCC>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     if ((a.L & 3) == 0 && !no_vec)
-        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, true>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
     else
-        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, false>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, false, OCC>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
     return DWS_OK;
 }
 
@@ -473,6 +472,18 @@ bool s4_tail_mfma_supported(int H, int ff) {
 }
 
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
+    static const int alt = getenv("DWS_TAIL_CFG") ? atoi(getenv("DWS_TAIL_CFG")) : 0;
+    if (alt == 1) {   // 64-position tiles, NT = 1: half the LDS and accumulators per workgroup, 4 workgroups per CU
+        if (H == 64) return launch_tail_t<64, 2, 2, 1, 4>(a, s);
+    }
+    if (alt == 2) {   // same tile, twice the waves (NT = 1), 2 workgroups per CU = 4 waves per SIMD
+        if (H == 64) return launch_tail_t<64, 2, 4, 1, 2>(a, s);
+        if (H == 128) return launch_tail_t<128, 4, 2, 1, 2>(a, s);
+    }
+    if (alt == 3) {   // twice the positions per workgroup at the same wave count
+        if (H == 128) return launch_tail_t<128, 4, 1, 4, 1>(a, s);
+        if (H == 256) return launch_tail_t<256, 8, 1, 4, 1>(a, s);
+    }
     switch (H) {
         case 32: return launch_tail_t<32, 1, 4, 1>(a, s);   // (256-position tiles, NT = 2: 177 us against 137 us)
         case 64: return launch_tail_t<64, 2, 2, 2>(a, s);
