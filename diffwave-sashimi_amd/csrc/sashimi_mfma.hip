@@ -473,16 +473,14 @@ bool s4_tail_mfma_supported(int H, int ff) {
 
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     static const int alt = getenv("DWS_TAIL_CFG") ? atoi(getenv("DWS_TAIL_CFG")) : 0;
-    if (alt == 1) {   // 64-position tiles, NT = 1: half the LDS and accumulators per workgroup, 4 workgroups per CU
+    if (alt == 1) {   // half-size tiles, NT = 1: half the LDS and accumulators per workgroup, more workgroups per CU
+        if (H == 32) return launch_tail_t<32, 1, 2, 1, 4>(a, s);
         if (H == 64) return launch_tail_t<64, 2, 2, 1, 4>(a, s);
+        if (H == 128) return launch_tail_t<128, 4, 1, 1, 3>(a, s);
+        if (H == 256) return launch_tail_t<256, 8, 1, 1, 2>(a, s);
     }
-    if (alt == 2) {   // same tile, twice the waves (NT = 1), 2 workgroups per CU = 4 waves per SIMD
-        if (H == 64) return launch_tail_t<64, 2, 4, 1, 2>(a, s);
-        if (H == 128) return launch_tail_t<128, 4, 2, 1, 2>(a, s);
-    }
-    if (alt == 3) {   // twice the positions per workgroup at the same wave count
-        if (H == 128) return launch_tail_t<128, 4, 1, 4, 1>(a, s);
-        if (H == 256) return launch_tail_t<256, 8, 1, 4, 1>(a, s);
+    if (alt == 2) {
+        if (H == 128) return launch_tail_t<128, 4, 1, 1, 4>(a, s);
     }
     switch (H) {
         case 32: return launch_tail_t<32, 1, 4, 1>(a, s);   // (256-position tiles, NT = 2: 177 us against 137 us)
