@@ -54,6 +54,9 @@ __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* _
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int m = 0; m < MT; ++m) buf[d][m] = A[((size_t)mt[m] * nkg_total + kg0 + d) * 64 + lane];
+#ifndef DWS_TAIL_KG_UNROLL
+#pragma unroll 1   // fully unrolled (nkg is a constant at every call site) hipcc hoists the ring loads: +40..100 VGPRs
+#endif
     for (int kg = 0; kg < nkg; kg += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -476,11 +479,8 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     if (alt == 1) {   // half-size tiles, NT = 1: half the LDS and accumulators per workgroup, more workgroups per CU
         if (H == 32) return launch_tail_t<32, 1, 2, 1, 4>(a, s);
         if (H == 64) return launch_tail_t<64, 2, 2, 1, 4>(a, s);
-        if (H == 128) return launch_tail_t<128, 4, 1, 1, 3>(a, s);
-        if (H == 256) return launch_tail_t<256, 8, 1, 1, 2>(a, s);
-    }
-    if (alt == 2) {
         if (H == 128) return launch_tail_t<128, 4, 1, 1, 4>(a, s);
+        if (H == 256) return launch_tail_t<256, 8, 1, 1, 2>(a, s);
     }
     switch (H) {
         case 32: return launch_tail_t<32, 1, 4, 1>(a, s);   // (256-position tiles, NT = 2: 177 us against 137 us)
