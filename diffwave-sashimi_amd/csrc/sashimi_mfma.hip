@@ -40,7 +40,9 @@ struct TailCfg {
 
 // One H-row x K GEMM slab on the wave's MT tiles: acc[m][n] += A[tile rows] . Bt[K x P]
 // A packed as pack[mt][kg][lane][4]; Bt in LDS row-major [K][P].
-template <int MT, int NT, int P>
+// KGU: leave the k-group loop to hipcc's unroller (nkg is a constant at every call site: it unrolls fully and hoists
+// ring loads, +40..100 VGPRs but a little faster where the registers are there); !KGU pins it rolled (`unroll 1`).
+template <int MT, int NT, int P, bool KGU>
 __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* __restrict__ A, int nkg_total,
                                           int kg0, int nkg, const int (&mt)[MT], const float* __restrict__ bt, int wn,
                                           int lane) {
@@ -54,33 +56,30 @@ __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* _
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int m = 0; m < MT; ++m) buf[d][m] = A[((size_t)mt[m] * nkg_total + kg0 + d) * 64 + lane];
-#ifndef DWS_TAIL_KG_UNROLL
-#pragma unroll 1   // fully unrolled (nkg is a constant at every call site) hipcc hoists the ring loads: +40..100 VGPRs
-#endif
-    for (int kg = 0; kg < nkg; kg += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float4 cur[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) cur[m] = buf[d][m];
-            const int kn = min(kg + d + D, nkg - 1);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) buf[d][m] = A[((size_t)mt[m] * nkg_total + kg0 + kn) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int krow = (kg + d) * 8 + j * 2 + lhi;
-                float bf[NT];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bf[n] = bt[krow * P + (wn * NT + n) * 32 + l31];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(cur[m], j), bf[n], acc[m][n], 0, 0, 0);
-            }
-        }
+#define DWS_TAIL_GROUP4                                                                                               \
+    _Pragma("unroll") for (int d = 0; d < D; ++d) {                                                                  \
+        float4 cur[MT];                                                                                              \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) cur[m] = buf[d][m];                                           \
+        const int kn = min(kg + d + D, nkg - 1);                                                                     \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                               \
+            buf[d][m] = A[((size_t)mt[m] * nkg_total + kg0 + kn) * 64 + lane];                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+            const int krow = (kg + d) * 8 + j * 2 + lhi;                                                             \
+            float bf[NT];                                                                                            \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) bf[n] = bt[krow * P + (wn * NT + n) * 32 + l31];          \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                           \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                       \
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(cur[m], j), bf[n], acc[m][n], 0, 0, 0);  \
+        }                                                                                                            \
     }
+    if constexpr (KGU) {
+        for (int kg = 0; kg < nkg; kg += D) { DWS_TAIL_GROUP4 }
+    } else {
+#pragma unroll 1
+        for (int kg = 0; kg < nkg; kg += D) { DWS_TAIL_GROUP4 }
+    }
+#undef DWS_TAIL_GROUP4
 }
 
 // TransposedLN statistics of an [H][P] tile in LDS, down each column (population std, no eps; `sashimi.py:17-20`):
@@ -125,7 +124,7 @@ __device__ __forceinline__ void column_stats(float* __restrict__ tile, float* __
 // a row-major float4 pass over the tile in LDS.  In the accumulator layout (a lane owns single positions of 16 rows)
 // the same traffic takes four times the VMEM instructions, and their issue was the larger part of the kernel's
 // non-MFMA time.
-template <int H, int WM, int WN, int NT, int FFE, bool VEC, int OCC = (512 / (64 * WM * WN) > 0 ? 512 / (64 * WM * WN) : 1)>
+template <int H, int WM, int WN, int NT, int FFE, bool VEC, int OCC, bool KGU>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailArgs a) {
     using T = TailCfg<H, WM, WN, NT, FFE>;
     constexpr int P = T::P, MT = T::MT, THREADS = T::THREADS, PARTS = T::PARTS;
@@ -213,8 +212,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc_a[m][n][r] = 0.f; acc_b[m][n][r] = 0.f; }
-        gemm_slab<MT, NT, P>(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane);
-        gemm_slab<MT, NT, P>(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane);
+        gemm_slab<MT, NT, P, KGU>(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane);
+        gemm_slab<MT, NT, P, KGU>(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane);
         __syncthreads();  // every wave is done reading g
         // x1 = x + GLU(o) (+ mel) -> tile.  (Requesting x together with the g tile, so that its HBM round trip overlaps the
         // staging barrier, was measured on the same box: 166.5 vs 165.1 us at H = 64 -- no gain, not kept.)
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         int mt_q[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) mt_q[m] = q * (H / 32) + mt_h[m];
-        gemm_slab<MT, NT, P>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
+        gemm_slab<MT, NT, P, KGU>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
         if (q > 0) __syncthreads();  // previous chunk of u fully consumed by GEMM-2
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
             }
         }
         __syncthreads();
-        gemm_slab<MT, NT, P>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
+        gemm_slab<MT, NT, P, KGU>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
     }
 
     // ---- out = x1 + f (+ addend);  x1 = centred tile + mean
@@ -448,7 +447,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
     }
 }
 
-template <int H, int WM, int WN, int NT, int OCC = (512 / (64 * WM * WN) > 0 ? 512 / (64 * WM * WN) : 1)>
+template <int H, int WM, int WN, int NT, int OCC, bool KGU>
 static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     using T = TailCfg<H, WM, WN, NT, 2>;
     ProfileScope ps("s4_tail_mfma", s);
@@ -457,16 +456,16 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     static const bool no_vec = getenv("DWS_TAIL_NO_VEC") != nullptr;
     static bool attr_set = false;
     if (!attr_set) {
-        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC>,
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, KGU>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, false, OCC>,
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, false, OCC, KGU>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     if ((a.L & 3) == 0 && !no_vec)
-        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, KGU>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
     else
-        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, false, OCC>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+        hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, false, OCC, KGU>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
     return DWS_OK;
 }
 
@@ -475,19 +474,25 @@ bool s4_tail_mfma_supported(int H, int ff) {
 }
 
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
+    // Tile shapes <H, waves along rows, waves along positions, 32-position tiles per wave, workgroups per CU the register
+    // budget is set for, k-group loop unrolled>, each the best of a same-box sweep (`profiles/r02_tail_shapes.txt`): up to
+    // H = 128 small tiles win (NT = 1, 32-64 positions: a workgroup is MFMA-active less than a third of its life, and
+    // four of them per CU hide each other's staging, LayerNorm and epilogue phases better than two); at H = 256 the
+    // A-fragment reuse of NT = 2 is worth more.  DWS_TAIL_CFG=1 selects the round-1 shapes.
     static const int alt = getenv("DWS_TAIL_CFG") ? atoi(getenv("DWS_TAIL_CFG")) : 0;
-    if (alt == 1) {   // half-size tiles, NT = 1: half the LDS and accumulators per workgroup, more workgroups per CU
-        if (H == 32) return launch_tail_t<32, 1, 2, 1, 4>(a, s);
-        if (H == 64) return launch_tail_t<64, 2, 2, 1, 4>(a, s);
-        if (H == 128) return launch_tail_t<128, 4, 1, 1, 4>(a, s);
-        if (H == 256) return launch_tail_t<256, 8, 1, 1, 2>(a, s);
+    if (alt == 1) {
+        switch (H) {
+            case 32: return launch_tail_t<32, 1, 4, 1, 2, true>(a, s);
+            case 64: return launch_tail_t<64, 2, 2, 2, 2, true>(a, s);
+            case 128: return launch_tail_t<128, 4, 1, 2, 2, true>(a, s);
+        }
     }
     switch (H) {
-        case 32: return launch_tail_t<32, 1, 4, 1>(a, s);   // (256-position tiles, NT = 2: 177 us against 137 us)
-        case 64: return launch_tail_t<64, 2, 2, 2>(a, s);
-        case 128: return launch_tail_t<128, 4, 1, 2>(a, s);
-        case 256: return launch_tail_t<256, 8, 1, 2>(a, s);
-        case 512: return launch_tail_t<512, 16, 1, 1>(a, s);  // 32 positions x 16 waves: the tiles fill 139 KB of LDS
+        case 32: return launch_tail_t<32, 1, 2, 1, 4, true>(a, s);    // 124.7 us (C4) against 127.9 for <32,1,4,1,2>
+        case 64: return launch_tail_t<64, 2, 2, 1, 4, true>(a, s);    // 141.9 / 89.2 us (C3 / C4) against 157.2 / 109.2 for <64,2,2,2,2>
+        case 128: return launch_tail_t<128, 4, 1, 1, 4, false>(a, s); // 128.6 / 72.5 us against 126.9 / 77.0 for <128,4,1,2,2>
+        case 256: return launch_tail_t<256, 8, 1, 2, 1, true>(a, s);  // (32-position tiles, two workgroups per CU: 121-149 us against 115)
+        case 512: return launch_tail_t<512, 16, 1, 1, 1, true>(a, s); // 32 positions x 16 waves: the tiles fill 139 KB of LDS
     }
     return set_error(DWS_ERR_UNSUPPORTED, "s4_tail_mfma: H=%d not instantiated", H);
 }
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nchunk) stage_load(c + 1);
-        gemm_slab<MT, NT, P>(acc, A, K / 8, c * (KC / 8), KC / 8, mt, lds + (c & 1) * KC * P, 0, lane);
+        gemm_slab<MT, NT, P, true>(acc, A, K / 8, c * (KC / 8), KC / 8, mt, lds + (c & 1) * KC * P, 0, lane);
         if (c + 1 < nchunk) stage_store((c + 1) & 1);
         __syncthreads();
     }
