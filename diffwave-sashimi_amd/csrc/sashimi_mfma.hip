@@ -453,7 +453,7 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     ProfileScope ps("s4_tail_mfma", s);
     const int ntl = ceil_div(a.L, T::P);
     const size_t lds = (size_t)T::LDS_FLOATS * 4;
-    static const bool no_vec = getenv("DWS_TAIL_NO_VEC") != nullptr;
+    const bool no_vec = getenv("DWS_TAIL_NO_VEC") != nullptr;   // (read per launch: tests switch it inside one process)
     static bool attr_set = false;
     if (!attr_set) {
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, KGU>,
@@ -479,7 +479,7 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     // H = 128 small tiles win (NT = 1, 32-64 positions: a workgroup is MFMA-active less than a third of its life, and
     // four of them per CU hide each other's staging, LayerNorm and epilogue phases better than two); at H = 256 the
     // A-fragment reuse of NT = 2 is worth more.  DWS_TAIL_CFG=1 selects the round-1 shapes.
-    static const int alt = getenv("DWS_TAIL_CFG") ? atoi(getenv("DWS_TAIL_CFG")) : 0;
+    const int alt = getenv("DWS_TAIL_CFG") ? atoi(getenv("DWS_TAIL_CFG")) : 0;
     if (alt == 1) {
         switch (H) {
             case 32: return launch_tail_t<32, 1, 4, 1, 2, true>(a, s);

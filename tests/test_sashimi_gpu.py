@@ -227,3 +227,28 @@ def test_fused_next_block_layernorm_agrees_with_the_separate_pass(gpu, name):
         del os.environ["DWS_SASHIMI_NO_LN_FUSION"]
     assert rel_err(fused, plain) < 1e-5
     assert torch.equal(fused, _run(net, gpu, audio, steps))
+
+
+@pytest.mark.parametrize("name", ["ss_d64_short", "ss_d128_short", "ss_cond_d32"])
+@pytest.mark.parametrize("switch", ["DWS_TAIL_CFG", "DWS_TAIL_NO_VEC"])
+def test_tail_kernel_variants_agree(gpu, name, switch):
+    """The fused tail kernel (`sashimi.py:177-184`) in its other tile shapes (DWS_TAIL_CFG=1: 128-position tiles) and with
+    per-lane dword instead of 16-byte global traffic (DWS_TAIL_NO_VEC=1, the path L % 4 != 0 takes) -- same weights, same
+    inputs (the conditional case with its mel term); only the order of the LayerNorm partial sums differs between shapes."""
+    import os
+    mel = None
+    if name in cases.SASHIMI_COND_CASES:
+        cfg, B, Tmel, wseed, iseed, _ = cases.SASHIMI_COND_CASES[name]
+        mel = cases.mel_inputs(B, Tmel, iseed)
+    else:
+        cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES[name]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    base = _run(net, gpu, audio, steps, mel)
+    os.environ[switch] = "1"
+    try:
+        other = _run(net, gpu, audio, steps, mel)
+    finally:
+        del os.environ[switch]
+    assert rel_err(base, other) < 1e-5
+    assert torch.equal(base, _run(net, gpu, audio, steps, mel))
