@@ -489,9 +489,11 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     switch (H) {
         case 32: return launch_tail_t<32, 1, 2, 1, 4, true>(a, s);    // 124.7 us (C4) against 127.9 for <32,1,4,1,2>
         case 64: return launch_tail_t<64, 2, 2, 1, 4, true>(a, s);    // 141.9 / 89.2 us (C3 / C4) against 157.2 / 109.2 for <64,2,2,2,2>
-        case 128:   // 32-position tiles only while they are needed to fill the chip: 72.5 us against 77.0 at 32 k positions
-                    // (C4), 128.6 against 126.9 at 64 k (C3), 17.96 against 17.91 ms per config-5 sampling step at 256 k
-            if ((size_t)a.B * a.L < 48000) return launch_tail_t<128, 4, 1, 1, 4, false>(a, s);
+        case 128:   // 32-position tiles on short stages only: 72.5 us against 77.0 at L = 1000 x 32 clips (C4), 128.6 against
+                    // 126.9 at 4000 x 16 (C3), 17.96 against 17.91 ms per config-5 sampling step at 16000 x 16.  The choice
+                    // looks at L alone, so a clip's result does not depend on how many neighbours share its batch
+                    // (the shapes sum the LayerNorm partials in different orders).
+            if (a.L < 2048) return launch_tail_t<128, 4, 1, 1, 4, false>(a, s);
             return launch_tail_t<128, 4, 1, 2, 2, true>(a, s);
         case 256: return launch_tail_t<256, 8, 1, 2, 1, true>(a, s);  // (32-position tiles, two workgroups per CU: 121-149 us against 115)
         case 512: return launch_tail_t<512, 16, 1, 1, 1, true>(a, s); // 32 positions x 16 waves: the tiles fill 139 KB of LDS
