@@ -326,6 +326,11 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
     for (int cb = 0; cb < T::NCB; ++cb) {
         if (cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
         const float* xs = lds + (cb & 1) * (3 * KC * P);
+        // B fragments are read ONE k-step ahead of the MFMAs that use them (hipcc leaves each ds_read directly in front
+        // of its first use and the wave sits out the LDS latency every 8 MFMAs otherwise); bfq = the next step's values
+        float bfq[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bfq[n] = xs[lhi * P + (wn * NT + n) * 32 + l31];
 #pragma unroll
         for (int it = 0; it < 3 * KC / 8; ++it) {  // (tap, kg) flattened: 8 consecutive k per iteration
             const int kg = cb * (3 * KC / 8) + it;
@@ -337,15 +342,25 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int krow = it * 8 + j * 2 + lhi;  // row inside the chunk (tap*KC + cc)
                 float bf[NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bf[n] = xs[krow * P + (wn * NT + n) * 32 + l31];
+                for (int n = 0; n < NT; ++n) bf[n] = bfq[n];
+                const int kq = it * 4 + j + 1;              // next k-step of this chunk (the last one re-reads itself)
+                const int krow = (kq < 3 * KC / 2 ? kq : kq - 1) * 2 + lhi;
+#ifndef DWS_WN_NO_BPREFETCH
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bfq[n] = xs[krow * P + (wn * NT + n) * 32 + l31];
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int m = 0; m < 2 * MP; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j], bf[n], acc[m][n], 0, 0, 0);
+#ifdef DWS_WN_NO_BPREFETCH
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bfq[n] = xs[krow * P + (wn * NT + n) * 32 + l31];
+#endif
             }
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) a_cur[m] = a_nxt[m];
@@ -435,6 +450,9 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
     f32x4 c_cur[MR + MS], c_nxt[MR + MS];
 #pragma unroll
     for (int m = 0; m < MR + MS; ++m) c_cur[m] = buf_load_f4(rA2, lane16, (mt2[m] * NKG2) * 1024);
+    float gq[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) gq[n] = gt[lhi * P + (wn * NT + n) * 32 + l31];
 #pragma unroll 2
     for (int kg = 0; kg < NKG2; ++kg) {
         const int kgn = (kg + 1 < NKG2) ? kg + 1 : kg;
@@ -443,15 +461,25 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int krow = kg * 8 + j * 2 + lhi;
             float bf[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = gt[krow * P + (wn * NT + n) * 32 + l31];
+            for (int n = 0; n < NT; ++n) bf[n] = gq[n];
+            const int kq = kg * 4 + j + 1;                  // next k-step (the last one re-reads itself)
+            const int krow = (kq < C / 2 ? kq : kq - 1) * 2 + lhi;
+#ifndef DWS_WN_NO_BPREFETCH
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gq[n] = gt[krow * P + (wn * NT + n) * 32 + l31];
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int m = 0; m < MR + MS; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][j], bf[n], acc2[m][n], 0, 0, 0);
+#ifdef DWS_WN_NO_BPREFETCH
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gq[n] = gt[krow * P + (wn * NT + n) * 32 + l31];
+#endif
         }
 #pragma unroll
         for (int m = 0; m < MR + MS; ++m) c_cur[m] = c_nxt[m];
