@@ -176,9 +176,9 @@ int launch_init_conv(const float* audio, const float* W, const float* bias, floa
 // ---------------------------------------------------------------------------
 // Fused residual layer, exact-f32 MFMA path
 // ---------------------------------------------------------------------------
-template <int C, int S, int PP = 64>
+template <int C, int S>
 struct WnTile {
-    static constexpr int P = PP;                            // positions per workgroup (64, or 32: see launch_layer_t)
+    static constexpr int P = 64;                            // positions per workgroup
     static constexpr int WAVES = 4;
     static constexpr int WM = (C / 32 >= 4) ? 4 : C / 32;   // waves along M
     static constexpr int WN = WAVES / WM;                   // waves along N
@@ -222,9 +222,9 @@ __device__ __forceinline__ f32x4 buf_load_f4(__amdgpu_buffer_rsrc_t r, int voff,
 
 // EXTRA = false is the unconditional sampling instance: the conditioner add and the training save of the gate
 // pre-activations (128 never-taken branches per tile otherwise) are compiled out.
-template <int C, int S, bool EXTRA, int PP = 64, int OCC = 2>
-__global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) {
-    using T = WnTile<C, S, PP>;
+template <int C, int S, bool EXTRA>
+__global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
+    using T = WnTile<C, S>;
     constexpr int P = T::P, KC = T::KC, NT = T::NT, MP = T::MP, MR = T::MR, MS = T::MS;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
 
@@ -251,42 +251,16 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
     // added here; it enters GEMM1 as three extra K rows (see `ind` below).
     constexpr int ROWS = 3 * KC;            // rows per chunk
     constexpr int RPW = ROWS / T::WAVES;    // rows per wave
-    // P = 32: a 64-lane DMA instruction moves TWO consecutive channel rows (adjacent in the tile and L floats apart in
-    // memory) through a descriptor over both.  That is exact wherever no tap leaves [0, L) -- the interior tiles;
-    // a tile within `dil` of either end takes per-row descriptors on the lower half of the wave instead.
-    const bool interior = (l0 - dil >= 0) && (l0 + P - 1 + dil < L);
     auto stage_dma = [&](int cb, int buf) {
         float* xs = lds + buf * (3 * KC * P);
-        if constexpr (P == 64) {
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int row = wave + T::WAVES * i;
-                const int tap = row / KC, cc = row % KC;
-                const int c = cb * KC + cc;
-                __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * L), 0, L * 4, 0x00020000);
-                const int voff = (l0 + lane + (tap - 1) * dil) * 4;  // negative -> huge unsigned -> out of range -> 0
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 4, voff, 0, 0, 0);
-            }
-        } else if (interior) {
-#pragma unroll
-            for (int i = 0; i < RPW / 2; ++i) {
-                const int row = 2 * (wave + T::WAVES * i);          // rows (tap, cc) and (tap, cc + 1)
-                const int tap = row / KC, cc = row % KC;
-                const int c = cb * KC + cc;
-                __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * L), 0, 2 * L * 4, 0x00020000);
-                const int voff = (lhi * L + l0 + l31 + (tap - 1) * dil) * 4;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 4, voff, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int row = wave + T::WAVES * i;
-                const int tap = row / KC, cc = row % KC;
-                const int c = cb * KC + cc;
-                __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * L), 0, L * 4, 0x00020000);
-                const int voff = (l0 + l31 + (tap - 1) * dil) * 4;
-                if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 4, voff, 0, 0, 0);
-            }
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + T::WAVES * i;
+            const int tap = row / KC, cc = row % KC;
+            const int c = cb * KC + cc;
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * L), 0, L * 4, 0x00020000);
+            const int voff = (l0 + lane + (tap - 1) * dil) * 4;  // negative -> huge unsigned -> out of range -> 0
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 4, voff, 0, 0, 0);
         }
     };
 
@@ -326,11 +300,6 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
     for (int cb = 0; cb < T::NCB; ++cb) {
         if (cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
         const float* xs = lds + (cb & 1) * (3 * KC * P);
-        // B fragments are read ONE k-step ahead of the MFMAs that use them (hipcc leaves each ds_read directly in front
-        // of its first use and the wave sits out the LDS latency every 8 MFMAs otherwise); bfq = the next step's values
-        float bfq[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bfq[n] = xs[lhi * P + (wn * NT + n) * 32 + l31];
 #pragma unroll
         for (int it = 0; it < 3 * KC / 8; ++it) {  // (tap, kg) flattened: 8 consecutive k per iteration
             const int kg = cb * (3 * KC / 8) + it;
@@ -342,25 +311,15 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                const int krow = it * 8 + j * 2 + lhi;  // row inside the chunk (tap*KC + cc)
                 float bf[NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bf[n] = bfq[n];
-                const int kq = it * 4 + j + 1;              // next k-step of this chunk (the last one re-reads itself)
-                const int krow = (kq < 3 * KC / 2 ? kq : kq - 1) * 2 + lhi;
-#ifndef DWS_WN_NO_BPREFETCH
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bfq[n] = xs[krow * P + (wn * NT + n) * 32 + l31];
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                for (int n = 0; n < NT; ++n) bf[n] = xs[krow * P + (wn * NT + n) * 32 + l31];
 #pragma unroll
                 for (int m = 0; m < 2 * MP; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j], bf[n], acc[m][n], 0, 0, 0);
-#ifdef DWS_WN_NO_BPREFETCH
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bfq[n] = xs[krow * P + (wn * NT + n) * 32 + l31];
-#endif
             }
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) a_cur[m] = a_nxt[m];
@@ -450,9 +409,6 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
     f32x4 c_cur[MR + MS], c_nxt[MR + MS];
 #pragma unroll
     for (int m = 0; m < MR + MS; ++m) c_cur[m] = buf_load_f4(rA2, lane16, (mt2[m] * NKG2) * 1024);
-    float gq[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) gq[n] = gt[lhi * P + (wn * NT + n) * 32 + l31];
 #pragma unroll 2
     for (int kg = 0; kg < NKG2; ++kg) {
         const int kgn = (kg + 1 < NKG2) ? kg + 1 : kg;
@@ -461,25 +417,15 @@ __global__ __launch_bounds__(256, OCC) void wn_layer_mfma_kernel(WnLayerArgs a) 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const int krow = kg * 8 + j * 2 + lhi;
             float bf[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = gq[n];
-            const int kq = kg * 4 + j + 1;                  // next k-step (the last one re-reads itself)
-            const int krow = (kq < C / 2 ? kq : kq - 1) * 2 + lhi;
-#ifndef DWS_WN_NO_BPREFETCH
-#pragma unroll
-            for (int n = 0; n < NT; ++n) gq[n] = gt[krow * P + (wn * NT + n) * 32 + l31];
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            for (int n = 0; n < NT; ++n) bf[n] = gt[krow * P + (wn * NT + n) * 32 + l31];
 #pragma unroll
             for (int m = 0; m < MR + MS; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][j], bf[n], acc2[m][n], 0, 0, 0);
-#ifdef DWS_WN_NO_BPREFETCH
-#pragma unroll
-            for (int n = 0; n < NT; ++n) gq[n] = gt[krow * P + (wn * NT + n) * 32 + l31];
-#endif
         }
 #pragma unroll
         for (int m = 0; m < MR + MS; ++m) c_cur[m] = c_nxt[m];
@@ -594,21 +540,10 @@ template <int C, int S>
 static int launch_layer_t(const WnLayerArgs& a, hipStream_t s) {
     // (Start skews were measured and dropped: delaying the round-0 workgroups per CU, or the second workgroup of each
     // CU by up to half a tile time so the pair runs in anti-phase, left the step at 72.0-72.1 ms or made it slower.)
+    // (Also measured and dropped in round 2, same box each: a 32-position tile with three or four workgroups per CU --
+    // 71.3-71.9 ms on one box, 72.9-73.1 on another, against 71.5-72.1 for this shape; and B fragments read one k-step
+    // ahead of their MFMAs instead of directly in front of them -- 71.62 against 71.46 ms.)
     ProfileScope ps("wn_layer_mfma", s);
-    static const int p32 = getenv("DWS_WN_P32") ? atoi(getenv("DWS_WN_P32")) : 0;
-    if constexpr (C / 32 >= 4) if (p32) {   // 32-position tiles, p32 = 3 or 4 workgroups per CU (experiment)
-        const int ntl = ceil_div(a.L, 32);
-        const dim3 grid(a.B * ntl);
-        const bool extra = a.melc || a.hsave;
-        if (p32 == 3) {
-            if (extra) hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, true, 32, 3>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, false, 32, 3>), grid, dim3(256), 0, s, a);
-        } else {
-            if (extra) hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, true, 32, 4>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, false, 32, 4>), grid, dim3(256), 0, s, a);
-        }
-        return DWS_OK;
-    }
     const int ntl = ceil_div(a.L, WnTile<C, S>::P);
     if (a.melc || a.hsave) hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, true>), dim3(a.B * ntl), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wn_layer_mfma_kernel<C, S, false>), dim3(a.B * ntl), dim3(256), 0, s, a);
