@@ -56,11 +56,6 @@ __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* _
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int m = 0; m < MT; ++m) buf[d][m] = A[((size_t)mt[m] * nkg_total + kg0 + d) * 64 + lane];
-#ifdef DWS_TAIL_NO_BPREFETCH
-#define DWS_TAIL_BFENCE ((void)0)
-#else
-#define DWS_TAIL_BFENCE __builtin_amdgcn_sched_barrier(0)
-#endif
 #define DWS_TAIL_GROUP4                                                                                               \
     _Pragma("unroll") for (int d = 0; d < D; ++d) {                                                                  \
         float4 cur[MT];                                                                                              \
@@ -70,21 +65,16 @@ __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* _
             buf[d][m] = A[((size_t)mt[m] * nkg_total + kg0 + kn) * 64 + lane];                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+            const int krow = (kg + d) * 8 + j * 2 + lhi;                                                             \
             float bf[NT];                                                                                            \
-            _Pragma("unroll") for (int n = 0; n < NT; ++n) bf[n] = bfq[n];                                           \
-            const int kq = min((kg + d) * 4 + j + 1, nkg * 4 - 1);   /* next k-step (the last re-reads itself) */   \
-            _Pragma("unroll") for (int n = 0; n < NT; ++n) bfq[n] = bt[(kq * 2 + lhi) * P + (wn * NT + n) * 32 + l31]; \
-            DWS_TAIL_BFENCE;                                                                                         \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) bf[n] = bt[krow * P + (wn * NT + n) * 32 + l31];          \
             _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                           \
                 _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                       \
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(cur[m], j), bf[n], acc[m][n], 0, 0, 0);  \
         }                                                                                                            \
     }
-    // B fragments are read one k-step ahead of the MFMAs that use them (left to hipcc each ds_read sits directly in front
-    // of its first use and the wave waits out the LDS latency every MT*NT MFMAs)
-    float bfq[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) bfq[n] = bt[lhi * P + (wn * NT + n) * 32 + l31];
+    // (Reading the B fragments one k-step ahead of their MFMAs instead of directly in front of them changed nothing:
+    // C3 6.30 vs 6.33 ms, C4 5.35 vs 5.32 ms per step on the same box -- the partner waves already cover that latency.)
     if constexpr (KGU) {
         for (int kg = 0; kg < nkg; kg += D) { DWS_TAIL_GROUP4 }
     } else {
@@ -92,7 +82,6 @@ __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* _
         for (int kg = 0; kg < nkg; kg += D) { DWS_TAIL_GROUP4 }
     }
 #undef DWS_TAIL_GROUP4
-#undef DWS_TAIL_BFENCE
 }
 
 // TransposedLN statistics of an [H][P] tile in LDS, down each column (population std, no eps; `sashimi.py:17-20`):

@@ -109,10 +109,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int cb = 0; cb < ncb; ++cb) {
         if (cb + 1 < ncb) stage_dma(cb + 1, (cb + 1) & 1);
         const float* xs = lds + (cb & 1) * (ROWS * P);
-        // B fragments are read one k-step ahead of the MFMAs that use them (see wn_layer_mfma_kernel)
-        float bfq[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bfq[n] = xs[lhi * P + n * 32 + l31];
 #pragma unroll
         for (int it = 0; it < ROWS / 8; ++it) {
             const int kg = cb * (ROWS / 8) + it;
@@ -122,25 +118,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                const int krow = it * 8 + j * 2 + lhi;
                 float bf[NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bf[n] = bfq[n];
-                const int kq = it * 4 + j + 1;                  // next k-step of the chunk (the last re-reads itself)
-                const int krow = (kq < ROWS / 2 ? kq : kq - 1) * 2 + lhi;
-#ifndef DWS_TC_NO_BPREFETCH
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bfq[n] = xs[krow * P + n * 32 + l31];
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                for (int n = 0; n < NT; ++n) bf[n] = xs[krow * P + n * 32 + l31];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j], bf[n], acc[m][n], 0, 0, 0);
-#ifdef DWS_TC_NO_BPREFETCH
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bfq[n] = xs[krow * P + n * 32 + l31];
-#endif
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
@@ -550,7 +536,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
 #pragma unroll 8
             for (int p = 0; p < PC; ++p) bsum += sdy[tid * LD + p];
         }
-#ifdef DWS_WG_NO_PREFETCH
+        // (Operands fetched one group of two k-steps ahead of their MFMAs, and the B fragments of the tapconv loop one
+        // k-step ahead: 160-162 ms per config-5 step either way on the same box.  Not kept.)
 #pragma unroll 8
         for (int ks = 0; ks < PC / 2; ++ks) {
             const int pp = ks * 2 + lhi;
@@ -559,28 +546,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
         }
-#else
-        // operands of two k-steps per group (one ds_read2_b32 each), fetched ONE GROUP AHEAD of the four MFMAs that use
-        // them: left to hipcc the reads sit directly in front of their MFMAs and the wave waits out the LDS latency
-        // every 256 MFMA cycles
-        const float* pb = sx + (wc * 32 + l31) * LD + lhi;
-        const float* pa0 = sdy + (wo * 64 + l31) * LD + lhi;
-        const float* pa1 = pa0 + 32 * LD;
-        float bq[2] = {pb[0], pb[2]}, a0q[2] = {pa0[0], pa0[2]}, a1q[2] = {pa1[0], pa1[2]};
-#pragma unroll 4
-        for (int g = 0; g < PC / 4; ++g) {
-            const float b0 = bq[0], b1 = bq[1], x00 = a0q[0], x01 = a0q[1], x10 = a1q[0], x11 = a1q[1];
-            const int gn = (g + 1 < PC / 4 ? g + 1 : g) * 4;   // the last group re-reads itself
-            bq[0] = pb[gn]; bq[1] = pb[gn + 2];
-            a0q[0] = pa0[gn]; a0q[1] = pa0[gn + 2];
-            a1q[0] = pa1[gn]; a1q[1] = pa1[gn + 2];
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x00, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x10, b0, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x01, b1, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x11, b1, acc[1], 0, 0, 0);
-        }
-#endif
         __syncthreads();   // chunk ch+1 has landed (the barrier waits for the DMA) and buffer `buf` is free again
     }
     float* part = a.partial + (size_t)split * a.O * a.C;
