@@ -189,20 +189,8 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     const int tid = threadIdx.x;
     const int L = a.L, Lc = L / 2;  // L even
     constexpr int NG = (1 << LOG2M) / 16 / THREADS;
-#ifdef DWS_FC_SETPRIO
-    // stagger the waves of a SIMD: with equal priority they share the VALU round-robin, finish a pass's butterflies
-    // together and then queue on the LDS for their writes; with distinct priorities the first one is writing while the
-    // others still compute
-    {
-        const int w = threadIdx.x >> 6;
-        switch ((w >> 2) & 3) {
-            case 0: __builtin_amdgcn_s_setprio(3); break;
-            case 1: __builtin_amdgcn_s_setprio(2); break;
-            case 2: __builtin_amdgcn_s_setprio(1); break;
-            default: __builtin_amdgcn_s_setprio(0); break;
-        }
-    }
-#endif
+    // (Distinct s_setprio per wave of a SIMD, so that one wave is writing its pass back while the others still compute:
+    // 86.6 vs 86.4 us, no effect.)
     FftTw<LOG2M, NG> W;
     W.load(a.tw, tid);
     const float scale = 1.f / (float)M, csign = a.conj_k ? -1.f : 1.f;
