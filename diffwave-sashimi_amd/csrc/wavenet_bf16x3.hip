@@ -6,11 +6,13 @@
 // at 16/3 = 5.3x the matrix rate of the exact-f32 MFMA.  Opt-in: precision = "bf16x3".
 //
 // Same structure as wn_layer_mfma_kernel (wavenet_kernels.hip) -- LDS-DMA staging of the raw x
-// window with hardware zero padding, the step embedding as extra K rows, gate in registers,
-// [res; skip] GEMM from the LDS gate tile -- but with a 128-position tile and 8 waves so every A
-// fragment (streamed from L2) feeds 4 position tiles.  After each chunk's DMA lands, ONE cooperative
-// pass splits the fp32 window into (hi, lo) bf16 and stores it in MFMA B-fragment order
-// ([k-octet][position] 16-byte items), so a B fragment is a single conflict-free ds_read_b128.
+// window (16-channel chunks: a k-block of 16 is one tap), the step embedding AND the conv bias as extra K rows,
+// gate in registers, [res; skip] GEMMs from the LDS gate tile -- but with a 128-position tile and 8 waves so every A
+// fragment (streamed from L2) feeds 4 position tiles.  The fp32 window is split into (hi, lo) bf16 one chunk AHEAD of
+// the MFMAs, a 4-channel half item per thread and k-block, and stored in MFMA B-fragment order ([k-octet][position]
+// 16-byte items), so a B fragment is a single conflict-free ds_read_b128.  Epilogue: the running skip tile is
+// requested before the gate stage, the skip rows are multiplied and stored first (transposed piecewise through the LDS
+// beside the gate tile), the res rows last; all tile streams carry the nontemporal hint.
 #include <cstdlib>
 
 #include "wavenet.h"
@@ -39,15 +41,6 @@ __device__ __forceinline__ bf16x8 buf_load_bf8(__amdgpu_buffer_rsrc_t r, int vof
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)x[i];
-        hi[i] = h;
-        lo[i] = (__bf16)(x[i] - (float)h);
-    }
-}
-
 // tanh(t) * sigmoid(s) with a single quotient (same as wavenet_kernels.hip fast_gate)
 __device__ __forceinline__ float fast_gate3(float t, float s) {
     const float tc = __builtin_amdgcn_fmed3f(t, -30.f, 30.f);
@@ -55,8 +48,6 @@ __device__ __forceinline__ float fast_gate3(float t, float s) {
     const float en = __builtin_amdgcn_exp2f(s * -1.4426950408889634f);      // e^{-s}
     return (e2 - 1.f) * __builtin_amdgcn_rcpf((e2 + 1.f) * (1.f + en));
 }
-__device__ __forceinline__ float fast_sigmoid3(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh3(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 template <int C, int S, int P_, int WAVES_>
 struct Bx3Tile {
