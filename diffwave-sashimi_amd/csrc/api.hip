@@ -15,8 +15,10 @@ dws_model::~dws_model() {
     if (smp_ev_in) hipEventDestroy(smp_ev_in);
     if (smp_ev_out) hipEventDestroy(smp_ev_out);
     if (smp_stream) hipStreamDestroy(smp_stream);
-    if (copy_consumed) hipEventDestroy(copy_consumed);
-    if (copy_pinned) hipHostFree(copy_pinned);
+    for (int i = 0; i < COPY_SLOTS; ++i) {
+        if (copy_consumed[i]) (void)hipEventDestroy(copy_consumed[i]);
+        if (copy_pinned[i]) (void)hipHostFree(copy_pinned[i]);
+    }
     for (auto* p : params) delete p;
 }
 
@@ -251,20 +253,22 @@ int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, f
 }
 
 // One kernel for a list of device-to-device copies.  The job table travels through a pinned staging buffer so nothing
-// blocks the host; an event guards the buffer's reuse.
+// blocks the host; an event per staging slot guards its reuse.  The device-side table is written and read in stream order.
 static int multi_copy(dws_model* m, std::vector<dws::CopyJob>& jobs, hipStream_t stream) {
-    if (!m->copy_consumed) DWS_HIP(hipEventCreateWithFlags(&m->copy_consumed, hipEventDisableTiming));
-    else DWS_HIP(hipEventSynchronize(m->copy_consumed));
-    if (m->copy_pinned_cap < jobs.size()) {
-        if (m->copy_pinned) hipHostFree(m->copy_pinned);
-        m->copy_pinned_cap = jobs.size() * 2;
-        DWS_HIP(hipHostMalloc(&m->copy_pinned, m->copy_pinned_cap * sizeof(dws::CopyJob), hipHostMallocDefault));
+    const int slot = m->copy_slot;
+    m->copy_slot = (slot + 1) % dws_model::COPY_SLOTS;
+    if (!m->copy_consumed[slot]) DWS_HIP(hipEventCreateWithFlags(&m->copy_consumed[slot], hipEventDisableTiming));
+    else DWS_HIP(hipEventSynchronize(m->copy_consumed[slot]));
+    if (m->copy_pinned_cap[slot] < jobs.size()) {
+        if (m->copy_pinned[slot]) (void)hipHostFree(m->copy_pinned[slot]);
+        m->copy_pinned_cap[slot] = jobs.size() * 2;
+        DWS_HIP(hipHostMalloc(&m->copy_pinned[slot], m->copy_pinned_cap[slot] * sizeof(dws::CopyJob), hipHostMallocDefault));
     }
-    std::memcpy(m->copy_pinned, jobs.data(), jobs.size() * sizeof(dws::CopyJob));
+    std::memcpy(m->copy_pinned[slot], jobs.data(), jobs.size() * sizeof(dws::CopyJob));
     dws::DevBuf& table = m->copy_table;
-    DWS_TRY(table.ensure(m->copy_pinned_cap * sizeof(dws::CopyJob)));
-    DWS_HIP(hipMemcpyAsync(table.p, m->copy_pinned, jobs.size() * sizeof(dws::CopyJob), hipMemcpyHostToDevice, stream));
-    DWS_HIP(hipEventRecord(m->copy_consumed, stream));
+    DWS_TRY(table.ensure(jobs.size() * 2 * sizeof(dws::CopyJob)));
+    DWS_HIP(hipMemcpyAsync(table.p, m->copy_pinned[slot], jobs.size() * sizeof(dws::CopyJob), hipMemcpyHostToDevice, stream));
+    DWS_HIP(hipEventRecord(m->copy_consumed[slot], stream));
     const int parts = 8;
     hipLaunchKernelGGL(dws::multi_copy_kernel, dim3((unsigned)jobs.size(), parts), dim3(256), 0, stream,
                        (const dws::CopyJob*)table.p, parts);

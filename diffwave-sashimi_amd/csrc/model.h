@@ -60,10 +60,15 @@ struct dws_model {
 
     dws::DevBuf lin_scratch;  // split-O partials of the embedding adjoint
     // batched parameter / gradient copies (api.hip): device job table, pinned staging, reuse guard
+    // multi_copy staging: the job table of a call travels through one of COPY_SLOTS pinned buffers (round robin; an
+    // event per slot guards its reuse, so the host only ever waits for the call made COPY_SLOTS calls ago and can run
+    // a training step ahead of the GPU)
+    static constexpr int COPY_SLOTS = 4;
     dws::DevBuf copy_table;
-    void* copy_pinned = nullptr;
-    size_t copy_pinned_cap = 0;
-    hipEvent_t copy_consumed = nullptr;
+    void* copy_pinned[COPY_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    size_t copy_pinned_cap[COPY_SLOTS] = {0, 0, 0, 0};
+    hipEvent_t copy_consumed[COPY_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int copy_slot = 0;
 
     // sampler state (sampler.hip)
     dws::DevBuf smp_tables;   // [3][T] c1, c2, sigma

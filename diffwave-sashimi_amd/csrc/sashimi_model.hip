@@ -111,6 +111,7 @@ struct SashimiModel : dws_model {
     FftPlans fft;
     std::map<int, FftTables*> tables;  // by log2(M)
     DevBuf Wi, Wt_all, bt_all, Wf, Af, freq;
+    bool freq_ready = false;
     DevBuf x_init, emb, h1, h2, part_t, nfin, scratch_out;
     // commit scratch
     DevBuf cv, cwdt, cdt, cr, ckf, ck, cK, cKf;
@@ -419,7 +420,8 @@ struct SashimiModel : dws_model {
             DWS_TRY(Af.ensure((size_t)D * D * 4));
             DWS_TRY(launch_pack_a_frag(Wf.f(), Af.f(), D, D, s));
         }
-        {
+        if (!freq_ready) {   // depends on the embedding width only: uploaded (and waited for) once, not on every commit --
+                             // a training step commits once, and a blocking wait there keeps the host from running ahead of the GPU
             const int half = Ein / 2;
             std::vector<float> f(half);
             const float e = (float)(-(std::log(10000.0) / (half - 1)));
@@ -427,6 +429,7 @@ struct SashimiModel : dws_model {
             DWS_TRY(freq.ensure((size_t)half * 4));
             DWS_HIP(hipMemcpyAsync(freq.p, f.data(), (size_t)half * 4, hipMemcpyHostToDevice, s));
             DWS_HIP(hipStreamSynchronize(s));
+            freq_ready = true;
         }
         dirty = false;
         ++commit_version;

@@ -24,6 +24,7 @@ struct WaveNetModel : dws_model {
     DevBuf b1_all;                   // stacked dilated-conv biases [NL][2C] (bf16x3: folded into the correction rows)
     DevBuf Wf, Af;                   // final_conv[0]
     DevBuf freq;                     // embedding frequencies [Ein/2]
+    bool freq_ready = false;
     DevBuf tmp_pack;                 // scratch for permute -> pack
     // conditioner
     std::vector<DevBuf> melW0, melW1, melWc;  // folded upsampler kernels + mel_conv weight per layer
@@ -167,14 +168,16 @@ struct WaveNetModel : dws_model {
             DWS_TRY(launch_pack_a_frag(Wf.f(), Af.f(), S, S, s));
         }
         // embedding frequencies: exp(float(i) * float(-ln(1e4)/(half-1)))  (`models/utils.py:22-23`)
-        {
+        if (!freq_ready) {   // depends on the embedding width only: uploaded (and waited for) once, not on every commit --
+                             // a training step commits once, and a blocking wait there keeps the host from running ahead of the GPU
             const int half = Ein / 2;
             std::vector<float> f(half);
             const float e = (float)(-(std::log(10000.0) / (half - 1)));
             for (int i = 0; i < half; ++i) f[i] = (float)std::exp((double)((float)i * e));
             DWS_TRY(freq.ensure((size_t)half * 4));
             DWS_HIP(hipMemcpyAsync(freq.p, f.data(), (size_t)half * 4, hipMemcpyHostToDevice, s));
-            DWS_HIP(hipStreamSynchronize(s));  // f goes out of scope
+            DWS_HIP(hipStreamSynchronize(s));
+            freq_ready = true;  // f goes out of scope
         }
         if (Abt.p) DWS_HIP(hipMemsetAsync(Abt.p, 0, Abt.bytes, s));  // correction layout depends on the precision
         dirty = false;
