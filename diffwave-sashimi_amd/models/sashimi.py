@@ -137,6 +137,7 @@ class Sashimi(EngineModule):
         self.final_conv = nn.ModuleList([ConvParams(d_model, d_model, 1), nn.Identity(),
                                          ZeroConvParams(d_model, out_channels)])
         self._nodes = {}
+        self._L_host = {}     # id(kernel) -> ((data_ptr, version) of its L buffer, value): see _kernel_L
 
     def _blocks(self):
         for ml in (self.d_layers, self.c_layers, self.u_layers):
@@ -161,6 +162,16 @@ class Sashimi(EngineModule):
         d.expand, d.ff, d.unet, d.L = self.expand, self.ff, 1 if self.unet else 0, self.L
         return d
 
+    def _kernel_L(self, k):
+        """Host copy of a kernel's ``L`` buffer, re-read only when the buffer changed (in place, or replaced by
+        ``.to()`` / ``load_state_dict``).  ``int(k.L)`` on a GPU buffer is a device-to-host copy that waits for everything
+        queued before it; twice per block on every call it kept the host from ever running ahead of the GPU."""
+        key = (k.L.data_ptr(), k.L._version, str(k.L.device))
+        hit = self._L_host.get(id(k))
+        if hit is None or hit[0] != key:
+            hit = self._L_host[id(k)] = (key, int(k.L))
+        return hit[1]
+
     @torch.no_grad()
     def _setup_C(self):
         """First-forward mutation of the reference (``s4.py:531-551,686-687``): a kernel
@@ -170,7 +181,7 @@ class Sashimi(EngineModule):
         ``min(L_in, l_max)`` taps (``s4.py:1387``), so the length-doubling branch is unreachable."""
         for blk in self._blocks():
             k = blk.layer.kernel.kernel
-            if int(k.L) == 0:
+            if self._kernel_L(k) == 0:
                 Ct = s4_init.setup_C(k.C, k.P, k.inv_w_real, k.w_imag, k.log_dt, blk.L_stage)
                 k.C.copy_(Ct.to(k.C.device))
                 k.L.fill_(blk.L_stage)
@@ -184,7 +195,7 @@ class Sashimi(EngineModule):
             raise RuntimeError(f"sashimi: input length {L_in} is not divisible by the pooling factors {self.pool}")
         self._setup_C()
         items = list(self.state_dict(keep_vars=True).items())
-        for Lk in sorted({int(blk.layer.kernel.kernel.L) for blk in self._blocks()}):
+        for Lk in sorted({self._kernel_L(blk.layer.kernel.kernel) for blk in self._blocks()}):
             if Lk not in self._nodes:
                 omega, z = s4_init.omega_z(Lk)
                 self._nodes[Lk] = (torch.view_as_real(omega).contiguous(), torch.view_as_real(z).contiguous())
