@@ -206,15 +206,6 @@ int dws_model_get_grad(dws_model* m, const char* name, float* dst, int64_t numel
     return DWS_OK;
 }
 
-namespace dws {
-struct CopyJob { const float* src; float* dst; int64_t n; };
-// one launch for all parameter gradients: block (j, part) copies a slice of tensor j
-__global__ void multi_copy_kernel(const CopyJob* __restrict__ jobs, int parts) {
-    const CopyJob j = jobs[blockIdx.x];
-    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < j.n; i += (int64_t)parts * blockDim.x) j.dst[i] = j.src[i];
-}
-}  // namespace dws
-
 static int multi_copy(dws_model* m, std::vector<dws::CopyJob>& jobs, hipStream_t stream);
 
 int dws_model_update_params(dws_model* m, int32_t count, const char* const* names, const float* const* srcs, void* stream) {
@@ -269,11 +260,7 @@ static int multi_copy(dws_model* m, std::vector<dws::CopyJob>& jobs, hipStream_t
     DWS_TRY(table.ensure(jobs.size() * 2 * sizeof(dws::CopyJob)));
     DWS_HIP(hipMemcpyAsync(table.p, m->copy_pinned[slot], jobs.size() * sizeof(dws::CopyJob), hipMemcpyHostToDevice, stream));
     DWS_HIP(hipEventRecord(m->copy_consumed[slot], stream));
-    const int parts = 8;
-    hipLaunchKernelGGL(dws::multi_copy_kernel, dim3((unsigned)jobs.size(), parts), dim3(256), 0, stream,
-                       (const dws::CopyJob*)table.p, parts);
-    DWS_HIP(hipGetLastError());
-    return DWS_OK;
+    return dws::launch_multi_copy((const dws::CopyJob*)table.p, (int)jobs.size(), stream);
 }
 
 int dws_model_read_tap(dws_model* m, const char* tap, float* dst, int64_t capacity, void* stream) {

@@ -1,5 +1,6 @@
 // Error plumbing, ABI identification and the per-kernel event profiler of libdws.so.
 #include "dws_common.h"
+#include "model.h"
 
 #include <mutex>
 
@@ -38,6 +39,20 @@ ProfileScope::~ProfileScope() {
     hipEventRecord(e1, stream);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_events.emplace_back(e0, e1);
+}
+
+// One launch for a table of device-to-device copies (model.h CopyBatch, dws_model_get_grads / update_params): block
+// (j, part) copies a slice of job j.
+__global__ void multi_copy_kernel(const CopyJob* __restrict__ jobs, int parts) {
+    const CopyJob j = jobs[blockIdx.x];
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < j.n; i += (int64_t)parts * blockDim.x) j.dst[i] = j.src[i];
+}
+
+int launch_multi_copy(const CopyJob* table_dev, int njobs, hipStream_t s) {
+    const int parts = 8;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)njobs, parts), dim3(256), 0, s, table_dev, parts);
+    DWS_HIP(hipGetLastError());
+    return DWS_OK;
 }
 
 }  // namespace dws

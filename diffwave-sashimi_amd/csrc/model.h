@@ -1,5 +1,7 @@
 // dws_model: base of the two backbones behind the C ABI (include/dws.h).
 #pragma once
+#include <cstring>
+
 #include "dws_common.h"
 
 namespace dws {
@@ -32,6 +34,31 @@ struct DevBuf {
         return DWS_OK;
     }
     float* f() const { return static_cast<float*>(p); }
+};
+
+struct CopyJob { const float* src; float* dst; int64_t n; };
+int launch_multi_copy(const CopyJob* table_dev, int njobs, hipStream_t s);   // api.hip: one kernel for a job table
+
+// A fixed list of device-to-device copies run as ONE launch (the per-layer fc_t / bias tensors into their stacked
+// buffers and the stacked gradients back out: 4-5 hipMemcpyAsync per layer and step otherwise).  The job table is
+// uploaded only when it differs from the one already on the device (buffers are allocated once, so: the first time).
+struct CopyBatch {
+    std::vector<CopyJob> jobs, uploaded;
+    DevBuf table;
+    void begin() { jobs.clear(); }
+    void add(const float* src, float* dst, size_t n) { jobs.push_back({src, dst, (int64_t)n}); }
+    int run(hipStream_t s) {
+        if (jobs.empty()) return DWS_OK;
+        const bool same = jobs.size() == uploaded.size() &&
+                          std::memcmp(jobs.data(), uploaded.data(), jobs.size() * sizeof(CopyJob)) == 0;
+        if (!same) {
+            DWS_HIP(hipStreamSynchronize(s));   // nothing in flight may still read the old table / host copy
+            uploaded = jobs;
+            DWS_TRY(table.ensure(uploaded.size() * sizeof(CopyJob)));
+            DWS_HIP(hipMemcpy(table.p, uploaded.data(), uploaded.size() * sizeof(CopyJob), hipMemcpyHostToDevice));
+        }
+        return launch_multi_copy((const CopyJob*)table.p, (int)jobs.size(), s);
+    }
 };
 
 struct ParamSpec {

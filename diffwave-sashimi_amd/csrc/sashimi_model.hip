@@ -111,6 +111,7 @@ struct SashimiModel : dws_model {
     FftPlans fft;
     std::map<int, FftTables*> tables;  // by log2(M)
     DevBuf Wi, Wt_all, bt_all, Wf, Af, freq;
+    CopyBatch stack_fc_t, unstack_fc_t;   // per-layer fc_t tensors <-> their stacked buffers, one launch each
     bool freq_ready = false;
     DevBuf x_init, emb, h1, h2, part_t, nfin, scratch_out;
     // commit scratch
@@ -366,13 +367,12 @@ struct SashimiModel : dws_model {
         DWS_TRY(fold("init_conv.0.conv", Wi.f(), D, Cin, s));
         DWS_TRY(Wt_all.ensure((size_t)pt_total * Eout * 4));
         DWS_TRY(bt_all.ensure((size_t)pt_total * 4));
+        stack_fc_t.begin();
         for (auto* l : all) {
             if (l->kind == L_BLOCK) {
                 const int H = l->H;
-                DWS_HIP(hipMemcpyAsync(Wt_all.f() + (size_t)l->pt_off * Eout, P(l->prefix + ".fc_t.weight"),
-                                       (size_t)H * Eout * 4, hipMemcpyDeviceToDevice, s));
-                DWS_HIP(hipMemcpyAsync(bt_all.f() + l->pt_off, P(l->prefix + ".fc_t.bias"), (size_t)H * 4,
-                                       hipMemcpyDeviceToDevice, s));
+                stack_fc_t.add(P(l->prefix + ".fc_t.weight"), Wt_all.f() + (size_t)l->pt_off * Eout, (size_t)H * Eout);
+                stack_fc_t.add(P(l->prefix + ".fc_t.bias"), bt_all.f() + l->pt_off, (size_t)H);
                 DWS_TRY(l->W1.ensure((size_t)FF * H * H * 4));
                 DWS_TRY(l->W2.ensure((size_t)FF * H * H * 4));
                 DWS_TRY(fold(l->prefix + ".ff.ff.0.conv", l->W1.f(), FF * H, H, s));
@@ -420,6 +420,7 @@ struct SashimiModel : dws_model {
             DWS_TRY(Af.ensure((size_t)D * D * 4));
             DWS_TRY(launch_pack_a_frag(Wf.f(), Af.f(), D, D, s));
         }
+        DWS_TRY(stack_fc_t.run(s));
         if (!freq_ready) {   // depends on the embedding width only: uploaded (and waited for) once, not on every commit --
                              // a training step commits once, and a blocking wait there keeps the host from running ahead of the GPU
             const int half = Ein / 2;
@@ -1135,13 +1136,13 @@ struct SashimiModel : dws_model {
 
         // ---- step embedding: per-block fc_t (stacked), then the shared swish MLP
         DWS_TRY(launch_lin_bwd_w(dpt.f(), h2.f(), dWt_all.f(), dbt_all.f(), nB, Eout, pt_total, s));
+        unstack_fc_t.begin();
         for (auto* l : all) {
             if (l->kind != L_BLOCK) continue;
-            DWS_HIP(hipMemcpyAsync(G(l->prefix + ".fc_t.weight"), dWt_all.f() + (size_t)l->pt_off * Eout,
-                                   (size_t)l->H * Eout * 4, hipMemcpyDeviceToDevice, s));
-            DWS_HIP(hipMemcpyAsync(G(l->prefix + ".fc_t.bias"), dbt_all.f() + l->pt_off, (size_t)l->H * 4,
-                                   hipMemcpyDeviceToDevice, s));
+            unstack_fc_t.add(dWt_all.f() + (size_t)l->pt_off * Eout, G(l->prefix + ".fc_t.weight"), (size_t)l->H * Eout);
+            unstack_fc_t.add(dbt_all.f() + l->pt_off, G(l->prefix + ".fc_t.bias"), (size_t)l->H);
         }
+        DWS_TRY(unstack_fc_t.run(s));
         DWS_TRY(launch_lin_bwd_x(dpt.f(), Wt_all.f(), ta2.f(), dh2.f(), nB, Eout, pt_total, lin_scratch, s));
         DWS_TRY(launch_lin_bwd_w(dh2.f(), h1.f(), G("fc_t2.weight"), G("fc_t2.bias"), nB, Emid, Eout, s));
         DWS_TRY(launch_lin_bwd_x(dh2.f(), P("fc_t2.weight"), ta1.f(), dh1.f(), nB, Emid, Eout, lin_scratch, s));

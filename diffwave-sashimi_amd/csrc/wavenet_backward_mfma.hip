@@ -569,8 +569,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
 // four keeps 16 independent loads in flight per thread: the first version (one dependent load chain per thread)
 // ran at 0.75 TB/s.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
-                                                           size_t n, int nsplit, float scale) {
-    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+                                                           size_t n, int nsplit, float scale,
+                                                           const float* __restrict__ partial2, float* __restrict__ dW2,
+                                                           size_t n2, float scale2, int blocks1) {
+    // blocks [0, blocks1): the weight partials; blocks [blocks1, ...): the bias partials of the same GEMM (one launch)
+    int blk = blockIdx.x;
+    if (blk >= blocks1) {
+        blk -= blocks1;
+        partial = partial2; dW = dW2; n = n2; scale = scale2;
+    }
+    const size_t i4 = ((size_t)blk * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
     if (i4 + 4 <= n && (n & 3) == 0) {
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
@@ -637,10 +645,9 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
         hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, s, a);
     }
     const size_t n = (size_t)a.O * a.C * T;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, s, a.partial, dW, n, a.nsplit, scale);
-    if (a.bias_part)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(a.O, 1024)), dim3(256), 0, s, a.bias_part, a.dbias,
-                           (size_t)a.O, a.nsplit, a.bias_scale);
+    const int blocks1 = (int)ceil_div(n, 1024), blocks2 = a.bias_part ? (int)ceil_div(a.O, 1024) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks1 + blocks2), dim3(256), 0, s, a.partial, dW, n, a.nsplit, scale,
+                       (const float*)a.bias_part, a.dbias, (size_t)a.O, a.bias_scale, blocks1);
     return DWS_OK;
 }
 

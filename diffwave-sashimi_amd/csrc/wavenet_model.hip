@@ -24,6 +24,7 @@ struct WaveNetModel : dws_model {
     DevBuf b1_all;                   // stacked dilated-conv biases [NL][2C] (bf16x3: folded into the correction rows)
     DevBuf Wf, Af;                   // final_conv[0]
     DevBuf freq;                     // embedding frequencies [Ein/2]
+    CopyBatch stack_params, unstack_fc_t;   // per-layer tensors <-> their stacked buffers, one launch each
     bool freq_ready = false;
     DevBuf tmp_pack;                 // scratch for permute -> pack
     // conditioner
@@ -123,21 +124,19 @@ struct WaveNetModel : dws_model {
         DWS_TRY(b1_all.ensure((size_t)NL * 2 * C * 4));
         DWS_TRY(Wd_all.ensure((size_t)NL * 2 * C * C * 3 * 4));
         if (mfma_layer) DWS_TRY(tmp_pack.ensure((size_t)2 * C * 3 * C * 4));
+        stack_params.begin();
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
-            DWS_HIP(hipMemcpyAsync(Wt_all.f() + (size_t)n * C * Eout, P(p + ".fc_t.weight"), (size_t)C * Eout * 4,
-                                   hipMemcpyDeviceToDevice, s));
-            DWS_HIP(hipMemcpyAsync(bt_all.f() + (size_t)n * C, P(p + ".fc_t.bias"), (size_t)C * 4,
-                                   hipMemcpyDeviceToDevice, s));
-            DWS_HIP(hipMemcpyAsync(b1_all.f() + (size_t)n * 2 * C, P(p + ".dilated_conv_layer.conv.bias"), (size_t)2 * C * 4,
-                                   hipMemcpyDeviceToDevice, s));
+            stack_params.add(P(p + ".fc_t.weight"), Wt_all.f() + (size_t)n * C * Eout, (size_t)C * Eout);
+            stack_params.add(P(p + ".fc_t.bias"), bt_all.f() + (size_t)n * C, (size_t)C);
+            stack_params.add(P(p + ".dilated_conv_layer.conv.bias"), b1_all.f() + (size_t)n * 2 * C, (size_t)2 * C);
             DWS_TRY(fold(p + ".dilated_conv_layer.conv", Wd(n), 2 * C, C * 3, s));
             DWS_TRY(Wrs[n].ensure((size_t)(C + S) * C * 4));
             DWS_TRY(fold(p + ".res_conv", Wrs[n].f(), C, C, s));
             DWS_TRY(fold(p + ".skip_conv", Wrs[n].f() + (size_t)C * C, S, C, s));
             DWS_TRY(bias2[n].ensure((size_t)(C + S) * 4));
-            DWS_HIP(hipMemcpyAsync(bias2[n].f(), P(p + ".res_conv.bias"), (size_t)C * 4, hipMemcpyDeviceToDevice, s));
-            DWS_HIP(hipMemcpyAsync(bias2[n].f() + C, P(p + ".skip_conv.bias"), (size_t)S * 4, hipMemcpyDeviceToDevice, s));
+            stack_params.add(P(p + ".res_conv.bias"), bias2[n].f(), (size_t)C);
+            stack_params.add(P(p + ".skip_conv.bias"), bias2[n].f() + C, (size_t)S);
             if (mfma_layer) {
                 DWS_TRY(A1[n].ensure((size_t)2 * C * 3 * C * 4));
                 DWS_TRY(launch_permute_dconv(Wd(n), tmp_pack.f(), C, bf16x3 ? WN_BX3_KC : WN_LAYER_KC, s));
@@ -168,6 +167,7 @@ struct WaveNetModel : dws_model {
             DWS_TRY(launch_pack_a_frag(Wf.f(), Af.f(), S, S, s));
         }
         // embedding frequencies: exp(float(i) * float(-ln(1e4)/(half-1)))  (`models/utils.py:22-23`)
+        DWS_TRY(stack_params.run(s));
         if (!freq_ready) {   // depends on the embedding width only: uploaded (and waited for) once, not on every commit --
                              // a training step commits once, and a blocking wait there keeps the host from running ahead of the GPU
             const int half = Ein / 2;
@@ -466,12 +466,13 @@ struct WaveNetModel : dws_model {
 
         // ---- step embedding: per-layer fc_t (stacked), then the shared swish MLP
         DWS_TRY(launch_lin_bwd_w(dpt.f(), h2.f(), dWt_all.f(), dbt_all.f(), nB, Eout, NL * C, s));
+        unstack_fc_t.begin();
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
-            DWS_HIP(hipMemcpyAsync(G(p + ".fc_t.weight"), dWt_all.f() + (size_t)n * C * Eout, (size_t)C * Eout * 4,
-                                   hipMemcpyDeviceToDevice, s));
-            DWS_HIP(hipMemcpyAsync(G(p + ".fc_t.bias"), dbt_all.f() + (size_t)n * C, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+            unstack_fc_t.add(dWt_all.f() + (size_t)n * C * Eout, G(p + ".fc_t.weight"), (size_t)C * Eout);
+            unstack_fc_t.add(dbt_all.f() + (size_t)n * C, G(p + ".fc_t.bias"), (size_t)C);
         }
+        DWS_TRY(unstack_fc_t.run(s));
         DWS_TRY(launch_lin_bwd_x(dpt.f(), Wt_all.f(), ta2.f(), dh2.f(), nB, Eout, NL * C, lin_scratch, s));   // d(pre-activation 2)
         DWS_TRY(launch_lin_bwd_w(dh2.f(), h1.f(), G("residual_layer.fc_t2.weight"), G("residual_layer.fc_t2.bias"), nB, Emid,
                                  Eout, s));
