@@ -82,6 +82,8 @@ struct SLayer {
     DevBuf t_u, t_a, t_g, t_o, t_x1, t_n2, t_f1, t_ge, t_xr, dbuf;   // t_g = gelu(t_a), t_ge = gelu(t_f1): kept so the
                                                                     // weight gradients need no GELU recompute
     DevBuf tAo, tA1, tA2, tAp, tAoT, tA1T, tA2T, tApT;
+    const float *pAo = nullptr, *pA1 = nullptr, *pA2 = nullptr, *pAp = nullptr;   // forward operands of the training GEMMs: the
+                                                                                 // commit's packs where they exist, else tA*
 };
 
 struct Exec {             // one step of Sashimi.forward: out_node = layer(in_node) (+ add_node)
@@ -749,21 +751,26 @@ struct SashimiModel : dws_model {
     DevBuf rAfT;
     std::vector<DevBuf*> row_major_bufs;   // owned transposes
 
-    // A-fragment pack of W [O][K] and of its transpose (the adjoint GEMM)
-    int pack_pair(const float* W, int O, int K, DevBuf& A, DevBuf& AT, hipStream_t s) {
-        DWS_TRY(tmp_pack.ensure((size_t)O * K * 4));
+    // A-fragment pack of W [O][K] and of its transpose (the adjoint GEMM).  `packed`: the commit's own pack of W when it
+    // made one (same layout) -- reused instead of packing again; *pA receives the operand to hand to gemm().
+    int pack_pair(const float* W, int O, int K, DevBuf& A, DevBuf& AT, const float* packed, const float** pA, hipStream_t s) {
         DWS_TRY(A.ensure((size_t)O * K * 4));
         DWS_TRY(AT.ensure((size_t)O * K * 4));
         if (tapconv_mfma_supported(O, K, 0, 1) && tapconv_mfma_supported(K, O, 0, 1)) {
-            DWS_TRY(launch_pack_a_frag(W, A.f(), O, K, s));
-            DWS_TRY(launch_tapconv_pack_transposed(W, tmp_pack.f(), O, K, 1, O, 0, 1.f, s));
-            DWS_TRY(launch_pack_a_frag(tmp_pack.f(), AT.f(), K, O, s));
+            if (packed) {
+                *pA = packed;
+            } else {
+                DWS_TRY(launch_pack_a_frag(W, A.f(), O, K, s));
+                *pA = A.f();
+            }
+            DWS_TRY(launch_pack_a_frag_t(W, AT.f(), O, K, s));
             return DWS_OK;
         }
         // generic: A / AT only serve as keys; AT's storage holds the row-major transpose itself
         DWS_TRY(launch_tapconv_pack_transposed(W, AT.f(), O, K, 1, O, 0, 1.f, s));
         row_major[A.f()] = RowMajor{W, O, K};
         row_major[AT.f()] = RowMajor{AT.f(), K, O};
+        *pA = A.f();
         return DWS_OK;
     }
 
@@ -772,20 +779,21 @@ struct SashimiModel : dws_model {
         for (auto* l : all) {
             if (l->kind == L_BLOCK) {
                 const int H = l->H;
-                DWS_TRY(pack_pair(P(l->prefix + ".layer.output_linear.0.weight"), 2 * H, H, l->tAo, l->tAoT, s));
-                DWS_TRY(pack_pair(l->W1.f(), FF * H, H, l->tA1, l->tA1T, s));
-                DWS_TRY(pack_pair(l->W2.f(), H, FF * H, l->tA2, l->tA2T, s));
+                const bool cp = l->mfma;   // the commit packed Ao / A1 / A2 for the sampling tail kernel
+                DWS_TRY(pack_pair(P(l->prefix + ".layer.output_linear.0.weight"), 2 * H, H, l->tAo, l->tAoT, cp ? l->Ao.f() : nullptr,
+                                  &l->pAo, s));
+                DWS_TRY(pack_pair(l->W1.f(), FF * H, H, l->tA1, l->tA1T, cp ? l->A1.f() : nullptr, &l->pA1, s));
+                DWS_TRY(pack_pair(l->W2.f(), H, FF * H, l->tA2, l->tA2T, cp ? l->A2.f() : nullptr, &l->pA2, s));
             } else {
                 const int O = (l->kind == L_DOWN) ? l->Hout : l->Hout * l->p;
                 const int K = (l->kind == L_DOWN) ? l->H * l->p : l->H;
-                DWS_TRY(pack_pair(l->Wp.f(), O, K, l->tAp, l->tApT, s));
+                DWS_TRY(pack_pair(l->Wp.f(), O, K, l->tAp, l->tApT, (l->mfma || l->mfma2) ? l->Ap.f() : nullptr, &l->pAp, s));
             }
         }
         DWS_TRY(tmp_pack.ensure((size_t)D * D * 4));
         DWS_TRY(tAfT.ensure((size_t)D * D * 4));
         if (tapconv_mfma_supported(D, D, 0, 1)) {
-            DWS_TRY(launch_tapconv_pack_transposed(Wf.f(), tmp_pack.f(), D, D, 1, D, 0, 1.f, s));
-            DWS_TRY(launch_pack_a_frag(tmp_pack.f(), tAfT.f(), D, D, s));
+            DWS_TRY(launch_pack_a_frag_t(Wf.f(), tAfT.f(), D, D, s));
         } else {
             DWS_TRY(launch_tapconv_pack_transposed(Wf.f(), tAfT.f(), D, D, 1, D, 0, 1.f, s));
             row_major[tAfT.f()] = RowMajor{tAfT.f(), D, D};
@@ -916,25 +924,25 @@ struct SashimiModel : dws_model {
                 fa.B = nB; fa.H = H; fa.L = Ls;
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
                 if (tapconv_glu_supported(2 * H, H, Ls)) {   // o and x1 = x + GLU(o) (+ mel) from one kernel
-                    DWS_TRY(gemm(l->tAo.f(), 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 6, P(p + ".layer.output_linear.0.bias"), x,
+                    DWS_TRY(gemm(l->pAo, 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 6, P(p + ".layer.output_linear.0.bias"), x,
                                  nullptr, melBm ? l->melc.f() : nullptr, l->t_x1.f(), s));
                 } else {
-                    DWS_TRY(gemm(l->tAo.f(), 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"),
+                    DWS_TRY(gemm(l->pAo, 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"),
                                  nullptr, nullptr, nullptr, nullptr, s));
                     DWS_TRY(launch_glu_res(l->t_o.f(), x, melBm ? l->melc.f() : nullptr, l->t_x1.f(), nB, H, Ls, s));
                 }
                 DWS_TRY(launch_ln(l->t_x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, l->t_n2.f(), nB, H, Ls,
                                   (size_t)Ls, s));
-                DWS_TRY(gemm(l->tA1.f(), FF * H, H, l->t_n2.f(), l->t_f1.f(), Ls, 3, P(p + ".ff.ff.0.conv.bias"), nullptr,
+                DWS_TRY(gemm(l->pA1, FF * H, H, l->t_n2.f(), l->t_f1.f(), Ls, 3, P(p + ".ff.ff.0.conv.bias"), nullptr,
                              nullptr, nullptr, l->t_ge.f(), s));
-                DWS_TRY(gemm(l->tA2.f(), H, FF * H, l->t_ge.f(), l->out.f(), Ls, 4, P(p + ".ff.ff.2.conv.bias"), l->t_x1.f(),
+                DWS_TRY(gemm(l->pA2, H, FF * H, l->t_ge.f(), l->out.f(), Ls, 4, P(p + ".ff.ff.2.conv.bias"), l->t_x1.f(),
                              add, nullptr, nullptr, s));
             } else if (l->kind == L_DOWN) {
                 DWS_TRY(launch_pool_rearrange(x, l->t_xr.f(), nullptr, 0, 0, nB, l->H, l->p, l->Lout, s));
-                DWS_TRY(gemm(l->tAp.f(), l->Hout, l->H * l->p, l->t_xr.f(), l->out.f(), l->Lout, 2,
+                DWS_TRY(gemm(l->pAp, l->Hout, l->H * l->p, l->t_xr.f(), l->out.f(), l->Lout, 2,
                              P(l->prefix + ".linear.conv.bias"), nullptr, nullptr, nullptr, nullptr, s));
             } else {
-                DWS_TRY(gemm(l->tAp.f(), l->Hout * l->p, l->H, x, pool_scr.f(), l->L, 2, P(l->prefix + ".linear.conv.bias"),
+                DWS_TRY(gemm(l->pAp, l->Hout * l->p, l->H, x, pool_scr.f(), l->L, 2, P(l->prefix + ".linear.conv.bias"),
                              nullptr, nullptr, nullptr, nullptr, s));
                 DWS_TRY(launch_pool_rearrange(pool_scr.f(), l->out.f(), add, 1, 0, nB, l->Hout, l->p, l->L, s));
             }

@@ -44,6 +44,7 @@ struct WnFinalArgs {
 int launch_fold_weight_norm(const float* v, const float* g, float* out, int O, int inner, hipStream_t s);
 int launch_permute_dconv(const float* w, float* out, int C, int KC, hipStream_t s);
 int launch_pack_a_frag(const float* w, float* out, int M, int K, hipStream_t s);
+int launch_pack_a_frag_t(const float* w, float* out, int O, int K, hipStream_t s);   // fragments of W^T from row-major W[O][K]
 int launch_step_embed(const float* steps, const float* freq, float* emb, int B, int half, hipStream_t s);
 int launch_linear_rows(const float* in, const float* W, const float* bias, float* out, int B, int K, int O,
                        int act, hipStream_t s, float* pre_out = nullptr);

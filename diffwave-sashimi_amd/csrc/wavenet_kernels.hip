@@ -77,6 +77,24 @@ __global__ void pack_a_frag_kernel(const float* __restrict__ w, float* __restric
     out[i] = w[(size_t)row * K + col];
 }
 
+// The same fragment order for the TRANSPOSE of a row-major W[O][K] (the adjoint GEMM's operand W^T [K][O]) straight from
+// W: one launch instead of transpose-to-scratch + pack (and no shared scratch buffer between consecutive weights).
+__global__ void pack_a_frag_t_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int K) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)O * K) return;
+    int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    size_t r = i >> 8;  // mt * (O/8) + kg   (rows of W^T = K, contraction = O)
+    int kg = (int)(r % (O / 8)), mt = (int)(r / (O / 8));
+    int row = mt * 32 + (lane & 31), col = (kg * 4 + j) * 2 + (lane >> 5);
+    out[i] = w[(size_t)col * K + row];
+}
+
+int launch_pack_a_frag_t(const float* w, float* out, int O, int K, hipStream_t s) {
+    size_t n = (size_t)O * K;
+    hipLaunchKernelGGL(pack_a_frag_t_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, out, O, K);
+    return DWS_OK;
+}
+
 int launch_pack_a_frag(const float* w, float* out, int M, int K, hipStream_t s) {
     size_t n = (size_t)M * K;
     hipLaunchKernelGGL(pack_a_frag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, out, M, K);
