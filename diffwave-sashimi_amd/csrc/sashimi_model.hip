@@ -1016,9 +1016,7 @@ struct SashimiModel : dws_model {
 
     int ln_scalars(const std::string& p, int nblk, hipStream_t s) {
         // lnpart holds [2][nblk] = (dm, ds) partials
-        DWS_TRY(launch_sum_leading(lnpart.f(), G(p + ".m"), 1, nblk, 1.f, s));
-        DWS_TRY(launch_sum_leading(lnpart.f() + nblk, G(p + ".s"), 1, nblk, 1.f, s));
-        return DWS_OK;
+        return launch_sum_pair(lnpart.f(), G(p + ".m"), G(p + ".s"), nblk, s);
     }
 
     // Adjoint of forward_train, plan steps in reverse (sashimi.py:143-184,277-313).

@@ -233,6 +233,25 @@ __global__ __launch_bounds__(256) void sum_leading_wide_kernel(const float* __re
     if (threadIdx.x == 0) out[i] = (red[0] + red[1] + red[2] + red[3]) * scale;
 }
 
+// two scalars in one launch: out0 = sum partial[0..k), out1 = sum partial[k..2k)  (the dm / ds partials of a LayerNorm
+// adjoint, in the same order as sum_leading_wide_kernel sums them)
+__global__ __launch_bounds__(256) void sum_pair_kernel(const float* __restrict__ partial, float* __restrict__ out0,
+                                                       float* __restrict__ out1, int k) {
+    __shared__ float red[4];
+    const float* p = partial + (size_t)blockIdx.x * k;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < k; j += 256) s += p[j];
+    s = wave_sum_t(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) (blockIdx.x ? out1 : out0)[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+int launch_sum_pair(const float* partial, float* out0, float* out1, int k, hipStream_t s) {
+    hipLaunchKernelGGL(sum_pair_kernel, dim3(2), dim3(256), 0, s, partial, out0, out1, k);
+    return DWS_OK;
+}
+
 int launch_sum_leading(const float* partial, float* out, size_t n, int k, float scale, hipStream_t s) {
     if (n <= 64 && k >= 256)
         hipLaunchKernelGGL(sum_leading_wide_kernel, dim3((unsigned)n), dim3(256), 0, s, partial, out, (int)n, k, scale);
