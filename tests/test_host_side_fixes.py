@@ -133,3 +133,42 @@ def test_backward_of_a_stale_training_forward_raises(gpu):
         l1.backward()
     l2.backward()                           # the latest forward is still valid
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_kernel_length_cache_follows_the_buffer():
+    """`Sashimi._kernel_L` keeps a host copy of every S4 kernel's `L` buffer (reading it from the GPU is a blocking
+    device-to-host copy, twice per block and call before).  The copy must follow in-place writes (`_setup_C`'s `fill_`,
+    `load_state_dict`) and replaced buffers (`.to()`)."""
+    cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES["ss_d64_short"]
+    net = cases.build_ours(cfg, wseed)
+    k = next(iter(net._blocks())).layer.kernel.kernel
+    assert net._kernel_L(k) == int(k.L)
+    k.L.fill_(123)
+    assert net._kernel_L(k) == 123
+    sd = net.state_dict()
+    name = next(n for n in sd if n.endswith("kernel.kernel.L"))
+    sd[name] = torch.full_like(sd[name], 77)
+    net.load_state_dict(sd)
+    assert net._kernel_L(k) == 77 == int(k.L)
+    k.L = k.L.clone() + 1          # a new tensor object behind the same attribute
+    assert net._kernel_L(k) == 78
+
+
+def test_training_loss_staging_keeps_the_reference_rng_order():
+    """`training_loss` draws steps and noise on the CPU generator (`train.py:198-222`); the pinned staging path used on
+    the GPU must not change what is drawn.  On the CPU the stager is the identity: same seed -> same loss, and the
+    generator ends in the same state as after the reference's two draws."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from diffwave_sashimi_amd.training import _stage, training_loss
+    dh = calc_diffusion_hyperparams(20, 1e-4, 0.05)
+    audio = torch.rand(2, 1, 64) - 0.5
+    net = lambda xs, mel_spec=None: xs[0] * 0.5
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    l1 = training_loss(net, nn.MSELoss(), audio, dh, generator=g1)
+    steps = torch.randint(20, size=(2, 1, 1), generator=g2)
+    z = torch.normal(0, 1, size=audio.shape, generator=g2)
+    ab = dh["Alpha_bar"][steps]
+    l2 = nn.MSELoss()((torch.sqrt(ab) * audio + torch.sqrt(1 - ab) * z) * 0.5, z)
+    assert torch.equal(l1, l2) and torch.equal(g1.get_state(), g2.get_state())
+    t = torch.arange(6.).view(2, 3)
+    assert _stage(t, "cpu", "slot") is t or torch.equal(_stage(t, "cpu", "slot"), t)
