@@ -55,6 +55,11 @@ bool wn_layer_mfma_supported(int C, int S);
 int launch_wn_layer_mfma(int C, int S, const WnLayerArgs& a, hipStream_t s);
 int launch_wn_layer_generic(int C, int S, const WnLayerArgs& a, hipStream_t s);
 bool wn_final_mfma_supported(int S);
+// Winograd F(2,3) form of the fused layer (wavenet_wino.hip)
+bool wn_layer_wino_supported(int C, int S);
+int launch_wino_dconv(const float* w, float* out, int C, hipStream_t s);   // folded [2C][C][3] -> [2C][4C] (G0..G3)
+int launch_wn_wino_bias(const float* Wd_all, const float* part_t, float* Abt, int NL, int B, int C, hipStream_t s);
+int launch_wn_layer_wino(int C, int S, const WnLayerArgs& a, hipStream_t s);
 // bf16x3 path (wavenet_bf16x3.hip)
 bool wn_layer_bf16x3_supported(int C, int S);
 int launch_wn_layer_bf16x3(int C, int S, const WnLayerArgs& a, hipStream_t s);

@@ -14,6 +14,8 @@ struct WaveNetModel : dws_model {
     int Cin, Cout, C, S, NL, cycle, Ein, Emid, Eout, MB;
     bool cond, mfma_layer, mfma_final;
     bool bf16x3 = false;             // precision option (see include/dws.h)
+    bool wino_opt = true;            // conv_algo option: Winograd F(2,3) along the dilation stride (f32 path) or direct
+    bool wino() const { return wino_opt && mfma_layer && !bf16x3 && wn_layer_wino_supported(C, S); }
 
     // folded / packed weights
     DevBuf Wi;                       // init conv [C][Cin]
@@ -59,6 +61,7 @@ struct WaveNetModel : dws_model {
         mfma_bwd = tapconv_mfma_supported(C, S, C, 1) && tapconv_mfma_supported(C, 2 * C, 0, 3) &&
                    tapconv_mfma_supported(S, S, 0, 1) && std::getenv("DWS_WAVENET_GENERIC_BWD") == nullptr;
         mfma_final = wn_final_mfma_supported(S);
+        if (std::getenv("DWS_WN_DIRECT")) wino_opt = false;
         auto wn = [&](const std::string& p, std::vector<int64_t> vshape) {
             std::vector<int64_t> g(vshape.size(), 1);
             g[0] = vshape[0];
@@ -107,6 +110,10 @@ struct WaveNetModel : dws_model {
                 return DWS_OK;
             }
         }
+        if (key == "conv_algo") {
+            if (value == "winograd") { wino_opt = true; dirty = true; return DWS_OK; }
+            if (value == "direct") { wino_opt = false; dirty = true; return DWS_OK; }
+        }
         return dws_model::set_option(key, value);
     }
 
@@ -123,7 +130,7 @@ struct WaveNetModel : dws_model {
         DWS_TRY(bt_all.ensure((size_t)NL * C * 4));
         DWS_TRY(b1_all.ensure((size_t)NL * 2 * C * 4));
         DWS_TRY(Wd_all.ensure((size_t)NL * 2 * C * C * 3 * 4));
-        if (mfma_layer) DWS_TRY(tmp_pack.ensure((size_t)2 * C * 3 * C * 4));
+        if (mfma_layer) DWS_TRY(tmp_pack.ensure((size_t)2 * C * 4 * C * 4));
         stack_params.begin();
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
@@ -138,10 +145,14 @@ struct WaveNetModel : dws_model {
             stack_params.add(P(p + ".res_conv.bias"), bias2[n].f(), (size_t)C);
             stack_params.add(P(p + ".skip_conv.bias"), bias2[n].f() + C, (size_t)S);
             if (mfma_layer) {
-                DWS_TRY(A1[n].ensure((size_t)2 * C * 3 * C * 4));
-                DWS_TRY(launch_permute_dconv(Wd(n), tmp_pack.f(), C, bf16x3 ? WN_BX3_KC : WN_LAYER_KC, s));
+                DWS_TRY(A1[n].ensure((size_t)2 * C * 4 * C * 4));
+                if (wino()) DWS_TRY(launch_wino_dconv(Wd(n), tmp_pack.f(), C, s));
+                else DWS_TRY(launch_permute_dconv(Wd(n), tmp_pack.f(), C, bf16x3 ? WN_BX3_KC : WN_LAYER_KC, s));
                 DWS_TRY(A2[n].ensure((size_t)(C + S) * C * 4));
-                if (bf16x3) {
+                if (wino()) {
+                    DWS_TRY(launch_pack_a_frag(tmp_pack.f(), A1[n].f(), 2 * C, 4 * C, s));
+                    DWS_TRY(launch_pack_a_frag(Wrs[n].f(), A2[n].f(), C + S, C, s));
+                } else if (bf16x3) {
                     DWS_TRY(launch_pack_a_bf16x3(tmp_pack.f(), A1[n].p, 2 * C, 3 * C, s));
                     DWS_TRY(launch_pack_a_bf16x3(Wrs[n].f(), A2[n].p, C + S, C, s));
                 } else {
@@ -325,6 +336,7 @@ struct WaveNetModel : dws_model {
                                    (int)B, Emid, Eout, 1, s, train ? ta2.f() : nullptr));
         DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), (int)B, Eout, NL * C, 0, s));
         if (mfma_layer && bf16x3) DWS_TRY(launch_wn_bias_tap_bf16(Wd_all.f(), part_t.f(), b1_all.f(), Abt.p, NL, (int)B, C, s));
+        else if (wino()) DWS_TRY(launch_wn_wino_bias(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
         else if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
@@ -336,7 +348,8 @@ struct WaveNetModel : dws_model {
             a.part_t = part_t.f() + (size_t)n * C;
             a.part_t_bstride = NL * C;
             a.A1 = A1[n].f(); a.A2 = A2[n].f();
-            a.Abt = mfma_layer ? Abt.f() + (size_t)n * B * (2 * C / 32) * (bf16x3 ? 512 : 256) : nullptr;
+            a.Abt = !mfma_layer ? nullptr : wino() ? Abt.f() + (size_t)n * B * 4 * 2 * C
+                                                   : Abt.f() + (size_t)n * B * (2 * C / 32) * (bf16x3 ? 512 : 256);
             a.Wd = Wd(n); a.Wr = Wrs[n].f(); a.Ws = Wrs[n].f() + (size_t)C * C;
             a.bias1 = P(p + ".dilated_conv_layer.conv.bias");
             a.bias2 = bias2[n].f();
@@ -347,6 +360,7 @@ struct WaveNetModel : dws_model {
             a.dilation = 1 << (n % cycle);
             a.first_layer = (n == 0); a.last_layer = (n == NL - 1);
             if (mfma_layer && bf16x3) DWS_TRY(launch_wn_layer_bf16x3(C, S, a, s));
+            else if (wino()) DWS_TRY(launch_wn_layer_wino(C, S, a, s));
             else if (mfma_layer) DWS_TRY(launch_wn_layer_mfma(C, S, a, s));
             else DWS_TRY(launch_wn_layer_generic(C, S, a, s));
         }

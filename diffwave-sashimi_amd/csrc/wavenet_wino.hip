@@ -1,0 +1,407 @@
+// Fused WaveNet residual layer with the dilated 3-tap convolution in Winograd F(2,3) form ALONG THE DILATION STRIDE
+// (`models/wavenet.py:82-121`; the conv is `wavenet.py:19-20,95`).
+//
+//   H[o,l] = sum_c W0[o,c] h[c,l-d] + W1[o,c] h[c,l] + W2[o,c] h[c,l+d]          (h = x + fc_t(e), 0 outside [0,L))
+//
+// Outputs l and l+d share three of their inputs.  With d0..d3 = h[l-d], h[l], h[l+d], h[l+2d] and
+//   t0 = d0-d2   t1 = d1+d2   t2 = d2-d1   t3 = d1-d3           (one VALU op each, per B fragment)
+//   G0 = W0      G1 = (W0+W1+W2)/2   G2 = (W0-W1+W2)/2   G3 = W2  (folded once at commit)
+//   m_j = G_j t_j                                                (four K=C GEMMs per position PAIR instead of six)
+//   H[l] = m0+m1+m2      H[l+d] = m1-m2-m3
+// the convolution costs 8 C^2 flop per position instead of 12 C^2; the layer 12 C^2 + 2CS... (-25 % at C=S).
+//
+// Pairing: the positions are cut into blocks of 2d; position q of the "first halves" (q = 0,1,2,...) is
+//   p(q) = (q / d) * 2d + q % d,  its partner p(q) + d.
+// A workgroup owns 32 consecutive q (for d >= 32 that is 32 contiguous positions and their 32 partners d further on;
+// for d < 32 a contiguous block of 64 positions, pairs interleaved).  L is zero-extended to a multiple of 2d by the
+// buffer descriptors' bounds check (a row descriptor covers exactly [0, L): anything outside reads 0 and its stores
+// are dropped), at most 2.4 % extra pairs at L = 16000, d = 2048.
+//
+// The price of Winograd is accumulators: four products per pair = 2x the registers per output.  A wave therefore owns
+// ONE (tanh, sigmoid) row-tile pair (64 of the 2C conv outputs) x 32 pairs x 4 products = 128 accumulator registers,
+// and a workgroup has C/32 waves (8 at C = 256: one workgroup per CU, two waves per SIMD).
+//
+// Everything else follows the direct kernel (wavenet_kernels.hip): raw x staged by LDS-DMA through per-row
+// descriptors (zero padding for free), A fragments streamed from L2 one k-group ahead, the step embedding as one
+// extra k-step per product (exact at the padded edges: the B row is the Winograd transform of the in-range
+// indicator), the conv bias riding in the second k of that step, gate in registers, [res; skip] GEMM from the gate
+// tile in LDS, epilogue through buffer instructions.
+#include "dws_common.h"
+#include "wavenet.h"
+
+namespace dws {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Folded dilated-conv weight [2C][C][3] -> row-major [2C][4C] Winograd matrices in the K order the kernel walks:
+// column (kg*4 + j)*8 + cc  holds  G_j[o][kg*8 + cc]  (so pack_a_frag's k-group kg*4+j is product j of channel group kg)
+__global__ void wino_dconv_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int M) {
+    const int K = 4 * C;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * K) return;
+    const int o = (int)(i / K), k = (int)(i % K);
+    const int kg = k / 32, j = (k % 32) / 8, cc = k % 8;
+    const float* wr = w + ((size_t)o * C + kg * 8 + cc) * 3;
+    const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+    float g;
+    if (j == 0) g = w0;
+    else if (j == 1) g = 0.5f * ((w0 + w2) + w1);
+    else if (j == 2) g = 0.5f * ((w0 + w2) - w1);
+    else g = w2;
+    out[i] = g;
+}
+
+int launch_wino_dconv(const float* w, float* out, int C, hipStream_t s) {
+    const size_t n = (size_t)2 * C * 4 * C;
+    hipLaunchKernelGGL(wino_dconv_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, out, C, 2 * C);
+    return DWS_OK;
+}
+
+// Step-embedding correction of the Winograd products: Abt[n][b][j][o] = sum_c G_j[o,c] fc_t_n(e_b)[c].
+// One wave per (layer n, output row o); the folded weight row [C][3] stays in registers for all b.
+__global__ void wn_wino_bias_kernel(const float* __restrict__ Wd_all, const float* __restrict__ part_t,
+                                    float* __restrict__ Abt, int NL, int B, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // n * 2C + o
+    if (row >= NL * 2 * C) return;
+    const int n = row / (2 * C), o = row % (2 * C);
+    const float* w = Wd_all + (size_t)row * C * 3;
+    constexpr int MAXR = 8;  // C <= 512
+    float w0[MAXR], w1[MAXR], w2[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = c < C;
+        w0[i] = ok ? w[c * 3 + 0] : 0.f;
+        w1[i] = ok ? w[c * 3 + 1] : 0.f;
+        w2[i] = ok ? w[c * 3 + 2] : 0.f;
+    }
+    for (int b = 0; b < B; ++b) {
+        const float* pt = part_t + ((size_t)b * NL + n) * C;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int c = lane + 64 * i;
+            const float p = (c < C) ? pt[c] : 0.f;
+            s0 = fmaf(w0[i], p, s0); s1 = fmaf(w1[i], p, s1); s2 = fmaf(w2[i], p, s2);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off);
+        }
+        if (lane == 0) {
+            float* dst = Abt + ((size_t)n * B + b) * 4 * 2 * C;
+            dst[0 * 2 * C + o] = s0;
+            dst[1 * 2 * C + o] = 0.5f * ((s0 + s2) + s1);
+            dst[2 * 2 * C + o] = 0.5f * ((s0 + s2) - s1);
+            dst[3 * 2 * C + o] = s2;
+        }
+    }
+}
+
+int launch_wn_wino_bias(const float* Wd_all, const float* part_t, float* Abt, int NL, int B, int C, hipStream_t s) {
+    DWS_CHECK(C <= 512, DWS_ERR_UNSUPPORTED, "wn_wino_bias: C=%d > 512", C);
+    hipLaunchKernelGGL(wn_wino_bias_kernel, dim3(ceil_div((int64_t)NL * 2 * C, 4)), dim3(256), 0, s, Wd_all, part_t, Abt,
+                       NL, B, C);
+    return DWS_OK;
+}
+
+__device__ __forceinline__ float wino_gate(float t, float s) {   // tanh(t) * sigmoid(s), see fast_gate (wavenet_kernels.hip)
+    const float tc = __builtin_amdgcn_fmed3f(t, -30.f, 30.f);
+    const float e2 = __builtin_amdgcn_exp2f(tc * 2.8853900817779268f);
+    const float en = __builtin_amdgcn_exp2f(s * -1.4426950408889634f);
+    return (e2 - 1.f) * __builtin_amdgcn_rcpf((e2 + 1.f) * (1.f + en));
+}
+
+__device__ __forceinline__ f32x4 wino_load_f4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int C, int S>
+struct WinoTile {
+    static constexpr int WAVES = C / 32;          // one (tanh, sigmoid) tile pair per wave
+    static constexpr int NTH = WAVES * 64;
+    static constexpr int NP = 32;                 // position pairs per workgroup (64 positions)
+    static constexpr int KC = 32;                 // channels per staged chunk
+    static constexpr int NCB = C / KC;
+    static constexpr int MS = S / C;              // skip tiles per wave
+    static constexpr int XS = KC * 4 * NP;        // floats of one staged chunk: [cc][s][j]
+    static constexpr int G_FLOATS = C * 2 * NP;   // gate tile [C][64]: columns 0..31 = first halves, 32..63 = partners
+    static constexpr int LDS_FLOATS = 2 * XS + G_FLOATS;
+    static_assert(C % 32 == 0 && S % C == 0 && C % KC == 0, "channel counts");
+};
+
+template <int C, int S, bool EXTRA>
+__global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, int log2d) {
+    using T = WinoTile<C, S>;
+    constexpr int KC = T::KC, XS = T::XS, MS = T::MS, WAVES = T::WAVES;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int L = a.L, dil = 1 << log2d;
+
+    const int nblk = (L + 2 * dil - 1) >> (log2d + 1);     // blocks of 2d
+    const int ntl = ((nblk << log2d) + 31) >> 5;           // tiles of 32 pairs per batch element
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
+    const int q0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
+    // first-half position of this lane's column
+    const int q = q0 + l31;
+    const int p = ((q >> log2d) << (log2d + 1)) + (q & (dil - 1));
+
+    const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
+
+    // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 4 shifts (-d, 0, +d, +2d) x 32 columns of RAW x by LDS-DMA.
+    // One instruction moves two shifts of one channel row (lanes 0..31: shift 2*half, lanes 32..63: shift 2*half+1).
+    const int voffA = (p + (lhi - 1) * dil) * 4;   // shifts -d (lhi 0), 0 (lhi 1); negative -> huge unsigned -> reads 0
+    const int voffB = (p + (lhi + 1) * dil) * 4;   // shifts +d, +2d
+    constexpr int RPW = KC / WAVES;                // channel rows per wave and chunk
+    static_assert(KC % WAVES == 0, "rows per wave");
+    auto stage_dma = [&](int cb, int buf) {
+        float* xs = lds + buf * XS;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int cc = wave + WAVES * i;
+            const int c = cb * KC + cc;
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * L), 0, L * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + cc * 128, 4, voffA, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + cc * 128 + 64, 4, voffB, 0, 0, 0);
+        }
+    };
+
+    // ---- GEMM1: m_j[2C x 32] = G_j[2C x C] . t_j[C x 32],  j = 0..3;  this wave: rows of tiles `wave` and C/32 + wave
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    constexpr int NKG = C / 8;   // channel groups of 8 (4 k-steps)
+    __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A1, 0, 2 * C * 4 * C * 4, 0x00020000);
+    const int lane16 = lane * 16;
+    const int mt1[2] = {wave, C / 32 + wave};
+
+    stage_dma(0, 0);
+    f32x4 a_cur[2][4], a_nxt[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[m][j] = wino_load_f4(rA1, lane16, ((mt1[m] * NKG) * 4 + j) * 1024);
+    __syncthreads();
+
+    for (int cb = 0; cb < T::NCB; ++cb) {
+        if (cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
+        const float* xs = lds + (cb & 1) * XS;
+#pragma unroll
+        for (int it = 0; it < KC / 8; ++it) {
+            const int kg = cb * (KC / 8) + it;
+            const int kgn = (kg + 1 < NKG) ? kg + 1 : kg;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a_nxt[m][j] = wino_load_f4(rA1, lane16, ((mt1[m] * NKG + kgn) * 4 + j) * 1024);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole k-group (32 MFMAs) ahead of its use
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float* xr = xs + (it * 8 + ks * 2 + lhi) * 128 + l31;
+                const float d0 = xr[0], d1 = xr[32], d2 = xr[64], d3 = xr[96];
+                float t[4];
+                t[0] = d0 - d2; t[1] = d1 + d2; t[2] = d2 - d1; t[3] = d1 - d3;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j][ks], t[j], acc[m][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a_cur[m][j] = a_nxt[m][j];
+        }
+        __syncthreads();  // (LDS-DMA of chunk cb+1 has landed: the barrier's release waits vmcnt(0))
+    }
+    // extra k-step per product: k = 0 carries the step-embedding correction (A = G_j fc_t(e), B = Winograd transform of
+    // the in-range indicator of the four shifts), k = 1 of product 1 carries the conv bias (A = bias, B = 1): m1 enters
+    // both outputs of a pair with weight +1.
+    {
+        const float v0 = ((unsigned)(p - dil) < (unsigned)L) ? 1.f : 0.f;
+        const float v1 = ((unsigned)p < (unsigned)L) ? 1.f : 0.f;
+        const float v2 = ((unsigned)(p + dil) < (unsigned)L) ? 1.f : 0.f;
+        const float v3 = ((unsigned)(p + 2 * dil) < (unsigned)L) ? 1.f : 0.f;
+        float bi[4];
+        bi[0] = lhi ? 0.f : v0 - v2;
+        bi[1] = lhi ? 1.f : v1 + v2;
+        bi[2] = lhi ? 0.f : v2 - v1;
+        bi[3] = lhi ? 0.f : v1 - v3;
+        const float* Abt = a.Abt + (size_t)b * 4 * 2 * C;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = mt1[m] * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float av = lhi ? 0.f : Abt[j * 2 * C + row];
+                if (j == 1 && lhi) av = a.bias1[row];
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bi[j], acc[m][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- gate: g = tanh(H_t (+mel_t)) * sigmoid(H_s (+mel_s)) for both outputs of every pair -> LDS [C][64]
+    float* gt = lds + 2 * XS;
+    const float* melb = (EXTRA && a.melc) ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int pos = p + n * dil;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            float ht, hs;
+            if (n == 0) {
+                ht = (acc[0][0][r] + acc[0][1][r]) + acc[0][2][r];
+                hs = (acc[1][0][r] + acc[1][1][r]) + acc[1][2][r];
+            } else {
+                ht = (acc[0][1][r] - acc[0][2][r]) - acc[0][3][r];
+                hs = (acc[1][1][r] - acc[1][2][r]) - acc[1][3][r];
+            }
+            if (EXTRA && melb && pos < L) {
+                ht += melb[(size_t)ch * L + pos];
+                hs += melb[(size_t)(C + ch) * L + pos];
+            }
+            if (EXTRA && a.hsave && pos < L) {   // training: keep the pre-activations for the gate adjoint
+                float* __restrict__ hb = a.hsave + (size_t)b * 2 * C * L;
+                hb[(size_t)ch * L + pos] = ht;
+                hb[(size_t)(C + ch) * L + pos] = hs;
+            }
+            gt[ch * 64 + n * 32 + l31] = wino_gate(ht, hs);
+        }
+    }
+    __syncthreads();
+
+    // ---- GEMM2: [res; skip][(C+S) x 64] = [Wr; Ws][(C+S) x C] . g[C x 64];  this wave: res tile `wave`, skip tiles
+    f32x16 acc2[1 + MS][2];
+#pragma unroll
+    for (int m = 0; m < 1 + MS; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
+
+    __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 4, 0x00020000);
+    int mt2[1 + MS];
+    mt2[0] = wave;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) mt2[1 + m] = C / 32 + wave * MS + m;
+    f32x4 c_cur[1 + MS], c_nxt[1 + MS];
+#pragma unroll
+    for (int m = 0; m < 1 + MS; ++m) c_cur[m] = wino_load_f4(rA2, lane16, (mt2[m] * NKG) * 1024);
+#pragma unroll 2
+    for (int kg = 0; kg < NKG; ++kg) {
+        const int kgn = (kg + 1 < NKG) ? kg + 1 : kg;
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m) c_nxt[m] = wino_load_f4(rA2, lane16, (mt2[m] * NKG + kgn) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int krow = kg * 8 + ks * 2 + lhi;
+            float bf[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bf[n] = gt[krow * 64 + n * 32 + l31];
+#pragma unroll
+            for (int m = 0; m < 1 + MS; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][ks], bf[n], acc2[m][n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m) c_cur[m] = c_nxt[m];
+    }
+
+    // ---- epilogue: x' = (x + res + b_r) * sqrt(.5);  skip_acc (+)= skip + b_s   (buffer instructions: the row rides in
+    // the scalar offset, the lane part is one 32-bit offset per column; a position past L gets an out-of-range offset)
+    const float rs = 0.70710678118654752440f;
+    const bool first = a.first_layer, last = a.last_layer;
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rXo = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x_out + (size_t)b * C * L), 0, C * L * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rSk = __builtin_amdgcn_make_buffer_rsrc((void*)(a.skip + (size_t)b * S * L), 0, S * L * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias2, 0, (C + S) * 4, 0x00020000);
+    const int L4 = L * 4;
+    const int vb = 16 * lhi;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int pos = p + n * dil;
+        const int voff = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
+        if (!last) {
+            const int s0 = (wave * 32) * L4;
+            float xr[16], br[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0));
+                br[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, vb, (wave * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = (xr[r] + (acc2[0][n][r] + br[r])) * rs;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rXo, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
+            const int s0 = ((wave * MS + m) * 32) * L4;
+            float sr[16], bq[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bq[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, vb, (C + (wave * MS + m) * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+            if (!first) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rSk, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = sr[r] + (acc2[1 + m][n][r] + bq[r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
+            }
+        }
+    }
+}
+
+template <int C, int S>
+static int launch_wino_t(const WnLayerArgs& a, int log2d, hipStream_t s) {
+    ProfileScope ps("wn_layer_wino", s);
+    using T = WinoTile<C, S>;
+    const int dil = 1 << log2d;
+    const int nblk = (a.L + 2 * dil - 1) / (2 * dil);
+    const int ntl = (nblk * dil + 31) / 32;
+    if (a.melc || a.hsave)
+        hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, true>), dim3(a.B * ntl), dim3(T::NTH), 0, s, a, log2d);
+    else
+        hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, false>), dim3(a.B * ntl), dim3(T::NTH), 0, s, a, log2d);
+    return DWS_OK;
+}
+
+bool wn_layer_wino_supported(int C, int S) {
+    return (C == 64 && S == 64) || (C == 128 && S == 128) || (C == 128 && S == 256) || (C == 256 && S == 256);
+}
+
+int launch_wn_layer_wino(int C, int S, const WnLayerArgs& a, hipStream_t s) {
+    int log2d = 0;
+    while ((1 << log2d) < a.dilation) ++log2d;
+    DWS_CHECK((1 << log2d) == a.dilation, DWS_ERR_UNSUPPORTED, "wn_layer_wino: dilation %d is not a power of two", a.dilation);
+    DWS_CHECK((int64_t)a.L + 4 * (int64_t)a.dilation < ((int64_t)1 << 28), DWS_ERR_UNSUPPORTED, "wn_layer_wino: L too large");
+    if (C == 64 && S == 64) return launch_wino_t<64, 64>(a, log2d, s);
+    if (C == 128 && S == 128) return launch_wino_t<128, 128>(a, log2d, s);
+    if (C == 128 && S == 256) return launch_wino_t<128, 256>(a, log2d, s);
+    if (C == 256 && S == 256) return launch_wino_t<256, 256>(a, log2d, s);
+    return set_error(DWS_ERR_UNSUPPORTED, "wn_layer_wino: (C=%d,S=%d) not instantiated", C, S);
+}
+
+}  // namespace dws
