@@ -92,6 +92,20 @@ int dws_profile_query(int64_t* launches, double* total_ms) {
     return DWS_OK;
 }
 
+int dws_profile_query_each(double* ms, int64_t capacity, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(dws::g_prof_mu);
+    int64_t n = 0;
+    for (auto& p : dws::g_prof_events) {
+        if (hipEventSynchronize(p.second) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.first, p.second) != hipSuccess) continue;
+        if (ms && n < capacity) ms[n] = t;
+        ++n;
+    }
+    if (launches) *launches = n;
+    return DWS_OK;
+}
+
 int dws_profile_disable(void) {
     std::lock_guard<std::mutex> lk(dws::g_prof_mu);
     dws::g_prof_on = false;

@@ -26,6 +26,7 @@ struct WnLayerArgs {
     float* gate_ws;        // generic path scratch [B, C, L]
     float* hsave;          // nullable (training): pre-gate activations H of this layer [B, 2C, L]
     int B, L, dilation, first_layer, last_layer;
+    unsigned long long* trace;   // nullable (tools only): s_memtime stamps [tile][wave][8] of the Winograd kernel's phases
 };
 
 struct WnFinalArgs {

@@ -29,6 +29,9 @@
 #include "dws_common.h"
 #include "wavenet.h"
 
+#include <cstdlib>
+#include <vector>
+
 namespace dws {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -123,20 +126,25 @@ struct WinoTile {
     static constexpr int WAVES = C / 32;          // one (tanh, sigmoid) tile pair per wave
     static constexpr int NTH = WAVES * 64;
     static constexpr int NP = 32;                 // position pairs per workgroup (64 positions)
-    static constexpr int KC = 32;                 // channels per staged chunk
+    static constexpr int KC = (C >= 256) ? 32 : 16;   // channels per staged chunk (C = 128: two workgroups per CU fit)
     static constexpr int NCB = C / KC;
     static constexpr int MS = S / C;              // skip tiles per wave
-    static constexpr int XS = KC * 4 * NP;        // floats of one staged chunk: [cc][s][j]
-    static constexpr int G_FLOATS = C * 2 * NP;   // gate tile [C][64]: columns 0..31 = first halves, 32..63 = partners
-    static constexpr int LDS_FLOATS = 2 * XS + G_FLOATS;
-    static_assert(C % 32 == 0 && S % C == 0 && C % KC == 0, "channel counts");
+    static constexpr int XS = KC * 4 * NP;        // floats of one chunk: raw [cc][s][j] / transformed [cc][j][4]
+    static constexpr int G_FLOATS = C * 2 * NP;   // gate tile [C][32][2]: (first half, partner) of a pair adjacent
+    static constexpr int LDS_FLOATS = 4 * XS + G_FLOATS;
+    static constexpr int ITEMS = KC * NP / NTH;   // (channel, column) items per thread of the transform pass
+    static_assert(C % 32 == 0 && S % C == 0 && C % KC == 0 && KC % WAVES == 0 && (KC * NP) % NTH == 0 && 32 % KC == 0,
+                  "channel counts");
 };
 
 template <int C, int S, bool EXTRA>
 __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, int log2d) {
     using T = WinoTile<C, S>;
-    constexpr int KC = T::KC, XS = T::XS, MS = T::MS, WAVES = T::WAVES;
+    constexpr int KC = T::KC, XS = T::XS, MS = T::MS, WAVES = T::WAVES, NCB = T::NCB, NTH = T::NTH;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    float* const Xraw = lds;                 // 2 chunks of raw x (LDS-DMA target)
+    float* const Tt = lds + 2 * XS;          // 2 chunks of Winograd-transformed x (B operands)
+    float* const gt = lds + 4 * XS;          // gate tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -154,15 +162,48 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     const int p = ((q >> log2d) << (log2d + 1)) + (q & (dil - 1));
 
     const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
+    unsigned long long* __restrict__ trc = a.trace ? a.trace + ((size_t)blockIdx.x * WAVES + wave) * 32 : nullptr;
+    auto stamp = [&](int i) {
+        if (trc) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) trc[i] = t;
+        }
+    };
+    stamp(0);
 
-    // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 4 shifts (-d, 0, +d, +2d) x 32 columns of RAW x by LDS-DMA.
-    // One instruction moves two shifts of one channel row (lanes 0..31: shift 2*half, lanes 32..63: shift 2*half+1).
+    // ---- operands of the two extra k-steps, fetched first (their latency hides behind the first staging wait).
+    // GEMM1: k = 0 carries the step-embedding correction (A = G_j fc_t(e), B = Winograd transform of the in-range indicator
+    // of the four shifts), k = 1 of product 1 the conv bias (A = bias, B = 1: m1 enters both outputs of a pair with +1).
+    // GEMM2: A = [b_r; b_s] (k = 0), B = 1.
+    const int mt1[2] = {wave, C / 32 + wave};
+    int mt2[1 + MS];
+    mt2[0] = wave;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) mt2[1 + m] = C / 32 + wave * MS + m;
+    float av1[2][4], av2[1 + MS];
+    {
+        const float* Abt = a.Abt + (size_t)b * 4 * 2 * C;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = mt1[m] * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* src = (j == 1 && lhi) ? a.bias1 + row : Abt + j * 2 * C + row;
+                av1[m][j] = *src;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m) av2[m] = a.bias2[mt2[m] * 32 + l31];
+    }
+
+    // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 4 shifts (-d, 0, +d, +2d) x 32 columns of RAW x by LDS-DMA
+    // through one descriptor per channel row (num_records = L*4: a shifted position outside [0, L) reads 0 -- the conv's
+    // zero padding costs nothing).  One instruction moves two shifts of one row (lanes 0..31 / 32..63).
     const int voffA = (p + (lhi - 1) * dil) * 4;   // shifts -d (lhi 0), 0 (lhi 1); negative -> huge unsigned -> reads 0
     const int voffB = (p + (lhi + 1) * dil) * 4;   // shifts +d, +2d
     constexpr int RPW = KC / WAVES;                // channel rows per wave and chunk
-    static_assert(KC % WAVES == 0, "rows per wave");
-    auto stage_dma = [&](int cb, int buf) {
-        float* xs = lds + buf * XS;
+    auto stage_dma = [&](int cb) {
+        float* xs = Xraw + (cb & 1) * XS;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int cc = wave + WAVES * i;
@@ -173,31 +214,93 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
         }
     };
 
+    // [res; skip] accumulators: the res tile starts from x itself (picked out of the staged window below), so the
+    // residual add costs neither a reload of x nor an add
+    f32x16 acc2[1 + MS][2];
+#pragma unroll
+    for (int m = 0; m < 1 + MS; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
+
+    // ---- transform pass (all waves together, once per chunk instead of once per wave): raw chunk c1 -> t0..t3 in
+    // B-fragment order [cc][j][4] (one ds_read_b128 per k-step and lane in the MFMA loop, address = lane*16 + immediate);
+    // the wave whose res rows live in this chunk copies x[., p] and x[., p+d] (shifts 0 and +d) into its accumulators.
+    auto transform = [&](int c1) {
+        const float* xs = Xraw + (c1 & 1) * XS;
+        f32x4* tt = reinterpret_cast<f32x4*>(Tt + (c1 & 1) * XS);
+#pragma unroll
+        for (int k = 0; k < T::ITEMS; ++k) {
+            const int i = tid + NTH * k;
+            const int cc = i >> 5, j = i & 31;
+            const float* xr = xs + cc * 128 + j;
+            const float d0 = xr[0], d1 = xr[32], d2 = xr[64], d3 = xr[96];
+            f32x4 t;
+            t[0] = d0 - d2; t[1] = d1 + d2; t[2] = d2 - d1; t[3] = d1 - d3;
+            tt[i] = t;
+        }
+        if ((c1 * KC) / 32 == wave) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (r & 3) + 8 * (r >> 2);            // + 4*lhi: never crosses a multiple of 8
+                if ((ch % 32) / KC == c1 % (32 / KC)) {           // compile-time per r once c1's parity is known
+                    const float* xr = xs + ((ch % KC) + 4 * lhi) * 128 + l31;
+                    acc2[0][0][r] = xr[32];
+                    acc2[0][1][r] = xr[64];
+                }
+            }
+        }
+    };
+
     // ---- GEMM1: m_j[2C x 32] = G_j[2C x C] . t_j[C x 32],  j = 0..3;  this wave: rows of tiles `wave` and C/32 + wave
     f32x16 acc[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
-
     constexpr int NKG = C / 8;   // channel groups of 8 (4 k-steps)
     __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A1, 0, 2 * C * 4 * C * 4, 0x00020000);
     const int lane16 = lane * 16;
-    const int mt1[2] = {wave, C / 32 + wave};
 
-    stage_dma(0, 0);
+    stage_dma(0);
+    if (NCB > 1) stage_dma(1);
     f32x4 a_cur[2][4], a_nxt[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) a_cur[m][j] = wino_load_f4(rA1, lane16, ((mt1[m] * NKG) * 4 + j) * 1024);
+    __syncthreads();   // chunks 0 and 1 have landed
+    stamp(1);
+    {
+        const float v0 = ((unsigned)(p - dil) < (unsigned)L) ? 1.f : 0.f;
+        const float v1 = ((unsigned)p < (unsigned)L) ? 1.f : 0.f;
+        const float v2 = ((unsigned)(p + dil) < (unsigned)L) ? 1.f : 0.f;
+        const float v3 = ((unsigned)(p + 2 * dil) < (unsigned)L) ? 1.f : 0.f;
+        float bi[4];
+        bi[0] = lhi ? 0.f : v0 - v2;
+        bi[1] = lhi ? 1.f : v1 + v2;
+        bi[2] = lhi ? 0.f : v2 - v1;
+        bi[3] = lhi ? 0.f : v1 - v3;
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float av = (lhi && j != 1) ? 0.f : av1[m][j];
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bi[j], zero, 0, 0, 0);
+            }
+    }
+    transform(0);
     __syncthreads();
 
-    for (int cb = 0; cb < T::NCB; ++cb) {
-        if (cb + 1 < T::NCB) stage_dma(cb + 1, (cb + 1) & 1);
-        const float* xs = lds + (cb & 1) * XS;
+    for (int cb = 0; cb < NCB; ++cb) {
+#ifndef WINO_ABL_NODMA
+        if (cb + 2 < NCB) stage_dma(cb + 2);       // into the raw buffer chunk cb occupied (transformed an iteration ago)
+#endif
+        if (cb + 1 < NCB) transform(cb + 1);
+        const char* tb = reinterpret_cast<const char*>(Tt + (cb & 1) * XS) + lane16;
+#ifdef WINO_BPF
+        f32x4 t_nxt = *reinterpret_cast<const f32x4*>(tb);
+#endif
 #pragma unroll
         for (int it = 0; it < KC / 8; ++it) {
             const int kg = cb * (KC / 8) + it;
@@ -209,58 +312,49 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole k-group (32 MFMAs) ahead of its use
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const float* xr = xs + (it * 8 + ks * 2 + lhi) * 128 + l31;
-                const float d0 = xr[0], d1 = xr[32], d2 = xr[64], d3 = xr[96];
-                float t[4];
-                t[0] = d0 - d2; t[1] = d1 + d2; t[2] = d2 - d1; t[3] = d1 - d3;
+                // B fragment of the NEXT k-step first: a wave running alone on its SIMD (its partner parked at the chunk
+                // barrier) then never waits for LDS between k-steps
+#ifdef WINO_BPF
+                const f32x4 t = t_nxt;
+                if (it * 4 + ks + 1 < KC / 2) t_nxt = *reinterpret_cast<const f32x4*>(tb + (it * 8 + ks * 2 + 2) * 512);
+#else
+                const f32x4 t = *reinterpret_cast<const f32x4*>(tb + (it * 8 + ks * 2) * 512);
+#endif
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j][ks], t[j], acc[m][j], 0, 0, 0);
+#ifdef WINO_KSCHED
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a_cur[m][j] = a_nxt[m][j];
         }
-        __syncthreads();  // (LDS-DMA of chunk cb+1 has landed: the barrier's release waits vmcnt(0))
+        stamp(8 + 2 * cb);
+#ifndef WINO_ABL_NOBAR
+        // transformed chunk cb+1 visible after the barrier; the LDS-DMA of chunk cb+2 must have landed too, and hipcc does
+        // not count LDS-DMA among the accesses a barrier has to wait for: explicit vmcnt(0) (the only younger loads are
+        // the A fragments of the next k-group, fetched a whole k-group ago)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+#endif
+        stamp(9 + 2 * cb);
     }
-    // extra k-step per product: k = 0 carries the step-embedding correction (A = G_j fc_t(e), B = Winograd transform of
-    // the in-range indicator of the four shifts), k = 1 of product 1 carries the conv bias (A = bias, B = 1): m1 enters
-    // both outputs of a pair with weight +1.
-    {
-        const float v0 = ((unsigned)(p - dil) < (unsigned)L) ? 1.f : 0.f;
-        const float v1 = ((unsigned)p < (unsigned)L) ? 1.f : 0.f;
-        const float v2 = ((unsigned)(p + dil) < (unsigned)L) ? 1.f : 0.f;
-        const float v3 = ((unsigned)(p + 2 * dil) < (unsigned)L) ? 1.f : 0.f;
-        float bi[4];
-        bi[0] = lhi ? 0.f : v0 - v2;
-        bi[1] = lhi ? 1.f : v1 + v2;
-        bi[2] = lhi ? 0.f : v2 - v1;
-        bi[3] = lhi ? 0.f : v1 - v3;
-        const float* Abt = a.Abt + (size_t)b * 4 * 2 * C;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int row = mt1[m] * 32 + l31;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float av = lhi ? 0.f : Abt[j * 2 * C + row];
-                if (j == 1 && lhi) av = a.bias1[row];
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bi[j], acc[m][j], 0, 0, 0);
-            }
-        }
-    }
+    stamp(2);
 
-    // ---- gate: g = tanh(H_t (+mel_t)) * sigmoid(H_s (+mel_s)) for both outputs of every pair -> LDS [C][64]
-    float* gt = lds + 2 * XS;
+    // ---- gate: g = tanh(H_t (+mel_t)) * sigmoid(H_s (+mel_s)) for both outputs of every pair -> LDS [C][32][2]
     const float* melb = (EXTRA && a.melc) ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int pos = p + n * dil;
+    for (int r = 0; r < 16; ++r) {
+        const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float g2[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        for (int n = 0; n < 2; ++n) {
+            const int pos = p + n * dil;
             float ht, hs;
             if (n == 0) {
                 ht = (acc[0][0][r] + acc[0][1][r]) + acc[0][2][r];
@@ -278,28 +372,29 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
                 hb[(size_t)ch * L + pos] = ht;
                 hb[(size_t)(C + ch) * L + pos] = hs;
             }
-            gt[ch * 64 + n * 32 + l31] = wino_gate(ht, hs);
+            g2[n] = wino_gate(ht, hs);
         }
+        *reinterpret_cast<float2*>(gt + (ch * 32 + l31) * 2) = make_float2(g2[0], g2[1]);
     }
+    stamp(3);
     __syncthreads();
+    stamp(4);
 
-    // ---- GEMM2: [res; skip][(C+S) x 64] = [Wr; Ws][(C+S) x C] . g[C x 64];  this wave: res tile `wave`, skip tiles
-    f32x16 acc2[1 + MS][2];
-#pragma unroll
-    for (int m = 0; m < 1 + MS; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
-
+    // ---- GEMM2: [res; skip][(C+S) x 64] = [Wr; Ws][(C+S) x C] . g[C x 64] (+ bias k-step);  this wave: res tile `wave`
+    // (accumulating onto x) and its skip tiles
     __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 4, 0x00020000);
-    int mt2[1 + MS];
-    mt2[0] = wave;
-#pragma unroll
-    for (int m = 0; m < MS; ++m) mt2[1 + m] = C / 32 + wave * MS + m;
     f32x4 c_cur[1 + MS], c_nxt[1 + MS];
 #pragma unroll
     for (int m = 0; m < 1 + MS; ++m) c_cur[m] = wino_load_f4(rA2, lane16, (mt2[m] * NKG) * 1024);
+    {
+        const float one = lhi ? 0.f : 1.f;
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(lhi ? 0.f : av2[m], one, acc2[m][n], 0, 0, 0);
+    }
+    const char* gb = reinterpret_cast<const char*>(gt) + lane * 8;
 #pragma unroll 2
     for (int kg = 0; kg < NKG; ++kg) {
         const int kgn = (kg + 1 < NKG) ? kg + 1 : kg;
@@ -308,70 +403,108 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int krow = kg * 8 + ks * 2 + lhi;
-            float bf[2];
+            const float2 bf = *reinterpret_cast<const float2*>(gb + (kg * 8 + ks * 2) * 256);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bf[n] = gt[krow * 64 + n * 32 + l31];
-#pragma unroll
-            for (int m = 0; m < 1 + MS; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][ks], bf[n], acc2[m][n], 0, 0, 0);
+            for (int m = 0; m < 1 + MS; ++m) {
+                acc2[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][ks], bf.x, acc2[m][0], 0, 0, 0);
+                acc2[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][ks], bf.y, acc2[m][1], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int m = 0; m < 1 + MS; ++m) c_cur[m] = c_nxt[m];
     }
+    stamp(5);
 
-    // ---- epilogue: x' = (x + res + b_r) * sqrt(.5);  skip_acc (+)= skip + b_s   (buffer instructions: the row rides in
-    // the scalar offset, the lane part is one 32-bit offset per column; a position past L gets an out-of-range offset)
+    // ---- epilogue: x' = (x + res + b_r) * sqrt(.5) is the res accumulator scaled; skip_acc += skip + b_s goes out as a
+    // no-return float atomic (one add per element and layer, layers are stream-ordered: the same bits as load-add-store,
+    // without the load).  Buffer instructions: the row rides in the scalar offset, the lane part is one 32-bit offset per
+    // column; a position past L gets an out-of-range offset and is dropped.
     const float rs = 0.70710678118654752440f;
     const bool first = a.first_layer, last = a.last_layer;
-    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rXo = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x_out + (size_t)b * C * L), 0, C * L * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rSk = __builtin_amdgcn_make_buffer_rsrc((void*)(a.skip + (size_t)b * S * L), 0, S * L * 4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias2, 0, (C + S) * 4, 0x00020000);
     const int L4 = L * 4;
-    const int vb = 16 * lhi;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int pos = p + n * dil;
         const int voff = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
         if (!last) {
             const int s0 = (wave * 32) * L4;
-            float xr[16], br[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0));
-                br[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, vb, (wave * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = (xr[r] + (acc2[0][n][r] + br[r])) * rs;
+                const float v = acc2[0][n][r] * rs;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rXo, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
             }
         }
 #pragma unroll
         for (int m = 0; m < MS; ++m) {
             const int s0 = ((wave * MS + m) * 32) * L4;
-            float sr[16], bq[16];
+            if (first) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                bq[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, vb, (C + (wave * MS + m) * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
-            if (!first) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rSk, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0));
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc2[1 + m][n][r];   // (bit_cast straight from a vector element picks element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voff,
+                                                          s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
+                }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = sr[r] + (acc2[1 + m][n][r] + bq[r]);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc2[1 + m][n][r], rSk, voff,
+                                                                    s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
             }
         }
     }
+    stamp(6);
+    if (trc) {
+        __builtin_amdgcn_s_waitcnt(0);   // everything (stores included) retired
+        stamp(7);
+    }
+}
+
+// DWS_WINO_TRACE=1 (tools only): stamp the phases of every wave of the first traced launch and print a summary
+template <typename F>
+static void wino_trace_launch(int nwg, int waves, WnLayerArgs a, hipStream_t s, F launch) {
+    unsigned long long* d = nullptr;
+    const size_t n = (size_t)nwg * waves * 32;
+    if (hipMalloc(&d, n * 8) != hipSuccess) return;
+    hipMemsetAsync(d, 0, n * 8, s);
+    a.trace = d;
+    launch(a);
+    hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(n);
+    hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    double ph[8] = {0};
+    static double chunk[8][32];
+    for (auto& c : chunk) for (double& v : c) v = 0;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    double wgspan = 0;
+    for (int g = 0; g < nwg; ++g) {
+        unsigned long long g0 = ~0ull, g1 = 0;
+        for (int w = 0; w < waves; ++w) {
+            const unsigned long long* t = &h[((size_t)g * waves + w) * 32];
+            for (int i = 1; i < 8; ++i) ph[i] += (double)(t[i] - t[i - 1]);
+            if (w < 8)
+                for (int i = 8; i < 32; ++i)
+                    if (t[i]) { chunk[w][i] += (double)(t[i] - t[1]); }
+            if (t[0] < g0) g0 = t[0];
+            if (t[7] > g1) g1 = t[7];
+        }
+        wgspan += (double)(g1 - g0);
+        if (g0 < tmin) tmin = g0;
+        if (g1 > tmax) tmax = g1;
+    }
+    const double nw = (double)nwg * waves;
+    fprintf(stderr, "[wino trace] d=%d wgs=%d kernel span %.0f ticks (100 MHz: %.1f us); per-wave mean ticks: prologue %.0f gemm1 %.0f "
+            "extra+gate %.0f barrier %.0f gemm2 %.0f epilogue %.0f drain %.0f; mean WG span %.0f\n", a.dilation, nwg,
+            (double)(tmax - tmin), (double)(tmax - tmin) / 100.0, ph[1] / nw, ph[2] / nw, ph[3] / nw, ph[4] / nw, ph[5] / nw,
+            ph[6] / nw, ph[7] / nw, wgspan / nwg);
+    if (std::getenv("DWS_WINO_TRACE_CHUNKS"))
+        for (int w = 0; w < waves && w < 8; ++w) {
+            fprintf(stderr, "  wave %d arrive/release since gemm1 start:", w);
+            for (int i = 8; i < 24; ++i) fprintf(stderr, " %.0f%s", chunk[w][i] / nwg, (i & 1) ? " |" : "");
+            fprintf(stderr, "\n");
+        }
 }
 
 template <int C, int S>
@@ -381,6 +514,13 @@ static int launch_wino_t(const WnLayerArgs& a, int log2d, hipStream_t s) {
     const int dil = 1 << log2d;
     const int nblk = (a.L + 2 * dil - 1) / (2 * dil);
     const int ntl = (nblk * dil + 31) / 32;
+    static const bool trace = std::getenv("DWS_WINO_TRACE") != nullptr;
+    if (trace && !(a.melc || a.hsave)) {
+        wino_trace_launch(a.B * ntl, T::WAVES, a, s, [&](const WnLayerArgs& at) {
+            hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, false>), dim3(a.B * ntl), dim3(T::NTH), 0, s, at, log2d);
+        });
+        return DWS_OK;
+    }
     if (a.melc || a.hsave)
         hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, true>), dim3(a.B * ntl), dim3(T::NTH), 0, s, a, log2d);
     else

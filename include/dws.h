@@ -208,6 +208,8 @@ int dws_mel_spectrogram(const float* audio, int64_t B, int64_t T, const float* w
  * of launches and their total milliseconds since enable. */
 int dws_profile_enable(const char* substr);
 int dws_profile_query(int64_t* launches, double* total_ms);
+/* the same launches one by one, in launch order: ms[i] for i < min(*launches, capacity) */
+int dws_profile_query_each(double* ms, int64_t capacity, int64_t* launches);
 int dws_profile_disable(void);
 
 #ifdef __cplusplus

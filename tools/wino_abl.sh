@@ -1,0 +1,12 @@
+#!/bin/bash
+# same-box ablations of the Winograd layer kernel: tools/wino_abl.sh name1:"-DFLAG" name2:"..." ...
+R=${GRAFT_REPO_ROOT:-/root/repo}
+for v in "$@"; do
+  name=${v%%:*}; flags=${v#*:}
+  export DWS_HIPCC_FLAGS_wavenet_wino="$flags"
+  touch $R/diffwave-sashimi_amd/csrc/wavenet_wino.hip; python $R/diffwave-sashimi_amd/build.py > /dev/null
+  echo "== $name ($flags): $(python $R/tools/wn_layer_times.py --reps 3 2>/dev/null | tail -1)"
+  DWS_WINO_TRACE=1 python $R/tools/wn_layer_times.py --reps 1 2>&1 | grep "d=256 " | head -1
+done
+unset DWS_HIPCC_FLAGS_wavenet_wino
+touch $R/diffwave-sashimi_amd/csrc/wavenet_wino.hip; python $R/diffwave-sashimi_amd/build.py > /dev/null
