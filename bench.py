@@ -68,7 +68,6 @@ CONFIGS = {
 }
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-MEASURED_F32_MFMA_TFLOPS = 141.6  # tools/ubench/coexec.hip, MFMA-only leg on this pool's MI355X: extra context only
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA (three bf16 MFMAs per fp32-equivalent product)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
@@ -94,6 +93,23 @@ def layer_algorithmic_work(cfg):
     m = cfg["model"]
     C, S, B, L = m["res_channels"], m["skip_channels"], cfg["B"], cfg["L"]
     return B * L * (14 * C * C + 2 * C * S), B * L * 4 * (2 * C + 2 * S)
+
+
+def wino_executed_work(cfg):
+    """MFMA flops the Winograd layer kernel (csrc/wavenet_wino.hip) really executes per launch, averaged over the
+    dilations of the stack: workgroups(d) = B * ceil(ceil(L / 2d) * d / 32) tiles of 32 position pairs, C/32 waves each,
+    per wave C/2 k-steps x 8 MFMAs (4 Winograd products x the tanh and the sigmoid row tile) + 8 (step-embedding / bias
+    k-step) for the convolution and (C/2 + 1) k-steps x 2 column tiles x (1 + S/C) row tiles for [res; skip];
+    4096 flop per v_mfma_f32_32x32x2_f32.  (Direct-conv algorithmic flops: layer_algorithmic_work.)"""
+    m = cfg["model"]
+    C, S, B, L = m["res_channels"], m["skip_channels"], cfg["B"], cfg["L"]
+    per_wave = (C // 2) * 8 + 8 + (C // 2 + 1) * 2 * (1 + S // C)
+    tot = 0
+    dil = [1 << (n % m["dilation_cycle"]) for n in range(m["num_res_layers"])]
+    for d in dil:
+        nblk = -(-L // (2 * d))
+        tot += B * (-(-(nblk * d) // 32)) * (C // 32) * per_wave * 4096
+    return tot / len(dil)
 
 
 def sashimi_tail_work(cfg):
@@ -219,7 +235,7 @@ def _cpu_model():
     return "unknown"
 
 
-def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
+def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
     red_dev = red_dev or dev
     """One data-parallel training step (`train.py:118-143`): q-sample + forward_train + MSE + backward through the
     HIP engine, bucketed asynchronous RCCL all-reduce of the gradients, Adam.  Synthetic audio
@@ -257,6 +273,10 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
     mine = time.perf_counter() - t0
     elapsed = ddist.max_over_ranks(mine, red_dev)
     per_rank_ms = [t / args.steps * 1e3 for t in ddist.gather_over_ranks(mine, red_dev)]
+    per_rank_loss = ddist.gather_over_ranks(float(loss.detach()), red_dev)      # each rank's own shard (seed 99 + rank)
+    with torch.no_grad():   # after the averaged steps every rank holds the same weights: digest of all parameters, per rank
+        digest = float(sum(p.detach().double().abs().sum() for p in net.parameters()))
+    per_rank_param_digest = ddist.gather_over_ranks(digest, red_dev)
     ms = elapsed / args.steps * 1e3
     roofline = None
     if world == 1 and not args.no_roofline:     # (an extra step on one rank only would hang the other ranks' all-reduce)
@@ -280,8 +300,9 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "ms_per_step_in_kernels": tot_ms.value,
                         "algorithmic_flops_per_step": flops,
                         "whole_step_frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    line = None
     if rank == 0:
-        print(json.dumps({
+        line = ({
             **({"roofline": roofline} if roofline else {}),
             "metric": "training audio samples/sec (train.py-style DP step: fwd + bwd + grad all-reduce + Adam)",
             "value": ddist.aggregate_throughput(B * L, world, ms * 1e-3), "unit": "audio samples/s", "n_gpus": world,
@@ -290,8 +311,16 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None):
             "config": {"workload": args.config + " training", "batch_per_gpu": B, "L": L,
                        "parallelism": "dp%d, bucketed asynchronous RCCL all-reduce of the gradients" % world},
             "per_rank_ms_per_step": per_rank_ms, "process_group": ddist.group_info(),
-            "final_loss": float(loss)}))
+            "per_rank_final_loss": per_rank_loss, "per_rank_param_digest": per_rank_param_digest,
+            "final_loss": float(loss)})
+    del net, opt
+    torch.cuda.empty_cache()
+    if not emit:
+        return line
+    if rank == 0:
+        print(json.dumps(line))
     ddist.shutdown()
+    return line
 
 
 def spawn_ranks(n):
@@ -313,10 +342,17 @@ def spawn_ranks(n):
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:
-        for p in procs:
-            rc = p.wait() or rc
-            if rc:                       # a dead rank leaves the others in a collective: stop them
-                break
+        # poll ALL ranks: a rank that dies leaves the others inside a collective, so they are stopped as soon as any
+        # exits non-zero (waiting for them in order would sit out the collective timeout on rank 0 first)
+        live = list(procs)
+        while live and not rc:
+            for p in list(live):
+                r = p.poll()
+                if r is not None:
+                    live.remove(p)
+                    rc = r or rc
+            if live and not rc:
+                time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -344,6 +380,7 @@ def main():
                          "(forward_train + backward + RCCL gradient all-reduce + Adam)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs of the default headline run")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -369,16 +406,57 @@ def main():
     red_dev = torch.device("cpu") if share else dev     # gloo reduces the timing scalar on the host
 
     from diffwave_sashimi_amd import _lib
-    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    _lib.load()  # no fallback: fails loudly without the HIP engine
+    if args.mode == "train":
+        return train_bench(args, cfg, world, rank, dev, ddist, red_dev)
+    result = sample_bench(args, cfg, world, rank, dev, ddist, red_dev)
+    if (rank == 0 and world == 1 and not args.no_extra and args.config == "wnet_h256_d36_T200" and not args.batch
+            and args.precision == "f32"):
+        # the other BASELINE configs, short legs in the same process (NOT `value`): C3, C4 sampling, C5's per-GPU training step
+        result["extra_configs"] = extra_legs(args, world, rank, dev, ddist, red_dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg)
+        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result))
+    ddist.barrier()   # rank 0's roofline / extra legs are done: every rank leaves the process group together
+    ddist.shutdown()
+
+
+def extra_legs(args, world, rank, dev, ddist, red_dev):
+    """BASELINE configs 3, 4 (sampling) and 5 (one GPU's share of the DP training step), a few seconds each, so that
+    the driver's default run evidences all of them: ms/step, throughput and the per-kernel roofline of each."""
+    import copy
+    out = {}
+    for name, steps, warmup in (("unet_d64_n6_T200", 40, 3), ("unet_d32_n6_T50_cond", 50, 3)):
+        a = copy.copy(args)
+        a.config, a.steps, a.warmup = name, steps, warmup
+        t0 = time.perf_counter()
+        r = sample_bench(a, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False)
+        out[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")
+                     if k in r}
+        out[name]["leg_seconds"] = time.perf_counter() - t0
+    a = copy.copy(args)
+    a.config, a.steps, a.warmup, a.mode, a.batch = "unet_d128_n6_T200", 4, 2, "train", None
+    t0 = time.perf_counter()
+    r = train_bench(a, dict(CONFIGS[a.config]), world, rank, dev, ddist, red_dev, emit=False)
+    out["unet_d128_n6_T200 --mode train"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
+                                                                "dtype", "config", "roofline", "final_loss") if k in r}
+    out["unet_d128_n6_T200 --mode train"]["leg_seconds"] = time.perf_counter() - t0
+    return out
+
+
+def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
+    """One sampling measurement (the headline, or an extra leg): returns the result line as a dict (rank 0 prints it)."""
     import ctypes
     import numpy as np
+    from diffwave_sashimi_amd import _lib
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
 
-    lib = _lib.load()  # no fallback: fails loudly without the HIP engine
+    lib = _lib.load()
     B, L = cfg["B"], cfg["L"]
     dcfg = cfg["diffusion"]
     T = dcfg["T"]
-    if args.mode == "train":
-        return train_bench(args, cfg, world, rank, dev, ddist, red_dev)
     net = build_model(cfg, dev)
     if args.precision != "f32":
         net.set_option("precision", args.precision)
@@ -425,6 +503,10 @@ def main():
                    "parallelism": "independent clips per GPU, no collective",
                    "sampler": "hipGraph replay, on-device Philox noise"},
         "per_rank_ms_per_step": per_rank_ms, "process_group": ddist.group_info(),
+        # every rank samples its own clips from its own Philox stream (`generate.py:217-227`): seeds and a digest of
+        # each rank's state after the timed steps, in rank order
+        "per_rank_seed": [int(v) for v in ddist.gather_over_ranks(float(seed), red_dev)],
+        "per_rank_state_digest": ddist.gather_over_ranks(float(x.double().abs().sum()), red_dev),
     }
 
     if rank == 0 and not args.no_roofline and cfg["model"]["_name_"] == "wavenet":
@@ -440,20 +522,28 @@ def main():
         _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
         lib.dws_profile_disable()
         avg_ms = tot_ms.value / max(n_launch.value, 1)
-        ach = flops / (avg_ms * 1e-3) / 1e12
+        wino = args.precision == "f32" and os.environ.get("DWS_WN_DIRECT") is None
+        # `achieved` / `frac` are priced on the flops the kernel EXECUTES (frac <= 1 by construction): the Winograd
+        # F(2,3) form does 8 C^2 instead of 12 C^2 flop per position for the convolution.  The direct-convolution
+        # algorithmic flops of SURVEY.md 8(d) over the same time are reported beside it as `effective_*`.
+        executed = wino_executed_work(cfg) if wino else flops
+        ach = executed / (avg_ms * 1e-3) / 1e12
+        eff = flops / (avg_ms * 1e-3) / 1e12
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r02_wavenet_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r03_wavenet_traffic.json" if wino else "r02_wavenet_traffic.json")
         if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and os.path.exists(tfile):
             # PMC-derived HBM bytes per launch of this kernel (collected with rocprofv3 in
             # separate --pmc passes on the same command; corrected as the guide prescribes)
             traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
+        kname = ("wn_layer_wino_kernel" if wino else "wn_layer_mfma_kernel") if args.precision == "f32" else "wn_layer_bf16x3_kernel"
         result["roofline"] = {
-            "kernel": "%s<%d,%d>" % ("wn_layer_mfma_kernel" if args.precision == "f32" else "wn_layer_bf16x3_kernel",
-                                     cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
+            "kernel": "%s<%d,%d>" % (kname, cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
             "frac": ach / peak, "traffic": traffic if args.precision == "f32" else None,
-            **({"frac_of_measured_mfma_ceiling": ach / MEASURED_F32_MFMA_TFLOPS,
-                "measured_mfma_ceiling": MEASURED_F32_MFMA_TFLOPS} if args.precision == "f32" else {}),
+            "executed_flops_per_launch": executed,
+            "effective_TFLOPs_on_direct_conv_flops": eff, "effective_frac": eff / peak,
+            "algorithm": ("Winograd F(2,3) along the dilation stride (4 K=C products per position pair instead of 6)"
+                          if wino else "direct 3-tap convolution"),
             "avg_launch_ms": avg_ms, "launches_timed": n_launch.value,
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
             "hbm_achieved_GBs": bytes_ / (avg_ms * 1e-3) / 1e9,
@@ -475,7 +565,6 @@ def main():
             result["roofline"] = {
                 "kernel": "s4_tail_mfma_kernel<H,...> (all %d block launches of a step)" % nblocks, "bound": "mfma",
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "frac_of_measured_mfma_ceiling": ach / MEASURED_F32_MFMA_TFLOPS, "measured_mfma_ceiling": MEASURED_F32_MFMA_TFLOPS,
                 "traffic": None, "ms_per_step_in_kernel": step_ms, "launches_timed": n_launch.value,
                 "algorithmic_flops_per_step": flops, "algorithmic_bytes_per_step": bytes_,
                 "hbm_achieved_GBs": bytes_ / (step_ms * 1e-3) / 1e9,
@@ -497,7 +586,7 @@ def main():
                 "frac": fc_bytes / (fc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "ms_per_step_in_kernel": fc_ms,
                 "algorithmic_bytes_per_step": fc_bytes}
     if (rank == 0 and world == 1 and args.precision == "f32" and cfg["model"]["_name_"] == "wavenet"
-            and not args.no_roofline):
+            and not args.no_roofline and extras):
         # Additional, clearly separate measurement (NOT `value`): the opt-in bf16x3 matrix arithmetic
         # (3-term bf16 split, fp32 accumulate, ~1e-5 relative vs the reference; tests/test_wavenet_gpu.py).
         net.set_option("precision", "bf16x3")
@@ -511,14 +600,9 @@ def main():
         result["extra_bf16x3"] = {"ms_per_step": ms3, "value": B * L / (T * ms3 * 1e-3), "unit": "audio samples/s",
                                   "note": "opt-in precision=bf16x3 (hi/lo bf16 MFMA inputs, fp32 accumulate); "
                                           "max rel err vs reference 1e-5; not the headline value"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg)
-        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
-
-    if rank == 0:
-        print(json.dumps(result))
-    ddist.barrier()   # rank 0's roofline leg is done: every rank leaves the process group together
-    ddist.shutdown()
+    del net
+    torch.cuda.empty_cache()
+    return result
 
 
 if __name__ == "__main__":

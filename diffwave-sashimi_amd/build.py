@@ -40,8 +40,33 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _extra_flags(stem):
+    extra = os.environ.get("DWS_HIPCC_FLAGS_" + stem)      # experiments: override a file's extra flags
+    return FILE_FLAGS.get(stem, []) if extra is None else extra.split()
+
+
+def _compile_cmd(hipcc, src):
+    stem = os.path.basename(src)[:-4]
+    return [hipcc] + FLAGS + _extra_flags(stem) + ["-c", src, "-o", _obj(src)]
+
+
+def _cmd_key(src):
+    # flags only (no paths: the tree is copied to another directory on the GPU box)
+    return " ".join(FLAGS + _extra_flags(os.path.basename(src)[:-4]))
+
+
+def _cmd_changed(hipcc, src):
+    """An object is also stale when it was built with a different command line (FLAGS, FILE_FLAGS or a
+    DWS_HIPCC_FLAGS_<stem> experiment): the command is kept in a sidecar next to the object."""
+    try:
+        return open(_obj(src) + ".cmd").read() != _cmd_key(src)
+    except OSError:
+        return True
+
+
 def needs_build():
-    return _stale(LIB, sources() + _headers())
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return _stale(LIB, sources() + _headers()) or any(_cmd_changed(hipcc, s) for s in sources())
 
 
 def build(force=False, verbose=False):
@@ -51,23 +76,24 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = _headers()
-    todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
+    todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs) or _cmd_changed(hipcc, s)]
 
     def compile_one(src):
-        stem = os.path.basename(src)[:-4]
-        extra = os.environ.get("DWS_HIPCC_FLAGS_" + stem)      # experiments: override a file's extra flags
-        extra = FILE_FLAGS.get(stem, []) if extra is None else extra.split()
-        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", _obj(src)]
+        cmd = _compile_cmd(hipcc, src)
         if verbose:
             print(" ".join(cmd), flush=True)
+        if os.path.exists(_obj(src) + ".cmd"):
+            os.remove(_obj(src) + ".cmd")
         proc = subprocess.run(cmd, capture_output=True, text=True)
         if proc.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, proc.stdout[-4000:], proc.stderr[-8000:]))
+        with open(_obj(src) + ".cmd", "w") as f:
+            f.write(_cmd_key(src))
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(compile_one, todo))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in sources()] + \
-          ["-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
+          ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)

@@ -7,7 +7,7 @@
 // `s4.py:1388`) and, in set_condition(), the mel conditioner terms.
 // The per-step path is then LN+emb -> rocFFT r2c -> spectrum multiply -> c2r ->
 // D-skip+GELU -> 1x1+GLU+residual -> LN -> FF -> residual per block.
-#include <hipfft/hipfft.h>
+#include <rocfft/rocfft.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -25,31 +25,68 @@ namespace dws {
 
 #define DWS_FFT(expr)                                                                                  \
     do {                                                                                               \
-        hipfftResult _r = (expr);                                                                      \
-        if (_r != HIPFFT_SUCCESS)                                                                      \
-            return set_error(DWS_ERR_HIP, "%s failed: hipfftResult %d (%s:%d)", #expr, (int)_r, __FILE__, __LINE__); \
+        rocfft_status _r = (expr);                                                                     \
+        if (_r != rocfft_status_success)                                                               \
+            return set_error(DWS_ERR_HIP, "%s failed: rocfft_status %d (%s:%d)", #expr, (int)_r, __FILE__, __LINE__); \
     } while (0)
 
+// rocFFT, through its native API: batched 1-D real transforms, out of place, unscaled, rows packed back to back (the
+// defaults of a plan without a description: input distance n reals / n/2+1 complex, output the other way round).  Used
+// where the fused LDS FFT does not apply: the irfft(n = L) of the kernel generation (`s4.py:796-805`) and its adjoint,
+// and the R2C / C2R pair of stage lengths the fused kernels do not cover (odd lengths; more than 16384 taps).
+// A plan owns its work buffer and execution info, so rocfft_execute never allocates (it may run inside a stream capture).
+struct RocfftPlan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    DevBuf work;
+};
+
 struct FftPlans {
-    std::map<std::tuple<int, int, int>, hipfftHandle> plans;  // (type, n, batch)
+    std::map<std::tuple<int, int, int>, RocfftPlan*> plans;  // (type, n, batch)
+    bool setup_done = false;
     ~FftPlans() {
-        for (auto& kv : plans) hipfftDestroy(kv.second);
+        for (auto& kv : plans) {
+            if (kv.second->info) rocfft_execution_info_destroy(kv.second->info);
+            if (kv.second->plan) rocfft_plan_destroy(kv.second->plan);
+            delete kv.second;
+        }
+        if (setup_done) rocfft_cleanup();
     }
     // type 0: R2C rows of n reals (dist n) -> n/2+1 complex; type 1: C2R n/2+1 complex -> n reals (dist n)
-    int get(int type, int n, int batch, hipfftHandle* out) {
+    int get(int type, int n, int batch, RocfftPlan** out) {
         auto key = std::make_tuple(type, n, batch);
         auto it = plans.find(key);
         if (it == plans.end()) {
-            hipfftHandle h;
-            int nn[1] = {n};
-            int nr[1] = {n}, nc[1] = {n / 2 + 1};
-            if (type == 0)
-                DWS_FFT(hipfftPlanMany(&h, 1, nn, nr, 1, n, nc, 1, n / 2 + 1, HIPFFT_R2C, batch));
-            else
-                DWS_FFT(hipfftPlanMany(&h, 1, nn, nc, 1, n / 2 + 1, nr, 1, n, HIPFFT_C2R, batch));
-            it = plans.emplace(key, h).first;
+            if (!setup_done) {
+                DWS_FFT(rocfft_setup());
+                setup_done = true;
+            }
+            RocfftPlan* p = new RocfftPlan();
+            it = plans.emplace(key, p).first;      // owned by the map from here on (freed with it, also after an error)
+            const size_t len[1] = {(size_t)n};
+            DWS_FFT(rocfft_plan_create(&p->plan, rocfft_placement_notinplace,
+                                       type == 0 ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
+                                       rocfft_precision_single, 1, len, (size_t)batch, nullptr));
+            size_t wbytes = 0;
+            DWS_FFT(rocfft_plan_get_work_buffer_size(p->plan, &wbytes));
+            DWS_FFT(rocfft_execution_info_create(&p->info));
+            if (wbytes) {
+                DWS_TRY(p->work.ensure(wbytes));
+                DWS_FFT(rocfft_execution_info_set_work_buffer(p->info, p->work.p, wbytes));
+            }
         }
+        DWS_CHECK(it->second->plan && it->second->info, DWS_ERR_HIP, "rocFFT plan (type %d, n %d, batch %d) was not created", type, n, batch);
         *out = it->second;
+        return DWS_OK;
+    }
+    // one batched transform on stream s (the real inverse may use its input as scratch, as rocFFT documents)
+    int exec(int type, int n, int batch, void* in, void* out, hipStream_t s) {
+        RocfftPlan* p = nullptr;
+        DWS_TRY(get(type, n, batch, &p));
+        DWS_FFT(rocfft_execution_info_set_stream(p->info, (void*)s));
+        void* ib[1] = {in};
+        void* ob[1] = {out};
+        DWS_FFT(rocfft_execute(p->plan, ib, ob, p->info));
         return DWS_OK;
     }
 };
@@ -269,16 +306,58 @@ struct SashimiModel : dws_model {
         return launch_fold_weight_norm(P(p + ".weight_v"), P(p + ".weight_g"), out, O, inner, s);
     }
 
+    // length the kernel of a block was set up for (its `L` buffer): read back only when an int64 buffer was re-sent
+    int kernel_len(SLayer* l, hipStream_t s, int64_t* out) {
+        int64_t Lbuf = l->Lk;
+        if (l->Lk_version != int_params_version) {
+            DWS_HIP(hipMemcpyAsync(&Lbuf, P(l->prefix + ".layer.kernel.kernel.L"), 8, hipMemcpyDeviceToHost, s));
+            DWS_HIP(hipStreamSynchronize(s));
+            l->Lk_version = int_params_version;
+            l->Lk = (int)Lbuf;
+        }
+        *out = Lbuf;
+        return DWS_OK;
+    }
+
+    // rocFFT path of a stage: zero-padded input rows, spectrum, output rows, and the two plans (allocated here, never
+    // inside a stream capture)
+    int ensure_rocfft_stage(Stage* st) {
+        const size_t rows = (size_t)B * st->H, Ls = st->L;
+        const bool fresh = st->U.bytes < rows * 2 * Ls * 4;
+        DWS_TRY(st->U.ensure(rows * 2 * Ls * 4));
+        if (fresh) DWS_HIP(hipMemset(st->U.p, 0, rows * 2 * Ls * 4));  // zero padding of the FFT input rows
+        DWS_TRY(st->Uf.ensure(rows * (Ls + 1) * 8));
+        DWS_TRY(st->Y.ensure(rows * 2 * Ls * 4));
+        RocfftPlan* plan = nullptr;
+        DWS_TRY(fft.get(0, 2 * st->L, (int)B * st->H, &plan));
+        DWS_TRY(fft.get(1, 2 * st->L, (int)B * st->H, &plan));
+        return DWS_OK;
+    }
+
+    // prepare() picks the segmented convolution from the CONFIGURED stage length; a checkpoint whose kernels were set
+    // up for a longer l_max (its `L` buffers) can carry more taps than one segment holds: such a stage runs on rocFFT
+    int resolve_segmented_stages(hipStream_t s) {
+        for (auto* l : all) {
+            if (l->kind != L_BLOCK) continue;
+            Stage* st = stages[l->stage];
+            if (!st->seg) continue;
+            int64_t Lk = 0;
+            DWS_TRY(kernel_len(l, s, &Lk));
+            if (Lk > 0 && !fftconv_seg_supported(st->L, (int)std::min<int64_t>(st->L, Lk))) {
+                st->seg = false;
+                drop_graph();
+                DWS_TRY(ensure_rocfft_stage(st));
+            }
+        }
+        return DWS_OK;
+    }
+
     // S4 convolution kernel of one block: parameters -> K_f   (s4.py:704-807, 1391-1403)
     int build_kernel(SLayer* l, hipStream_t s) {
         const int H = l->H, L = l->L, N = NS;
         const std::string k = l->prefix + ".layer.kernel.kernel";
-        int64_t Lbuf = l->Lk;
-        if (l->Lk_version != int_params_version) {   // read back only when an int64 buffer was re-sent (not every step)
-            DWS_HIP(hipMemcpyAsync(&Lbuf, P(k + ".L"), 8, hipMemcpyDeviceToHost, s));
-            DWS_HIP(hipStreamSynchronize(s));
-            l->Lk_version = int_params_version;
-        }
+        int64_t Lbuf = 0;
+        DWS_TRY(kernel_len(l, s, &Lbuf));
         // the kernel is generated at its own length l_max; a run uses its first min(L, l_max) taps per direction
         // (`L_kernel`, s4.py:1387,805): shorter inputs truncate it, longer inputs keep l_max taps
         DWS_CHECK(Lbuf > 0 && Lbuf < (1 << 28), DWS_ERR_STATE,
@@ -305,10 +384,7 @@ struct SashimiModel : dws_model {
         DWS_TRY(launch_cauchy_sym_fwd_bcast(bv.f(), P(zname), bw.f(), br.f(), 6 * H, N, Lh, H, s));
         DWS_TRY(launch_s4_woodbury(br.f(), P(oname), bd.f(), ckf.f(), H, Lh, (Lk % 2) == 0, s));
         l->cache_version = keep_cauchy ? commit_version + 1 : ~0ull;   // commit() bumps commit_version when it is done
-        hipfftHandle plan;
-        DWS_TRY(fft.get(1, Lk, 2 * H, &plan));
-        DWS_FFT(hipfftSetStream(plan, s));
-        DWS_FFT(hipfftExecC2R(plan, (hipfftComplex*)ckf.p, (hipfftReal*)ck.p));
+        DWS_TRY(fft.exec(1, Lk, 2 * H, ckf.p, ck.p, s));
         int lg = 0;
         if (fftconv_supported(L, &lg) && !getenv("DWS_SASHIMI_ROCFFT")) {
             // fused path: spectrum at the power-of-two size Nf = 2M with the anti-causal half re-placed,
@@ -354,9 +430,7 @@ struct SashimiModel : dws_model {
             DWS_TRY(cK.ensure((size_t)H * 2 * L * 4));
             DWS_TRY(l->Kf.ensure((size_t)H * (L + 1) * 8));
             DWS_TRY(launch_s4_twosided(ck.f(), cK.f(), H, L, Lk, Lt, s));
-            DWS_TRY(fft.get(0, 2 * L, H, &plan));
-            DWS_FFT(hipfftSetStream(plan, s));
-            DWS_FFT(hipfftExecR2C(plan, (hipfftReal*)cK.p, (hipfftComplex*)l->Kf.p));
+            DWS_TRY(fft.exec(0, 2 * L, H, cK.p, l->Kf.p, s));
             l->log2m = 0;
             l->seg = false;
             stages[l->stage]->rocfft = true;
@@ -365,6 +439,7 @@ struct SashimiModel : dws_model {
     }
 
     int commit(hipStream_t s) override {
+        if (B > 0) DWS_TRY(resolve_segmented_stages(s));
         DWS_TRY(Wi.ensure((size_t)D * Cin * 4));
         DWS_TRY(fold("init_conv.0.conv", Wi.f(), D, Cin, s));
         DWS_TRY(Wt_all.ensure((size_t)pt_total * Eout * 4));
@@ -446,7 +521,7 @@ struct SashimiModel : dws_model {
         for (int p : pool) span *= p;
         DWS_CHECK(nL % span == 0, DWS_ERR_INVALID, "sashimi: input length %lld is not divisible by the pooling factors (%d)",
                   (long long)nL, span);
-        if (nB != B || nL != L) { drop_graph(); melBm = 0; }
+        if (nB != B || nL != L) { drop_graph(); melBm = 0; trained_fwd = false; }
         if (nL != L) {
             // variable-length run (s4.py:1387): every stage length scales with the input; the S4 kernels keep their
             // own length (the `L` buffers) and contribute min(run, l_max) taps per direction
@@ -467,11 +542,8 @@ struct SashimiModel : dws_model {
             st->seg = no_fused && !getenv("DWS_SASHIMI_ROCFFT") && fftconv_seg_supported((int)Ls, std::min((int)Ls, st->L0));
             const bool need_rocfft = no_fused && !st->seg;
             if (need_rocfft) {
-                const bool fresh = st->U.bytes < rows * 2 * Ls * 4;
-                DWS_TRY(st->U.ensure(rows * 2 * Ls * 4));
-                if (fresh) DWS_HIP(hipMemset(st->U.p, 0, rows * 2 * Ls * 4));  // zero padding of the FFT input rows
-                DWS_TRY(st->Uf.ensure(rows * (Ls + 1) * 8));
-                DWS_TRY(st->Y.ensure(rows * 2 * Ls * 4));
+                B = nB;
+                DWS_TRY(ensure_rocfft_stage(st));
             } else {
                 DWS_TRY(st->y.ensure(rows * Ls * 4));
             }
@@ -487,14 +559,6 @@ struct SashimiModel : dws_model {
             if (l->kind != L_BLOCK) pool_max = std::max(pool_max, std::max((size_t)B * l->H * l->L, n) * 4);
         }
         DWS_TRY(pool_scr.ensure(pool_max));
-        // FFT plans allocate: create them here, never inside a stream capture
-        for (auto* st : stages) {
-            int lg = 0;
-            if ((fftconv_supported(st->L, &lg) && !getenv("DWS_SASHIMI_ROCFFT")) || st->seg) continue;
-            hipfftHandle plan;
-            DWS_TRY(fft.get(0, 2 * st->L, (int)B * st->H, &plan));
-            DWS_TRY(fft.get(1, 2 * st->L, (int)B * st->H, &plan));
-        }
         DWS_TRY(x_init.ensure((size_t)B * D * L * 4));
         DWS_TRY(nfin.ensure((size_t)B * D * L * 4));
         DWS_TRY(emb.ensure((size_t)B * Ein * 4));
@@ -578,19 +642,14 @@ struct SashimiModel : dws_model {
         }
         DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->U.f(), nB, H, Ls,
                           (size_t)2 * Ls, s));
-        hipfftHandle plan;
-        DWS_TRY(fft.get(0, 2 * Ls, nB * H, &plan));
-        DWS_FFT(hipfftSetStream(plan, s));
         {
             ProfileScope ps("rocfft_r2c", s);
-            DWS_FFT(hipfftExecR2C(plan, (hipfftReal*)st->U.p, (hipfftComplex*)st->Uf.p));
+            DWS_TRY(fft.exec(0, 2 * Ls, nB * H, st->U.p, st->Uf.p, s));
         }
         DWS_TRY(launch_spec_mul(st->Uf.f(), l->Kf.f(), nB, H, Ls + 1, s));
-        DWS_TRY(fft.get(1, 2 * Ls, nB * H, &plan));
-        DWS_FFT(hipfftSetStream(plan, s));
         {
             ProfileScope ps("rocfft_c2r", s);
-            DWS_FFT(hipfftExecC2R(plan, (hipfftComplex*)st->Uf.p, (hipfftReal*)st->Y.p));
+            DWS_TRY(fft.exec(1, 2 * Ls, nB * H, st->Uf.p, st->Y.p, s));
         }
         DWS_TRY(launch_s4_post(st->Y.f(), st->U.f(), P(p + ".layer.D"), st->g.f(), nB, H, Ls, s));
         return run_tail(l, st, x, addend, next, s);
@@ -666,6 +725,7 @@ struct SashimiModel : dws_model {
     // Sashimi.forward (sashimi.py:277-313)
     int forward(const float* audio, const float* steps, float* out, hipStream_t s) override {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
+        trained_fwd = false;   // this forward (eval call, or a step of the sampler) overwrites the activations a pending backward needs
         if (dirty) DWS_TRY(commit(s));
         DWS_TRY(launch_init_conv(audio, Wi.f(), P("init_conv.0.conv.bias"), x_init.f(), (int)B, Cin, D, (int)L, s));
         DWS_TRY(launch_step_embed(steps, freq.f(), emb.f(), (int)B, Ein / 2, s));
@@ -974,16 +1034,11 @@ struct SashimiModel : dws_model {
         c.B = nB; c.H = H; c.L = Ls; c.bchunk = bchunk;
         DWS_TRY(launch_fftcorr(l->log2m, c, s));
         DWS_TRY(launch_sum_leading(fpart.f(), dKf.f(), (size_t)H * (M + 1) * 2, nchunks, 1.f, s));
-        hipfftHandle plan_;
-        DWS_TRY(fft.get(1, Nf, H, &plan_));
-        DWS_FFT(hipfftSetStream(plan_, s));
-        DWS_FFT(hipfftExecC2R(plan_, (hipfftComplex*)dKf.p, (hipfftReal*)dKt.p));
+        DWS_TRY(fft.exec(1, Nf, H, dKf.p, dKt.p, s));
         // dK_t = C2R / Nf; k enters K as k / L (s4_twosided_pow2); dD[h] = sum u da = dK_t[h][0]
         DWS_TRY(launch_s4_twosided_pow2_bwd(dKt.f(), dkt.f(), G(l->prefix + ".layer.D"), H, Ls, Nf,
                                             1.f / ((float)Nf * (float)Ls), 1.f / (float)Nf, s));
-        DWS_TRY(fft.get(0, Ls, 2 * H, &plan_));
-        DWS_FFT(hipfftSetStream(plan_, s));
-        DWS_FFT(hipfftExecR2C(plan_, (hipfftReal*)dkt.p, (hipfftComplex*)dkf.p));
+        DWS_TRY(fft.exec(0, Ls, 2 * H, dkt.p, dkf.p, s));
         // v, w dt, dt, r of this block: kept by build_kernel when this commit already ran in training mode, else regenerated
         const bool cached = l->cache_version == commit_version && l->t_cr.p;
         DevBuf& bv = cached ? l->t_cv : cv;

@@ -241,7 +241,7 @@ struct WaveNetModel : dws_model {
     int prepare(int64_t nB, int64_t nL) override {
         DWS_CHECK(nB > 0 && nL > 0, DWS_ERR_INVALID, "prepare: B=%lld L=%lld", (long long)nB, (long long)nL);
         DWS_CHECK(nB * nL * (int64_t)std::max(2 * C, S) < (int64_t)1 << 40, DWS_ERR_UNSUPPORTED, "workspace too large");
-        if (nB != B || nL != L) { drop_graph(); melBm = 0; }
+        if (nB != B || nL != L) { drop_graph(); melBm = 0; trained_fwd = false; }
         B = nB; L = nL;
         const size_t act = (size_t)B * C * L * 4;
         DWS_TRY(x0.ensure(act));

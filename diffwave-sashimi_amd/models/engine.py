@@ -180,6 +180,7 @@ class EngineModule(nn.Module):
                 raise RuntimeError(f"diffusion_steps must hold B={B} entries, got {tuple(diffusion_steps.shape)}")
             return _EngineTrainFn.apply(self, audio, steps, mel_spec, *self.parameters())
         with torch.no_grad():
+            self._train_generation += 1      # an eval forward overwrites the activations of a pending training forward
             self._sync_params(L)
             self._prepare(B, L)
             self._set_condition(mel_spec)

@@ -162,6 +162,12 @@ class Sashimi(EngineModule):
         d.expand, d.ff, d.unet, d.L = self.expand, self.ff, 1 if self.unet else 0, self.L
         return d
 
+    def invalidate(self):
+        """Also forget the host copies of the kernels' ``L`` buffers: a ``.data`` write (``broadcast_state``) changes
+        them without touching the version counter."""
+        self._L_host.clear()
+        super().invalidate()
+
     def _kernel_L(self, k):
         """Host copy of a kernel's ``L`` buffer, re-read only when the buffer changed (in place, or replaced by
         ``.to()`` / ``load_state_dict``).  ``int(k.L)`` on a GPU buffer is a device-to-host copy that waits for everything

@@ -51,6 +51,7 @@ def sampling(net, size, diffusion_hyperparams, condition=None, *, x_T=None, nois
     if seed is None:
         seed = int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64).item())
     with torch.no_grad():
+        net._train_generation += 1     # the sampler's forwards overwrite the activations of a pending training forward
         net._sync_params(L)
         net._prepare(B, L)
         net._set_condition(condition)

@@ -92,19 +92,30 @@ def errors(got, ref):
     return {k: float((got[k].double() - r.double()).abs().max()) / _scale(r, gmax) for k, r in ref.items()}
 
 
-def compare(got, ref, truth64, fp32_impls=(), label="", kink=None):
+MAX_TOL = 3.5e-2        # the adaptive bound never opens wider than this, whatever the measured noise (the reference's own
+                        # fp32 gradient of c_layers.0.norm2.m sits 1.1e-2 from its float64 evaluation: 3x that)
+# the cancelling sums: LayerNorm shifts / scales, 1-input-channel weight_v, and the per-channel step size log_dt (a sum over all
+# frequencies and state indices of the kernel generator; the oracle's own fp32 autograd sits up to 8e-4 from float64 there)
+WIDEN_FAMILIES = ("norm1.m", "norm2.m", "norm.m", "norm1.s", "norm2.s", "norm.s", "weight_v", "kernel.log_dt")
+
+
+def compare(got, ref, truth64, fp32_impls=(), label="", kink=None, max_widened=3, families=WIDEN_FAMILIES):
     """`got` vs `ref` per tensor: 1e-3, or 3x the fp32 noise of that tensor measured as the distance of the given fp32
-    implementations (always including `ref`) from `truth64` (and `kink`, the output of `kink_noise`, if given).
+    implementations (always including `ref`) from `truth64` (and `kink`, the output of `kink_noise`, if given) -- capped
+    at MAX_TOL, USED (error beyond 1e-3) by at most `max_widened` tensors, and only for the known cancelling families (the LayerNorm
+    shifts / scales and 1-input-channel `weight_v`): a wrong reference or oracle cannot buy its own tolerance.
     Returns (worst error, its key)."""
     gmax = max(float(v.abs().max()) for v in truth64.values())
-    bad, worst, worst_k, rows = [], 0.0, None, []
+    bad, worst, worst_k, rows, widened = [], 0.0, None, [], []
     for k, r in ref.items():
         sc = _scale(truth64[k], gmax)
         noise = max(float((impl[k].double() - truth64[k]).abs().max()) / sc for impl in (ref, *fp32_impls))
         if kink is not None:
             noise = max(noise, kink[k])
         err = float((got[k].double() - r.double()).abs().max()) / sc
-        tol = max(TOL, 3.0 * noise)
+        tol = min(max(TOL, 3.0 * noise), MAX_TOL)
+        if err >= TOL:      # this tensor USES the widened bound
+            widened.append((k, tol, err))
         rows.append((err / tol, err, tol, noise, k))
         if err > worst:
             worst, worst_k = err, k
@@ -112,8 +123,36 @@ def compare(got, ref, truth64, fp32_impls=(), label="", kink=None):
             bad.append(f"{k}: err {err:.2e} >= tol {tol:.2e} (fp32 noise {noise:.2e})")
     rows.sort(reverse=True)
     print(f"{label}: closest to their bound: " + "; ".join(f"{k} {e:.1e}/{t:.1e}" for _, e, t, _, k in rows[:6]))
+    print(f"{label}: {len(widened)} of {len(ref)} tensors beyond {TOL:g} (inside their widened bound): "
+          + "; ".join(f"{k} tol {t:.1e} err {e:.1e}" for k, t, e in widened))
     assert not bad, f"{label}: {len(bad)} of {len(ref)} gradients off:\n" + "\n".join(bad[:30])
+    if max_widened is not None:
+        off_family = [k for k, _, _ in widened if not k.endswith(tuple(families))]
+        assert len(widened) <= max_widened and not off_family, \
+            f"{label}: {len(widened)} tensors beyond {TOL:g} (allowed: {max_widened}, families {families}): {widened}"
     return worst, worst_k
+
+
+def smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed, tries=6, kink_tol=1e-4):
+    """Seeded test inputs WITHOUT a ReLU pre-activation within fp32 rounding of its kink: tries (aseed, gseed),
+    (aseed + 1000, gseed + 1000), ... and keeps the first whose `kink_noise` stays below `kink_tol` for every tensor
+    (falls back to the smoothest one tried).  A gate that fp32 rounding may decide either way moves EVERY gradient by a
+    fixed amount (2.8e-3 on the old d32 inputs, reproduced to three digits by `kink_noise`); picking inputs away from the
+    kinks lets the engine be held to the plain 1e-3 instead of a widened bound.
+    Returns (audio, generator seed, loss_of, float64 gradients, kink noise, try index)."""
+    best = None
+    for i in range(tries):
+        a, g = aseed + 1000 * i, gseed + 1000 * i
+        audio = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(a)) * 0.3
+        loss_of = mse_training_loss(audio, dh, mel, generator=torch.Generator().manual_seed(g))
+        _, truth = oracle_grads(cfg, sd, loss_of, torch.float64)
+        kink = kink_noise(cfg, sd, loss_of, truth)
+        worst = max(kink.values())
+        if best is None or worst < best[0]:
+            best = (worst, audio, g, loss_of, truth, kink, i)
+        if worst < kink_tol:
+            break
+    return best[1:]
 
 
 def mse_training_loss(audio, dh, mel=None, seed=None, generator=None):

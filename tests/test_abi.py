@@ -71,3 +71,24 @@ def test_construct_model_restores_name_and_rejects_unknown():
     assert cfg["_name_"] == "wavenet"
     with pytest.raises(KeyError):
         construct_model(dict(cfg, _name_="transformer"))
+
+
+def test_cauchy_mult_module_is_importable_by_its_reference_name():
+    """`extensions/cauchy/cauchy.py:5` does `from cauchy_mult import ...`; the standalone binding must import (library
+    load + symbol binding, no GPU work) under exactly that top-level name and export the four entry points."""
+    import importlib
+    import os
+    import sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffwave-sashimi_amd", "extensions")
+    sys.path.insert(0, d)
+    try:
+        m = importlib.import_module("cauchy_mult")
+    finally:
+        sys.path.remove(d)
+    for name in ("cauchy_mult_fwd", "cauchy_mult_bwd", "cauchy_mult_sym_fwd", "cauchy_mult_sym_bwd"):
+        assert callable(getattr(m, name))
+    import torch
+    import pytest
+    with pytest.raises(RuntimeError):      # CHECK_DEVICE of `cauchy.cpp:6` without touching a GPU
+        m.cauchy_mult_sym_fwd(torch.zeros(1, 4, dtype=torch.complex64), torch.zeros(3, dtype=torch.complex64),
+                              torch.zeros(1, 4, dtype=torch.complex64))

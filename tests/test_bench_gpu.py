@@ -56,3 +56,56 @@ def test_two_ranks_aggregate(gpu):
     assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
     # whole-job aggregate: 2 ranks x (4 clips x 16000 samples / 200 steps) per step time
     assert abs(d["value"] - 2 * 4 * 16000 / (200 * d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_default_headline_line_carries_the_other_baseline_configs(gpu):
+    """The default command (what the driver runs) evidences BASELINE configs 3, 4 and 5 too: `extra_configs` holds a
+    short sampling leg for unet_d64 and the conditional unet_d32, and one GPU's training step of unet_d128, each with
+    its own ms/step and roofline; the WaveNet roofline prices the Winograd kernel on the flops it executes."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert REQUIRED <= set(d) and d["config"]["workload"] == "wnet_h256_d36_T200" and d["dtype"] == "f32"
+    rf = d["roofline"]
+    assert 0 < rf["frac"] < 1 and rf["executed_flops_per_launch"] < rf["algorithmic_flops_per_launch"]
+    assert abs(rf["achieved"] - rf["executed_flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * rf["achieved"]
+    assert rf["effective_TFLOPs_on_direct_conv_flops"] > rf["achieved"]
+    ex = d["extra_configs"]
+    assert set(ex) == {"unet_d64_n6_T200", "unet_d32_n6_T50_cond", "unet_d128_n6_T200 --mode train"}
+    for name, leg in ex.items():
+        assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["dtype"] == "f32", name
+        assert leg["roofline"]["bound"] == "mfma" and 0 < leg["roofline"]["frac"] < 1, name
+    for name in ("unet_d64_n6_T200", "unet_d32_n6_T50_cond"):
+        fc = ex[name]["roofline"]["fftconv"]
+        assert fc["bound"] == "hbm" and 0 < fc["frac"] < 1
+    c3 = ex["unet_d64_n6_T200"]
+    assert abs(c3["value"] - 16 * 16000 / (200 * c3["ms_per_step"] * 1e-3)) < 1e-6 * c3["value"]
+    tr = ex["unet_d128_n6_T200 --mode train"]
+    assert tr["config"]["batch_per_gpu"] == 32 and "whole_step_frac" in tr["roofline"]
+
+
+@pytest.mark.parametrize("mode", ["sample", "train"])
+def test_eight_ranks_from_the_plain_command(gpu, mode):
+    """`python bench.py --gpus 8` (no launcher: bench.py spawns its ranks) with all eight ranks on this box's one GPU over
+    gloo (DWS_BENCH_SHARE_GPU=1; the driver's node has one GPU per rank over RCCL, same code path otherwise): eight
+    per-rank timings, eight DISTINCT Philox seeds / states (sampling) or shard losses (training), identical weights on
+    every rank after the averaged steps, whole-job aggregate = 8 x per-rank units / slowest rank's time."""
+    env = dict(os.environ, DWS_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "wnet_h128_d30_T200", "--batch", "1",
+           "--steps", "2", "--warmup", "1", "--mode", mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert REQUIRED <= set(d) and d["n_gpus"] == 8 and d["scaling"] == "weak" and d["process_group"]["world_size"] == 8
+    assert len(d["per_rank_ms_per_step"]) == 8 and abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-6 * d["ms_per_step"] + 1e-9
+    assert "cpu_baseline" not in d and "extra_configs" not in d
+    if mode == "sample":
+        assert d["per_rank_seed"] == [1234 + r_ for r_ in range(8)]
+        assert len(set(d["per_rank_state_digest"])) == 8            # eight different sets of clips
+        assert abs(d["value"] - 8 * 1 * 16000 / (200 * d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    else:
+        assert len(set(d["per_rank_final_loss"])) == 8              # eight different shards
+        assert len(set(d["per_rank_param_digest"])) == 1            # one model: the gradients were averaged
+        assert abs(d["value"] - 8 * 1 * 16000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -89,3 +89,77 @@ def test_cauchy_broadcast_front_end_and_errors(gpu):
     e = ext.cauchy_mult_sym_fwd(torch.zeros(0, 4, dtype=torch.complex64, device=gpu), z.to(gpu),
                                 torch.zeros(0, 4, dtype=torch.complex64, device=gpu))
     assert e.shape == (0, 33)
+
+
+def _import_cauchy_mult_by_name():
+    """The way the reference gets it (`extensions/cauchy/cauchy.py:5`, `models/s4.py:35-42`): a top-level module
+    called `cauchy_mult` on sys.path -- here the standalone ctypes binding diffwave-sashimi_amd/extensions/cauchy_mult.py."""
+    import importlib
+    import os
+    import sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffwave-sashimi_amd", "extensions")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    return importlib.import_module("cauchy_mult")
+
+
+@pytest.mark.parametrize("N,L", [(4, 3), (16, 17), (64, 489), (64, 1024)])
+def test_cauchy_mult_module_by_its_reference_name(gpu, N, L):
+    """INTEGRATION.md section 1 as a test: `from cauchy_mult import cauchy_mult_fwd, cauchy_mult_bwd,
+    cauchy_mult_sym_fwd, cauchy_mult_sym_bwd` (the reference's import line) and the four entry points against the
+    committed fp64 answers (tests/golden/cauchy.npz, generated from the reference's formula + autograd)."""
+    cm = _import_cauchy_mult_by_name()
+    from cauchy_mult import cauchy_mult_bwd, cauchy_mult_fwd, cauchy_mult_sym_bwd, cauchy_mult_sym_fwd  # noqa: F401
+    assert cm.__name__ == "cauchy_mult" and "diffwave_sashimi_amd" not in cm.__name__
+    g = load_golden("cauchy")
+    t = f"sym/N{N}_L{L}"
+    v, z, w, dout = (torch.from_numpy(g[f"{t}/{k}"]).to(gpu) for k in ("v_half", "z", "w_half", "dout"))
+    out = cauchy_mult_sym_fwd(v, z, w)
+    dv, dw = cauchy_mult_sym_bwd(v, z, w, dout)
+    assert out.shape == (v.shape[0], L) and out.dtype == torch.complex64 and out.device == v.device
+    for got, key in ((out, "out"), (dv, "dv"), (dw, "dw")):
+        assert rel_err(torch.view_as_real(got), torch.view_as_real(torch.from_numpy(g[f"{t}/{key}"]))) < 1e-4, key
+    t = f"nonsym/N{N}_L{L}"
+    v, z, w, dout = (torch.from_numpy(g[f"{t}/{k}"]).to(gpu) for k in ("v", "z", "w", "dout"))
+    out = cauchy_mult_fwd(v, z, w)
+    dv, dw = cauchy_mult_bwd(v, z, w, dout)
+    for got, key in ((out, "out"), (dv, "dv"), (dw, "dw")):
+        assert rel_err(torch.view_as_real(got), torch.view_as_real(torch.from_numpy(g[f"{t}/{key}"]))) < 1e-4, key
+    # the reference's error behaviour at this boundary: TORCH_CHECK -> RuntimeError, unsupported N -> NotImplementedError
+    with pytest.raises(RuntimeError):
+        cauchy_mult_sym_fwd(v.cpu(), z, w)
+    with pytest.raises(RuntimeError):
+        cauchy_mult_sym_fwd(v, z, w[:, :-1])
+    with pytest.raises(NotImplementedError):
+        big = torch.zeros(1, 2048, dtype=torch.complex64, device=gpu)
+        cauchy_mult_sym_fwd(big, z, big)
+
+
+def test_reference_style_autograd_wrapper_over_cauchy_mult(gpu):
+    """What `extensions/cauchy/cauchy.py:80-111` builds on top of the module (an autograd.Function calling
+    cauchy_mult_sym_fwd / _bwd): gradients through it agree with the package's own wrapper."""
+    cm = _import_cauchy_mult_by_name()
+    from diffwave_sashimi_amd.extensions import cauchy as ext
+
+    class Sym(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, v, z, w):
+            ctx.save_for_backward(v, z, w)
+            return cm.cauchy_mult_sym_fwd(v, z, w)
+
+        @staticmethod
+        def backward(ctx, dout):
+            v, z, w = ctx.saved_tensors
+            dv, dw = cm.cauchy_mult_sym_bwd(v, z, w, dout)
+            return dv, None, dw
+
+    v_half, z, w_half = oc.generate_data(4, 64, 1000, symmetric=True, seed=11)
+    v1, w1 = v_half.to(gpu).requires_grad_(True), w_half.to(gpu).requires_grad_(True)
+    v2, w2 = v_half.to(gpu).requires_grad_(True), w_half.to(gpu).requires_grad_(True)
+    o1 = Sym.apply(v1, z.to(gpu), w1)
+    o2 = ext.cauchy_mult(v2, z.to(gpu), w2, symmetric=True)
+    assert torch.equal(o1, o2)
+    dout = torch.randn(o1.shape, dtype=torch.complex64, generator=torch.Generator().manual_seed(2)).to(gpu)
+    g1 = torch.autograd.grad(o1, (v1, w1), dout)
+    g2 = torch.autograd.grad(o2, (v2, w2), dout)
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])

@@ -172,3 +172,69 @@ def test_training_loss_staging_keeps_the_reference_rng_order():
     assert torch.equal(l1, l2) and torch.equal(g1.get_state(), g2.get_state())
     t = torch.arange(6.).view(2, 3)
     assert _stage(t, "cpu", "slot") is t or torch.equal(_stage(t, "cpu", "slot"), t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backbone", ["wavenet", "sashimi"])
+@pytest.mark.parametrize("between", ["eval_forward", "sampling", "other_shape"])
+def test_backward_after_an_interleaved_eval_forward_or_sampling_raises(gpu, backbone, between):
+    """The engine's activations are shared by every kind of forward: an eval forward, a sampling run or a call at another
+    shape between a training forward and its backward overwrites (or reallocates) them -- the backward must fail, on
+    both sides of the C ABI, instead of returning gradients of the wrong activations."""
+    import ctypes
+    from diffwave_sashimi_amd import _lib
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    from diffwave_sashimi_amd.training import training_loss
+    if backbone == "wavenet":
+        cfg, B, L = cases.wn_cfg(res_channels=64, skip_channels=64, num_res_layers=2, dilation_cycle=2), 2, 128
+    else:
+        cfg, B, L = cases.ss_cfg(d_model=8, n_layers=1, L=256, diffusion_step_embed_dim_mid=64), 2, 256
+    net = cases.build_ours(cfg, 5).to(gpu).train()
+    dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
+    audio = (torch.randn(B, 1, L, generator=torch.Generator().manual_seed(1)) * 0.3).to(gpu)
+    loss = training_loss(net, nn.MSELoss(), audio, dh, generator=torch.Generator().manual_seed(3))
+    if between == "eval_forward":
+        with torch.no_grad():
+            net((audio, torch.zeros(B, 1, device=gpu)))
+    elif between == "sampling":
+        sampling(net, (B, 1, L), calc_diffusion_hyperparams(2, 1e-4, 0.05), seed=1)
+    else:
+        with torch.no_grad():
+            net((audio[:1], torch.zeros(1, 1, device=gpu)))
+    with pytest.raises(RuntimeError, match="ONE training forward"):
+        loss.backward()
+    # and below the Python guard: the C ABI itself refuses (DWS_ERR_STATE)
+    d = torch.zeros(B, 1, L, device=gpu)
+    status = _lib.load().dws_model_backward(net._handle, d.data_ptr(), _lib.current_stream())
+    assert status != _lib.DWS_OK and b"forward_train" in _lib.load().dws_last_error()
+    # a fresh pair still works
+    net.zero_grad()
+    training_loss(net, nn.MSELoss(), audio, dh, generator=torch.Generator().manual_seed(3)).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_invalidate_forgets_the_cached_kernel_lengths():
+    """`broadcast_state` writes `t.data` (int64 `L` buffers included) without touching the version counter;
+    `invalidate()` is the documented escape hatch and must drop the host copies of `L` too."""
+    cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES["ss_tiny"]
+    net = cases.build_ours(cfg, wseed)
+    k = next(iter(net._blocks())).layer.kernel.kernel
+    k.L.fill_(50)
+    assert net._kernel_L(k) == 50
+    k.L.data.copy_(torch.tensor(64))       # invisible to ._version
+    assert net._kernel_L(k) == 50          # the stale copy: why invalidate() has to clear it
+    net.invalidate()
+    assert net._kernel_L(k) == 64
+
+
+def test_build_notices_changed_compile_flags(monkeypatch):
+    """`build.py` keeps the flags an object was compiled with in a sidecar: an experiment flag set through
+    DWS_HIPCC_FLAGS_<stem> (or an edit of FILE_FLAGS) makes that object stale instead of silently reusing it."""
+    from diffwave_sashimi_amd import build
+    if not os.path.exists(build.LIB):
+        pytest.skip("libdws.so not built")
+    assert not build.needs_build()
+    monkeypatch.setenv("DWS_HIPCC_FLAGS_common", "-DSOME_EXPERIMENT")
+    assert build.needs_build()
+    src = os.path.join(build.CSRC, "common.hip")
+    assert build._cmd_changed("hipcc", src) and not build._cmd_changed("hipcc", os.path.join(build.CSRC, "api.hip"))

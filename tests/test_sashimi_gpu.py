@@ -252,3 +252,33 @@ def test_tail_kernel_variants_agree(gpu, name, switch):
         del os.environ[switch]
     assert rel_err(base, other) < 1e-5
     assert torch.equal(base, _run(net, gpu, audio, steps, mel))
+
+
+def test_checkpoint_with_longer_kernels_than_configured_runs_long_inputs(gpu):
+    """A checkpoint whose S4 kernels were set up for a longer l_max than the model is configured with (its `L` buffers
+    say 32768, the config 16384): at a 65536-sample input the top stage is picked for the segmented convolution from the
+    CONFIGURED length, but the kernels carry 32768 taps per direction -- more than a segment holds.  The engine must
+    fall back to the rocFFT convolution for that stage (it used to abort with DWS_ERR_UNSUPPORTED), and agree with
+    the CPU oracle."""
+    long_cfg = cases.ss_cfg(d_model=8, n_layers=1, L=32768, diffusion_step_embed_dim_mid=64)
+    donor = cases.build_ours(long_cfg, 91)
+    donor._setup_C()                                   # C~ and L = 32768 / 8192 / 2048, as a checkpoint stores them
+    sd = {k: v.detach().clone() for k, v in donor.state_dict().items()}
+    short_cfg = dict(long_cfg, L=16384)
+    net = cases.build_ours(short_cfg, 92)
+    net.load_state_dict(sd)
+    net = net.to(gpu)
+    k = next(iter(net._blocks())).layer.kernel.kernel
+    assert int(k.L) == 32768
+    gen = torch.Generator().manual_seed(93)
+    audio, steps = torch.randn(1, 1, 65536, generator=gen), torch.tensor([[11.0]])
+    out = _run(net, gpu, audio, steps)
+    with torch.no_grad():
+        ref = osa.sashimi_forward({k_: v.cpu() for k_, v in net.state_dict().items()}, short_cfg, audio, steps)
+    assert rel_err(out.cpu(), ref) < REL_TOL
+    # shorter input afterwards: back on the fused paths, still right
+    audio2 = torch.randn(1, 1, 16384, generator=gen)
+    out2 = _run(net, gpu, audio2, steps)
+    with torch.no_grad():
+        ref2 = osa.sashimi_forward({k_: v.cpu() for k_, v in net.state_dict().items()}, short_cfg, audio2, steps)
+    assert rel_err(out2.cpu(), ref2) < REL_TOL

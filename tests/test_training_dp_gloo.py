@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the data-parallel gradient exchange and the
+"""CPU, world_size 2 and 8 over gloo: the data-parallel gradient exchange and the
 training-loss caller (row a19) around a differentiable net of the reference surface."""
 import json
 import os
@@ -50,10 +50,11 @@ same_after_bcast = all(torch.equal(r, p) for r, p in zip(ref0, after))
 dh = calc_diffusion_hyperparams(20, 1e-4, 0.05)
 opt = torch.optim.SGD(net.parameters(), lr=0.05)
 gall = torch.Generator().manual_seed(7)
-data = torch.randn(3, 4, 1, 32, generator=gall)          # 3 steps x global batch 4
+PB = int(os.environ["DWS_PER_RANK_BATCH"])
+data = torch.randn(3, PB * world, 1, 32, generator=gall)  # 3 steps x global batch PB * world
 losses = []
 for step in range(3):
-    shard = data[step, 2 * rank: 2 * rank + 2]
+    shard = data[step, PB * rank: PB * rank + PB]
     g = torch.Generator().manual_seed(1000 + 10 * step + rank)
     opt.zero_grad()
     loss = training_loss(net, nn.MSELoss(), shard, dh, generator=g)
@@ -75,13 +76,21 @@ def _free_port():
     return p
 
 
-def test_two_rank_dp_matches_single_process_full_batch(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world,PB", [(2, 2), (8, 1)])
+def test_dp_matches_single_process_full_batch(tmp_path, world, PB):
+    """world 2 (2 clips per rank) and world 8 (the node size of BASELINE config 5; 1 clip per rank): the DP result --
+    broadcast, bucketed all-reduce of the averaged gradients, 3 optimizer steps -- equals ONE process stepping on the
+    concatenated global batch."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, WORLD_SIZE="2", RANK=str(rank), MASTER_PORT=str(port), DWS_ROOT=ROOT, OMP_NUM_THREADS="1")
+    for rank in range(world):
+        env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(rank), MASTER_PORT=str(port), DWS_ROOT=ROOT,
+                   OMP_NUM_THREADS="1", DWS_PER_RANK_BATCH=str(PB))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
@@ -90,12 +99,13 @@ def test_two_rank_dp_matches_single_process_full_batch(tmp_path):
         assert p.returncode == 0, e[-3000:]
         outs.append(json.loads(o.strip().splitlines()[-1]))
     outs.sort(key=lambda d: d["rank"])
-    assert outs[0]["same_after_bcast"] and outs[1]["same_after_bcast"]
-    assert outs[0]["unused_grad_none"] and outs[1]["unused_grad_none"]
-    # both ranks hold identical parameters after 3 averaged steps, and the logged loss is the mean
-    for a, b in zip(outs[0]["params"], outs[1]["params"]):
-        assert np.allclose(a, b, rtol=0, atol=1e-7)
-    assert outs[0]["losses"] == outs[1]["losses"]
+    assert [o["rank"] for o in outs] == list(range(world))
+    assert all(o["same_after_bcast"] and o["unused_grad_none"] for o in outs)
+    # every rank holds identical parameters after 3 averaged steps, and the logged loss is the mean
+    for o in outs[1:]:
+        for a, b in zip(outs[0]["params"], o["params"]):
+            assert np.allclose(a, b, rtol=0, atol=1e-7)
+        assert outs[0]["losses"] == o["losses"]
 
     # single-process reference: the same 3 steps on the concatenated (global) batch
     import torch.nn as nn
@@ -121,18 +131,18 @@ def test_two_rank_dp_matches_single_process_full_batch(tmp_path):
     dh = calc_diffusion_hyperparams(20, 1e-4, 0.05)
     opt = torch.optim.SGD(net.parameters(), lr=0.05)
     gall = torch.Generator().manual_seed(7)
-    data = torch.randn(3, 4, 1, 32, generator=gall)
+    data = torch.randn(3, PB * world, 1, 32, generator=gall)
     for step in range(3):
         xs, ts, zs = [], [], []
-        for rank in range(2):               # the two shards draw (t, z) from their own seeded streams
+        for rank in range(world):           # the shards draw (t, z) from their own seeded streams
             g = torch.Generator().manual_seed(1000 + 10 * step + rank)
-            shard = data[step, 2 * rank: 2 * rank + 2]
-            t = torch.randint(20, size=(2, 1, 1), generator=g)
+            shard = data[step, PB * rank: PB * rank + PB]
+            t = torch.randint(20, size=(PB, 1, 1), generator=g)
             z = torch.normal(0, 1, size=shard.shape, generator=g)
             xs.append(q_sample(shard, t, dh["Alpha_bar"], z)); ts.append(t); zs.append(z)
         x, t, z = torch.cat(xs), torch.cat(ts), torch.cat(zs)
         opt.zero_grad()
-        loss = nn.MSELoss()(net((x, t.view(4, 1))), z)
+        loss = nn.MSELoss()(net((x, t.view(PB * world, 1))), z)
         assert abs(float(loss) - outs[0]["losses"][step]) < 1e-6
         loss.backward()
         opt.step()
