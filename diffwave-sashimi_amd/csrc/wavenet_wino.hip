@@ -127,15 +127,22 @@ struct WinoTile {
     static constexpr int WAVES = C / 32;          // one (tanh, sigmoid) tile pair per wave
     static constexpr int NTH = WAVES * 64;
     static constexpr int NP = 32;                 // position pairs per workgroup (64 positions)
-    static constexpr int KC = (C >= 256) ? 32 : 16;   // channels per staged chunk (C = 128: two workgroups per CU fit)
+    // channels per staged chunk = channels between two workgroup barriers.  C = 256: 64 (four barriers per tile; same box,
+    // 32 -> 64: 59.99 -> 58.42 ms per C2 step -- the two waves of a SIMD pay their per-chunk staging / transform /
+    // restart overhead at the same time, right after each barrier, so it does not hide behind the partner's MFMAs);
+    // C <= 128: 16, so that two workgroups fit a CU's LDS
+    static constexpr int KC = (C >= 256) ? 64 : 16;
     static constexpr int NCB = C / KC;
     static constexpr int MS = S / C;              // skip tiles per wave
     static constexpr int XS = KC * 4 * NP;        // floats of one chunk: raw [cc][s][j] / transformed [cc][j][4]
     static constexpr int G_FLOATS = C * 2 * NP;   // gate tile [C][32][2]: (first half, partner) of a pair adjacent
-    static constexpr int LDS_FLOATS = 4 * XS + G_FLOATS;
+    // the gate tile lives in the two raw buffers when it fits there (their last use is the transform of the last chunk,
+    // a chunk barrier before the gate is written)
+    static constexpr bool G_ALIAS = G_FLOATS <= 2 * XS;
+    static constexpr int LDS_FLOATS = 4 * XS + (G_ALIAS ? 0 : G_FLOATS);
     static constexpr int ITEMS = KC * NP / NTH;   // (channel, column) items per thread of the transform pass
-    static_assert(C % 32 == 0 && S % C == 0 && C % KC == 0 && KC % WAVES == 0 && (KC * NP) % NTH == 0 && 32 % KC == 0,
-                  "channel counts");
+    static_assert(C % 32 == 0 && S % C == 0 && C % KC == 0 && KC % (2 * WAVES) == 0 && (KC * NP) % NTH == 0 &&
+                  (32 % KC == 0 || KC % 32 == 0) && LDS_FLOATS * 4 <= 163840, "channel counts");
 };
 
 template <int C, int S, bool EXTRA>
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     float* const Xraw = lds;                 // 2 chunks of raw x (LDS-DMA target)
     float* const Tt = lds + 2 * XS;          // 2 chunks of Winograd-transformed x (B operands)
-    float* const gt = lds + 4 * XS;          // gate tile
+    float* const gt = T::G_ALIAS ? lds : lds + 4 * XS;   // gate tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -197,21 +204,41 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
         for (int m = 0; m < 1 + MS; ++m) av2[m] = a.bias2[mt2[m] * 32 + l31];
     }
 
-    // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 4 shifts (-d, 0, +d, +2d) x 32 columns of RAW x by LDS-DMA
-    // through one descriptor per channel row (num_records = L*4: a shifted position outside [0, L) reads 0 -- the conv's
-    // zero padding costs nothing).  One instruction moves two shifts of one row (lanes 0..31 / 32..63).
-    const int voffA = (p + (lhi - 1) * dil) * 4;   // shifts -d (lhi 0), 0 (lhi 1); negative -> huge unsigned -> reads 0
-    const int voffB = (p + (lhi + 1) * dil) * 4;   // shifts +d, +2d
-    constexpr int RPW = KC / WAVES;                // channel rows per wave and chunk
+    // ---- staging: chunk cb = channels [cb*KC, cb*KC+KC) x 4 shifts (-d, 0, +d, +2d) x 32 columns of RAW x by LDS-DMA,
+    // layout [row][shift][32].  A shifted position outside [0, L) must read 0 (the conv's zero padding).
+    //  * L % 4 == 0 and d >= 4: 16 bytes per lane, one instruction = two channel rows x four shifts (1 KiB); lanes whose
+    //    shifted position is out of range get an offset beyond the buffer (reads 0).  A quarter of the instructions of the
+    //    dword form -- each LDS-DMA costs ~100 cycles of issue beside MFMAs (nodma ablation: 4 k cycles per tile);
+    //  * otherwise: one dword per lane through one descriptor per channel row (num_records = L*4 bounds the row), one
+    //    instruction = two shifts of one row.
+    const bool x4 = (L % 4 == 0) && log2d >= 2;
+    constexpr int RPW = KC / WAVES;                // channel rows per wave and chunk (as pairs of adjacent rows)
+    __amdgpu_buffer_rsrc_t rXall = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
+    int voffA, voffB;
+    if (x4) {   // lane = (row parity, shift, column quad)
+        const int s4 = (lane >> 3) & 3, qq = q0 + 4 * (lane & 7);
+        const int pp = ((qq >> log2d) << (log2d + 1)) + (qq & (dil - 1)) + (s4 - 1) * dil;
+        voffA = ((unsigned)pp < (unsigned)L) ? (lhi * L + pp) * 4 : 0x7ffffff0;
+        voffB = 0;
+    } else {
+        voffA = (p + (lhi - 1) * dil) * 4;   // shifts -d (lhi 0), 0 (lhi 1); negative -> huge unsigned -> reads 0
+        voffB = (p + (lhi + 1) * dil) * 4;   // shifts +d, +2d
+    }
     auto stage_dma = [&](int cb) {
         float* xs = Xraw + (cb & 1) * XS;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int cc = wave + WAVES * i;
-            const int c = cb * KC + cc;
-            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)c * L), 0, L * 4, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + cc * 128, 4, voffA, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + cc * 128 + 64, 4, voffB, 0, 0, 0);
+        for (int i = 0; i < RPW / 2; ++i) {
+            const int cc = 2 * (wave + WAVES * i);
+            if (x4) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rXall, xs + cc * 128, 16, voffA, (cb * KC + cc) * L * 4, 0, 0);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)(cb * KC + cc + h) * L), 0, L * 4, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + (cc + h) * 128, 4, voffA, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + (cc + h) * 128 + 64, 4, voffB, 0, 0, 0);
+                }
+            }
         }
     };
 
@@ -241,11 +268,21 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
             t[0] = d0 - d2; t[1] = d1 + d2; t[2] = d2 - d1; t[3] = d1 - d3;
             tt[i] = t;
         }
-        if ((c1 * KC) / 32 == wave) {
+        if (KC >= 32) {
+            if ((wave * 32) / KC == c1) {         // the chunk holds all 32 res rows of this wave
+                const float* xw = xs + ((wave * 32) % KC) * 128 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* xr = xw + ((r & 3) + 8 * (r >> 2) + 4 * lhi) * 128;
+                    acc2[0][0][r] = xr[32];
+                    acc2[0][1][r] = xr[64];
+                }
+            }
+        } else if ((c1 * KC) / 32 == wave) {      // KC < 32: the wave's rows span 32 / KC chunks
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = (r & 3) + 8 * (r >> 2);            // + 4*lhi: never crosses a multiple of 8
-                if ((ch % 32) / KC == c1 % (32 / KC)) {           // compile-time per r once c1's parity is known
+                if ((ch % 32) / KC == c1 % ((32 / KC) > 0 ? (32 / KC) : 1)) {   // compile-time per r once c1's parity is known
                     const float* xr = xs + ((ch % KC) + 4 * lhi) * 128 + l31;
                     acc2[0][0][r] = xr[32];
                     acc2[0][1][r] = xr[64];
@@ -293,15 +330,12 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     transform(0);
     __syncthreads();
 
+    // (Measured and dropped, same box: doing the staging / transform of the two waves of a SIMD at different k-groups, so
+    // that one's non-MFMA work sits beside the other's MFMAs: 61.3 against 58.4 ms per step.)
     for (int cb = 0; cb < NCB; ++cb) {
-#ifndef WINO_ABL_NODMA
         if (cb + 2 < NCB) stage_dma(cb + 2);       // into the raw buffer chunk cb occupied (transformed an iteration ago)
-#endif
         if (cb + 1 < NCB) transform(cb + 1);
         const char* tb = reinterpret_cast<const char*>(Tt + (cb & 1) * XS) + lane16;
-#ifdef WINO_BPF
-        f32x4 t_nxt = *reinterpret_cast<const f32x4*>(tb);
-#endif
 #pragma unroll
         for (int it = 0; it < KC / 8; ++it) {
             const int kg = cb * (KC / 8) + it;
@@ -313,22 +347,12 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole k-group (32 MFMAs) ahead of its use
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                // B fragment of the NEXT k-step first: a wave running alone on its SIMD (its partner parked at the chunk
-                // barrier) then never waits for LDS between k-steps
-#ifdef WINO_BPF
-                const f32x4 t = t_nxt;
-                if (it * 4 + ks + 1 < KC / 2) t_nxt = *reinterpret_cast<const f32x4*>(tb + (it * 8 + ks * 2 + 2) * 512);
-#else
                 const f32x4 t = *reinterpret_cast<const f32x4*>(tb + (it * 8 + ks * 2) * 512);
-#endif
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j][ks], t[j], acc[m][j], 0, 0, 0);
-#ifdef WINO_KSCHED
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -336,13 +360,11 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
                 for (int j = 0; j < 4; ++j) a_cur[m][j] = a_nxt[m][j];
         }
         stamp(8 + 2 * cb);
-#ifndef WINO_ABL_NOBAR
         // transformed chunk cb+1 visible after the barrier; the LDS-DMA of chunk cb+2 must have landed too, and hipcc does
         // not count LDS-DMA among the accesses a barrier has to wait for: explicit vmcnt(0) (the only younger loads are
         // the A fragments of the next k-group, fetched a whole k-group ago)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
-#endif
         stamp(9 + 2 * cb);
     }
     stamp(2);
@@ -462,417 +484,6 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     }
 }
 
-// ---------------------------------------------------------------------------
-// v3: persistent workgroups, wave-private staging rows, 16-byte LDS-DMA, LDS-transposed 16-byte epilogue
-// ---------------------------------------------------------------------------
-// Same arithmetic as the kernel above.  What changes is everything around the MFMAs (measured with the phase trace,
-// `tools/wn_layer_times.py` + DWS_WINO_TRACE=1: at C = 256 a tile spent 238 k cycles of which 198 k are MFMA):
-//  * one workgroup per CU slot walks tiles bid, bid + G, ... (no relaunch gap, no per-tile setup of descriptors);
-//  * a wave stages AND transforms its own rows of a chunk, so the raw window needs no cross-wave ordering: one raw
-//    buffer, refilled as soon as the wave has read it; the chunk barrier only publishes the transformed rows;
-//  * the window moves as 16-byte LDS-DMA (two channel rows x four shifts per instruction, 1 KiB) when L % 4 == 0 and
-//    d >= 4: a quarter of the staging instructions (each costs ~100 cycles of issue beside MFMAs).  Zero padding then
-//    comes from a per-lane out-of-range offset instead of a per-row descriptor;
-//  * chunks of 64 channels at C = 256: four barriers per tile instead of eight;
-//  * EPI (C = 256): the skip tile is prefetched into LDS (16-byte LDS-DMA, issued under the first chunk), the skip
-//    accumulators are added to it there, and both outputs leave as 16-byte row-major stores (a dword store / atomic
-//    per lane is bound by the address path at ~16 B/clk/CU; the epilogue was 12 k cycles per tile).  Each wave owns
-//    the LDS slice of its own rows, so the epilogue needs no barrier.
-template <int C, int S, bool EPI>
-struct Wino3 {
-    static constexpr int WAVES = C / 32;
-    static constexpr int NTH = WAVES * 64;
-    static constexpr int KC = (C >= 256) ? 64 : 32;
-    static constexpr int NCB = C / KC;
-    static constexpr int MS = S / C;
-    static constexpr int RPW = KC / WAVES;             // rows of a chunk per wave (contiguous block)
-    static constexpr int XS = KC * 128;                // floats of one chunk
-    static constexpr int G_FLOATS = C * 64;
-    static constexpr int A_FLOATS = (2 * XS > G_FLOATS) ? 2 * XS : G_FLOATS;   // T0 | T1, aliased by the gate tile
-    static constexpr int E_FLOATS = EPI ? S * 64 : 0;
-    static constexpr int LDS_FLOATS = A_FLOATS + XS + E_FLOATS;
-    static_assert(C % 32 == 0 && S % C == 0 && C % KC == 0 && KC % WAVES == 0 && RPW % 2 == 0, "channel counts");
-    static_assert(LDS_FLOATS * 4 <= 163840, "LDS");
-};
-
-template <int C, int S, bool EXTRA, bool EPI>
-__global__ __launch_bounds__(C * 2, 2) void wn_layer_wino3_kernel(WnLayerArgs a, int log2d, int ntiles) {
-    using T = Wino3<C, S, EPI>;
-    constexpr int KC = T::KC, XS = T::XS, MS = T::MS, WAVES = T::WAVES, NCB = T::NCB, RPW = T::RPW;
-    constexpr int NKG = C / 8;
-    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
-    float* const Tt = lds;                   // two chunks of Winograd-transformed x (B operands)
-    float* const gt = lds;                   // gate tile [C][32][2] (after GEMM1)
-    float* const Xraw = lds + T::A_FLOATS;   // one chunk of raw x
-    float* const Ep = Xraw + XS;             // EPI: skip / output transposition tile [S][64]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int L = a.L, dil = 1 << log2d;
-    const int nblk = (L + 2 * dil - 1) >> (log2d + 1);
-    const int ntl = ((nblk << log2d) + 31) >> 5;
-    const bool x4 = (L % 4 == 0) && log2d >= 2;        // 16-byte staging
-    constexpr bool epi = EPI;                          // 16-byte epilogue through LDS (the launcher picks it when L % 4 == 0)
-    const bool first = a.first_layer, last = a.last_layer;
-    const int lane16 = lane * 16;
-    const int L4 = L * 4;
-    const int ldd = log2d < 5 ? log2d : 5, dd = 1 << ldd;    // pairs interleave inside a 64-block for d < 32
-
-    const int mt1[2] = {wave, C / 32 + wave};
-    int mt2[1 + MS];
-    mt2[0] = wave;
-#pragma unroll
-    for (int m = 0; m < MS; ++m) mt2[1 + m] = C / 32 + wave * MS + m;
-    __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A1, 0, 2 * C * 4 * C * 4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 4, 0x00020000);
-    float av2[1 + MS];
-#pragma unroll
-    for (int m = 0; m < 1 + MS; ++m) av2[m] = a.bias2[mt2[m] * 32 + l31];
-
-    for (int t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
-        // tiles of one round are spread so that an XCD (bid % 8) gets neighbouring tiles
-        const int round0 = t0 - blockIdx.x;
-        const int inround = (ntiles - round0 < (int)gridDim.x) ? ntiles - round0 : (int)gridDim.x;
-        const int tile = round0 + ((int)blockIdx.x < inround ? xcd_remap(blockIdx.x, inround) : 0);
-        const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
-        const int q0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
-        const int q = q0 + l31;
-        const int p = ((q >> log2d) << (log2d + 1)) + (q & (dil - 1));       // first-half position of this lane's column
-        const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
-        unsigned long long* __restrict__ trc = a.trace ? a.trace + ((size_t)tile * WAVES + wave) * 32 : nullptr;
-        auto stamp = [&](int i) {
-            if (trc) {
-                const unsigned long long t = __builtin_amdgcn_s_memtime();
-                if (lane == 0) trc[i] = t;
-            }
-        };
-        stamp(0);
-
-        float av1[2][4];
-        {
-            const float* Abt = a.Abt + (size_t)b * 4 * 2 * C;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int row = mt1[m] * 32 + l31;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float* src = (j == 1 && lhi) ? a.bias1 + row : Abt + j * 2 * C + row;
-                    av1[m][j] = *src;
-                }
-            }
-        }
-
-        // ---- staging of this wave's rows [wave*RPW, wave*RPW + RPW) of chunk cb into Xraw ([row][shift][32])
-        __amdgpu_buffer_rsrc_t rXall = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
-        // 16-byte form: lane = (row parity, shift, column quad); out-of-range shifted positions get an offset beyond the buffer
-        int voff4;
-        {
-            const int s4 = (lane >> 3) & 3, jq = lane & 7;
-            const int qq = q0 + 4 * jq;
-            const int pp = ((qq >> log2d) << (log2d + 1)) + (qq & (dil - 1)) + (s4 - 1) * dil;
-            voff4 = ((unsigned)pp < (unsigned)L) ? (lhi * L + pp) * 4 : 0x7ffffff0;
-        }
-        const int voffA = (p + (lhi - 1) * dil) * 4;
-        const int voffB = (p + (lhi + 1) * dil) * 4;
-        auto stage_dma = [&](int cb) {
-            if (x4) {
-#pragma unroll
-                for (int i = 0; i < RPW / 2; ++i) {
-                    const int cc = wave * RPW + 2 * i;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rXall, Xraw + cc * 128, 16, voff4, (cb * KC + cc) * L4, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    const int cc = wave * RPW + i;
-                    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)(cb * KC + cc) * L), 0, L * 4, 0x00020000);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, Xraw + cc * 128, 4, voffA, 0, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, Xraw + cc * 128 + 64, 4, voffB, 0, 0, 0);
-                }
-            }
-        };
-
-        // this wave's rows of raw chunk c1 -> t0..t3 in B-fragment order [cc][j][4]
-        auto transform = [&](int c1) {
-            f32x4* tt = reinterpret_cast<f32x4*>(Tt + (c1 & 1) * XS);
-#pragma unroll
-            for (int k = 0; k < RPW / 2; ++k) {
-                const int cc = wave * RPW + 2 * k + lhi;
-                const float* xr = Xraw + cc * 128 + l31;
-                const float d0 = xr[0], d1 = xr[32], d2 = xr[64], d3 = xr[96];
-                f32x4 t;
-                t[0] = d0 - d2; t[1] = d1 + d2; t[2] = d2 - d1; t[3] = d1 - d3;
-                tt[cc * 32 + l31] = t;
-            }
-        };
-        f32x16 acc[2][4];
-        f32x4 a_cur[2][4], a_nxt[2][4];
-        stage_dma(0);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a_cur[m][j] = wino_load_f4(rA1, lane16, ((mt1[m] * NKG) * 4 + j) * 1024);
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): own rows of chunk 0 landed
-        __syncthreads();                         // every wave is past GEMM2 of the previous tile (the gate tile aliases T)
-        stamp(1);
-        transform(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the raw rows are read, they may be refilled
-        __builtin_amdgcn_sched_barrier(0);
-        if (NCB > 1) stage_dma(1);
-        // skip tile of this wave's rows -> LDS (16-byte LDS-DMA, four rows of 64 columns per instruction; issued under the
-        // first chunk, below); columns are in position order: [p0, p0+32) then [p0+d, p0+d+32) for d >= 32, one contiguous
-        // block of 64 positions for d < 32
-        int voffE = 0;
-        if (EPI) {
-            const int c4 = 4 * (lane & 15);
-            const int pbase = (q0 >> log2d) << (log2d + 1);      // (= p(q0) for d < 32: q0 is a multiple of 32)
-            const int pos = (log2d >= 5) ? pbase + (q0 & (dil - 1)) + (c4 >= 32 ? dil + c4 - 32 : c4) : pbase + c4;
-            voffE = (pos < L) ? ((lane >> 4) * L + pos) * 4 : 0x7ffffff0;
-        }
-        {   // extra k-step per product (step embedding, conv bias), see the v2 kernel
-            const float v0 = ((unsigned)(p - dil) < (unsigned)L) ? 1.f : 0.f;
-            const float v1 = ((unsigned)p < (unsigned)L) ? 1.f : 0.f;
-            const float v2 = ((unsigned)(p + dil) < (unsigned)L) ? 1.f : 0.f;
-            const float v3 = ((unsigned)(p + 2 * dil) < (unsigned)L) ? 1.f : 0.f;
-            float bi[4];
-            bi[0] = lhi ? 0.f : v0 - v2;
-            bi[1] = lhi ? 1.f : v1 + v2;
-            bi[2] = lhi ? 0.f : v2 - v1;
-            bi[3] = lhi ? 0.f : v1 - v3;
-            f32x16 zero;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float av = (lhi && j != 1) ? 0.f : av1[m][j];
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bi[j], zero, 0, 0, 0);
-                }
-        }
-
-        __syncthreads();                         // transformed chunk 0 visible
-
-        // ---- GEMM1 over the chunks.  A wave transforms its rows of raw chunk cb+1 after the first k-group of chunk cb (their
-        // LDS-DMA was issued a whole chunk earlier) and refills the raw rows with chunk cb+2 straight away.
-        for (int cb = 0; cb < NCB; ++cb) {
-            const char* tb = reinterpret_cast<const char*>(Tt + (cb & 1) * XS) + lane16;
-#pragma unroll
-            for (int it = 0; it < KC / 8; ++it) {
-                const int kg = cb * (KC / 8) + it;
-                const int kgn = (kg + 1 < NKG) ? kg + 1 : kg;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a_nxt[m][j] = wino_load_f4(rA1, lane16, ((mt1[m] * NKG + kgn) * 4 + j) * 1024);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(tb + (it * 8 + ks * 2) * 512);
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][j][ks], t[j], acc[m][j], 0, 0, 0);
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a_cur[m][j] = a_nxt[m][j];
-                if (it == 0 && cb + 1 < NCB) {
-                    // own rows of raw chunk cb+1: everything older than the 8 A loads just issued has landed
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
-                    transform(cb + 1);
-                    __builtin_amdgcn_s_waitcnt(0xC07F);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (cb + 2 < NCB) stage_dma(cb + 2);
-                    if (EPI && cb == 0 && !first) {
-                        __amdgpu_buffer_rsrc_t rSkp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.skip + (size_t)b * S * L), 0, S * L * 4, 0x00020000);
-#pragma unroll
-                        for (int i = 0; i < MS * 8; ++i)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rSkp, Ep + (wave * MS * 32 + 4 * i) * 64, 16, voffE,
-                                                                     (wave * MS * 32 + 4 * i) * L4, 0, 0);
-                    }
-                }
-            }
-            __syncthreads();     // transformed chunk cb+1 visible / all reads of chunk cb done
-        }
-        stamp(2);
-
-        // ---- gate -> LDS [C][32][2] (aliases the transformed chunks: the loop's last barrier ordered their last reads)
-        const float* melb = (EXTRA && a.melc) ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            float g2[2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int pos = p + n * dil;
-                float ht, hs;
-                if (n == 0) {
-                    ht = (acc[0][0][r] + acc[0][1][r]) + acc[0][2][r];
-                    hs = (acc[1][0][r] + acc[1][1][r]) + acc[1][2][r];
-                } else {
-                    ht = (acc[0][1][r] - acc[0][2][r]) - acc[0][3][r];
-                    hs = (acc[1][1][r] - acc[1][2][r]) - acc[1][3][r];
-                }
-                if (EXTRA && melb && pos < L) {
-                    ht += melb[(size_t)ch * L + pos];
-                    hs += melb[(size_t)(C + ch) * L + pos];
-                }
-                if (EXTRA && a.hsave && pos < L) {
-                    float* __restrict__ hb = a.hsave + (size_t)b * 2 * C * L;
-                    hb[(size_t)ch * L + pos] = ht;
-                    hb[(size_t)(C + ch) * L + pos] = hs;
-                }
-                g2[n] = wino_gate(ht, hs);
-            }
-            *reinterpret_cast<float2*>(gt + (ch * 32 + l31) * 2) = make_float2(g2[0], g2[1]);
-        }
-        // ---- the residual's x rows of this wave, fetched after the gate arithmetic (the accumulators are free; L2-warm: the window
-        // just went through) so that they are there when the epilogue needs them: 16-byte loads in the epilogue's row-major layout, or per-lane dwords in the
-        // accumulator layout
-        f32x4 xq[EPI ? 8 : 1];
-        float xr[2][EPI ? 1 : 16];
-        if (!last) {
-            if constexpr (epi) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) xq[i] = wino_load_f4(rXall, voffE, (wave * 32 + 4 * i) * L4);
-            } else {
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int pos = p + n * dil;
-                    const int voff = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
-#pragma unroll
-                    for (int r = 0; r < (EPI ? 1 : 16); ++r)
-                        xr[n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rXall, voff, (wave * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
-                }
-            }
-        }
-
-        stamp(3);
-        __syncthreads();
-        stamp(4);
-
-        // ---- GEMM2
-        f32x16 acc2[1 + MS][2];
-#pragma unroll
-        for (int m = 0; m < 1 + MS; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
-        f32x4 c_cur[1 + MS], c_nxt[1 + MS];
-#pragma unroll
-        for (int m = 0; m < 1 + MS; ++m) c_cur[m] = wino_load_f4(rA2, lane16, (mt2[m] * NKG) * 1024);
-        {
-            const float one = lhi ? 0.f : 1.f;
-#pragma unroll
-            for (int m = 0; m < 1 + MS; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(lhi ? 0.f : av2[m], one, acc2[m][n], 0, 0, 0);
-        }
-        const char* gb = reinterpret_cast<const char*>(gt) + lane * 8;
-#pragma unroll 2
-        for (int kg = 0; kg < NKG; ++kg) {
-            const int kgn = (kg + 1 < NKG) ? kg + 1 : kg;
-#pragma unroll
-            for (int m = 0; m < 1 + MS; ++m) c_nxt[m] = wino_load_f4(rA2, lane16, (mt2[m] * NKG + kgn) * 1024);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float2 bf = *reinterpret_cast<const float2*>(gb + (kg * 8 + ks * 2) * 256);
-#pragma unroll
-                for (int m = 0; m < 1 + MS; ++m) {
-                    acc2[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][ks], bf.x, acc2[m][0], 0, 0, 0);
-                    acc2[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c_cur[m][ks], bf.y, acc2[m][1], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 1 + MS; ++m) c_cur[m] = c_nxt[m];
-        }
-        stamp(5);
-
-        // ---- epilogue
-        const float rs = 0.70710678118654752440f;
-        __amdgpu_buffer_rsrc_t rXo = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x_out + (size_t)b * C * L), 0, C * L * 4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rSk = __builtin_amdgcn_make_buffer_rsrc((void*)(a.skip + (size_t)b * S * L), 0, S * L * 4, 0x00020000);
-        if constexpr (epi) {
-            // column of (pair column j, half n) in position order
-            const int cbase = ((l31 >> ldd) << (ldd + 1)) + (l31 & (dd - 1));
-            float* Ew = Ep + (wave * MS * 32) * 64;
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // the skip prefetch (and everything else) has landed
-#pragma unroll
-            for (int m = 0; m < MS; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float* e = Ew + (m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 64 + cbase + n * dd;
-                        const float v = acc2[1 + m][n][r];
-                        *e = first ? v : *e + v;
-                    }
-#pragma unroll
-            for (int i = 0; i < MS * 8; ++i) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(Ew + (4 * i + (lane >> 4)) * 64 + 4 * (lane & 15));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rSk, voffE, (wave * MS * 32 + 4 * i) * L4, 0);
-            }
-            if (!last) {
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        Ew[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 64 + cbase + n * dd] = acc2[0][n][r];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(Ew + (4 * i + (lane >> 4)) * 64 + 4 * (lane & 15));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (xq[i][e] + v[e]) * rs;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rXo, voffE, (wave * 32 + 4 * i) * L4, 0);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int pos = p + n * dil;
-                const int voff = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
-                if (!last) {
-                    const int s0 = (wave * 32) * L4;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = (xr[n][EPI ? 0 : r] + acc2[0][n][r]) * rs;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rXo, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < MS; ++m) {
-                    const int s0 = ((wave * MS + m) * 32) * L4;
-                    if (first) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = acc2[1 + m][n][r];
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc2[1 + m][n][r], rSk, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
-                    }
-                }
-            }
-        }
-        stamp(6);
-        if (trc) {
-            __builtin_amdgcn_s_waitcnt(0);
-            stamp(7);
-        }
-    }
-}
-
 // DWS_WINO_TRACE=1 (tools only): stamp the phases of every wave of the first traced launch and print a summary
 template <typename F>
 static void wino_trace_launch(int nwg, int waves, WnLayerArgs a, hipStream_t s, F launch) {
@@ -926,57 +537,23 @@ static void wino_trace_launch(int nwg, int waves, WnLayerArgs a, hipStream_t s, 
         }
 }
 
-template <int C, int S, bool EPI>
-static int launch_wino3(const WnLayerArgs& a, int log2d, int ntiles, bool extra, bool trace, hipStream_t s);
-
 template <int C, int S>
 static int launch_wino_t(const WnLayerArgs& a, int log2d, hipStream_t s) {
     ProfileScope ps("wn_layer_wino", s);
+    using T = WinoTile<C, S>;
     const int dil = 1 << log2d;
     const int nblk = (a.L + 2 * dil - 1) / (2 * dil);
     const int ntl = (nblk * dil + 31) / 32;
     const int ntiles = a.B * ntl;
     static const bool trace = std::getenv("DWS_WINO_TRACE") != nullptr;
-    static const bool v2 = std::getenv("DWS_WINO_V2") != nullptr;
-    const bool extra = a.melc || a.hsave;
-    if (v2) {
-        using T = WinoTile<C, S>;
-        if (trace && !extra) {
-            wino_trace_launch(ntiles, T::WAVES, a, s, [&](const WnLayerArgs& at) {
-                hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, at, log2d);
-            });
-            return DWS_OK;
-        }
-        if (extra) hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, true>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
-        else hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
-        return DWS_OK;
-    }
-    if (C >= 256 && a.L % 4 == 0) return launch_wino3<C, S, (C >= 256)>(a, log2d, ntiles, extra, trace, s);
-    return launch_wino3<C, S, false>(a, log2d, ntiles, extra, trace, s);
-}
-
-template <int C, int S, bool EPI>
-static int launch_wino3(const WnLayerArgs& a, int log2d, int ntiles, bool extra, bool trace, hipStream_t s) {
-    using T = Wino3<C, S, EPI>;
-    // persistent grid: as many workgroups as the chip holds at once (registers: two waves per SIMD; LDS: see Wino3)
-    static int slots = 0;
-    if (slots == 0) {
-        int dev = 0, ncu = 0, per_cu = 0;
-        DWS_HIP(hipGetDevice(&dev));
-        DWS_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        DWS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wn_layer_wino3_kernel<C, S, false, EPI>, T::NTH, 0));
-        DWS_CHECK(ncu > 0 && per_cu > 0, DWS_ERR_HIP, "wn_layer_wino: occupancy query returned %d x %d", ncu, per_cu);
-        slots = ncu * per_cu;
-    }
-    const int grid = ntiles < slots ? ntiles : slots;
-    if (trace && !extra) {
+    if (trace && !(a.melc || a.hsave)) {
         wino_trace_launch(ntiles, T::WAVES, a, s, [&](const WnLayerArgs& at) {
-            hipLaunchKernelGGL((wn_layer_wino3_kernel<C, S, false, EPI>), dim3(grid), dim3(T::NTH), 0, s, at, log2d, ntiles);
+            hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, at, log2d);
         });
         return DWS_OK;
     }
-    if (extra) hipLaunchKernelGGL((wn_layer_wino3_kernel<C, S, true, EPI>), dim3(grid), dim3(T::NTH), 0, s, a, log2d, ntiles);
-    else hipLaunchKernelGGL((wn_layer_wino3_kernel<C, S, false, EPI>), dim3(grid), dim3(T::NTH), 0, s, a, log2d, ntiles);
+    if (a.melc || a.hsave) hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, true>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
+    else hipLaunchKernelGGL((wn_layer_wino_kernel<C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
     return DWS_OK;
 }
 
