@@ -561,6 +561,104 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
 }
 
 
+// 16-byte form of the kernel above (L and the X row stride multiples of 4).  What the dword form pays for, per chunk of
+// 64 positions and wave: 32 LDS-DMA instructions (~100 cycles of issue each beside MFMAs) and three ds_read_b32 per two
+// MFMAs.  Here
+//  * one LDS-DMA instruction moves 16 bytes per lane = four whole rows of a 128 x 64 operand tile (8 instructions per
+//    wave and chunk).  The rows then sit 64 floats apart, which would put every row of a column in one bank; so the
+//    16-byte quads of row r are stored rotated by r (slot (q + r) mod 16) -- the rotation happens on the GLOBAL side of
+//    the DMA (a lane's source address), the LDS side stays "lane l -> bytes [16 l, 16 l + 16)";
+//  * a lane reads one ds_read_b128 per operand and FOUR k-steps: the contraction index of MFMA e of block j is position
+//    8 j + 4 lhi + e for both operands (any pairing of positions with k is as good as any other).  The sixteen lanes a
+//    ds_read_b128 services together sit in sixteen different rows, i.e. sixteen different rotations: conflict-free.
+__global__ __launch_bounds__(512, 1) void wgrad_dma4_kernel(WgradArgs a) {
+    constexpr int PC = 64, TILE = 128 * PC;
+    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [2 buffers][dY tile | X tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wo = wave & 1, wc = wave >> 1;
+    const int o0 = blockIdx.x * 128, c0 = blockIdx.y * 128, split = blockIdx.z;
+    const int L = a.L, xL = a.xL ? a.xL : L;
+    const int chunks_per_b = (L + PC - 1) / PC;
+    const int total_chunks = a.B * chunks_per_b;
+    const int per = (total_chunks + a.nsplit - 1) / a.nsplit;
+    const int ch_begin = split * per, ch_end = min(total_chunks, ch_begin + per);
+    const bool do_bias = a.bias_part != nullptr && blockIdx.y == 0;
+    constexpr int OOB = 0x7ffffff0;
+    __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)((size_t)a.B * a.O * L * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)((size_t)a.B * a.C * xL * 4), 0x00020000);
+
+    // staging: instruction i of a wave fills rows 4 g .. 4 g + 3 (g = wave + 8 i) of a tile; lane = (row in group, slot);
+    // slot s of row r holds source quad (s - r) mod 16, and (s - r) mod 16 does not depend on i (32 i = 0 mod 16)
+    const int rsub = lane >> 4, srcq = ((lane & 15) - rsub - 4 * wave) & 15;
+    auto stage = [&](int ch, int buf) {
+        const int b = ch / chunks_per_b, l0 = (ch % chunks_per_b) * PC;
+        const int pos = l0 + 4 * srcq;
+        const int voffY = pos < L ? (rsub * L + pos) * 4 : OOB;
+        const int voffX = pos < L ? (rsub * xL + pos) * 4 : OOB;
+        float* sdy = wlds + buf * 2 * TILE;
+        float* sx = sdy + TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * (wave + 8 * i);      // rows past O / C feed outputs that are never stored
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, sdy + row * PC, 16, voffY, (b * a.O + o0 + row) * L * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, sx + row * PC, 16, voffX, (b * a.C + c0 + row) * xL * 4, 0, 0);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float bsum = 0.f;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int rowA = wo * 64 + l31, rowB = wc * 32 + l31;     // (rowA + 32 has the same rotation: 32 = 0 mod 16)
+
+    if (ch_begin < ch_end) stage(ch_begin, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int buf = (ch - ch_begin) & 1;
+        if (ch + 1 < ch_end) stage(ch + 1, buf ^ 1);
+        const float* sdy = wlds + buf * 2 * TILE;
+        const float* sx = sdy + TILE;
+        if (do_bias && tid < 128) {           // the row sum does not care about the rotation
+#pragma unroll
+            for (int q = 0; q < PC / 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sdy + tid * PC + 4 * ((q + tid) & 15));
+                bsum += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PC / 8; ++j) {
+            const int qa = (2 * j + lhi + rowA) & 15, qb = (2 * j + lhi + rowB) & 15;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sdy + rowA * PC + 4 * qa);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sdy + (rowA + 32) * PC + 4 * qa);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sx + rowB * PC + 4 * qb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bv[e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bv[e], acc[1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk ch+1 has landed (hipcc does not make a barrier wait for LDS-DMA)
+        __syncthreads();                      // ... for every wave, and buffer `buf` is free again
+    }
+    float* part = a.partial + (size_t)split * a.O * a.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wo * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int c = c0 + wc * 32 + l31;
+            if (o < a.O && c < a.C) part[(size_t)o * a.C + c] = acc[i][r];
+        }
+    if (do_bias && tid < 128 && o0 + tid < a.O) a.bias_part[(size_t)split * a.O + o0 + tid] = bsum;
+}
+
+
 // (A 256 x 128 / 128 x 256 output tile per workgroup -- no operand fetched twice by the two halves of a 2H dimension,
 // 0.79 GB instead of 1.05 GB per launch at H = 128, 32-position chunks with a swizzle on the global side -- was built and
 // measured SLOWER: 365 us against 316 us.  The kernel is not bound by those bytes.)
@@ -631,7 +729,17 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
     WgradArgs a = a_in;
     const dim3 grid(ceil_div(a.O, 128), ceil_div(a.C, 128), T * a.nsplit);
     static const bool no_dma = getenv("DWS_WGRAD_NO_DMA") != nullptr;
-    if (T == 1 && !a.xact && !a.addc && !no_dma) {
+    static const bool no_dma4 = getenv("DWS_WGRAD_NO_DMA4") != nullptr;
+    if (T == 1 && !a.xact && !a.addc && !no_dma && !no_dma4 && a.L % 4 == 0 && (a.xL ? a.xL : a.L) % 4 == 0 &&
+        ((size_t)a.dY | (size_t)a.X) % 16 == 0) {
+        constexpr int lds = 2 * 2 * 128 * 64 * 4;
+        static bool attr4 = false;
+        if (!attr4) {
+            DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr4 = true;
+        }
+        hipLaunchKernelGGL(wgrad_dma4_kernel, grid, dim3(512), lds, s, a);
+    } else if (T == 1 && !a.xact && !a.addc && !no_dma) {
         constexpr int lds = 2 * 2 * 128 * 66 * 4;
         static bool attr = false;
         if (!attr) {
