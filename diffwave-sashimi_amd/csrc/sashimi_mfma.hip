@@ -203,7 +203,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         mt_a[m] = mt_h[m];
         mt_b[m] = H / 32 + mt_h[m];
     }
-    __syncthreads();   // the barrier's release waits for the DMA (vmcnt(0))
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
+    __syncthreads();
 
     const float4* Ao = reinterpret_cast<const float4*>(a.Ao);
     {

@@ -64,11 +64,26 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int K = a.K0 + a.K1;
     const int ncb = K / KC;
 
+    // T = 1 with L % 4 == 0: the chunk moves as 16-byte LDS-DMA, four whole rows (4 x 64 positions) per instruction -- two
+    // instructions per wave and chunk instead of eight (each costs ~100 cycles of issue beside the chunk's 64 MFMAs per
+    // wave); positions past L get an offset beyond the buffer (read 0).  Otherwise one dword per lane through a per-row
+    // descriptor whose bounds check zero-fills the shifted taps.
+    const bool x4 = (T == 1) && (L % 4 == 0) && ((((size_t)a.src0) | ((size_t)a.src1)) % 16 == 0);
+    const int voff4 = (l0 + 4 * (lane & 15) < L) ? ((lane >> 4) * L + l0 + 4 * (lane & 15)) * 4 : 0x7ffffff0;
     auto stage_dma = [&](int cb, int buf) {
         float* xs = lds + buf * (ROWS * P);
         const int k0 = cb * KC;
         const float* base = (k0 < a.K0) ? a.src0 + ((size_t)b * a.K0 + k0) * L
                                         : a.src1 + ((size_t)b * a.K1 + (k0 - a.K0)) * L;
+        if (T == 1 && x4) {
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, KC * L * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < KC / 16; ++i) {
+                const int row = 4 * (wave + 4 * i);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + row * P, 16, voff4, row * L * 4, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int row = wave + 4 * i;
@@ -104,6 +119,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a_cur[m] = buf_load4(rA, lane16, (mt[m] * a.nkg_total) * 1024);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): hipcc does not make a barrier wait for LDS-DMA
     __syncthreads();
     const int nkg = ncb * (ROWS / 8);
     for (int cb = 0; cb < ncb; ++cb) {
@@ -131,6 +147,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // the LDS-DMA of chunk cb+1 (the only younger loads: the next k-group's A fragments)
         __syncthreads();
     }
 
@@ -526,6 +543,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
     float bsum = 0.f;
 
     if (ch_begin < ch_end) stage(ch_begin, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
     __syncthreads();
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int buf = (ch - ch_begin) & 1;
@@ -546,7 +564,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
         }
-        __syncthreads();   // chunk ch+1 has landed (the barrier waits for the DMA) and buffer `buf` is free again
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
+        __syncthreads();   // chunk ch+1 has landed and buffer `buf` is free again
     }
     float* part = a.partial + (size_t)split * a.O * a.C;
 #pragma unroll

@@ -209,12 +209,14 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
         ahi[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1) * 2048);
         alo[m] = buf_load_bf8(rA1, lane16, (mt1[m] * NKB1) * 2048 + 1024);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
     __syncthreads();                           // DMA(0), DMA(1) landed
 #pragma unroll
     for (int it = 0; it < T::NKBC; ++it) convert_slice(0, 0, it);
 
     for (int cb = 0; cb < T::NCB; ++cb) {
         // X(cb) complete, DMA(cb+1) landed; every wave is done with X(cb-1) and with the fp32 buffer of chunk cb
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
         __syncthreads();
         if (cb + 2 < T::NCB) stage_dma(cb + 2, cb & 1);
         const u32x4* xhi = reinterpret_cast<const u32x4*>(lds + T::F_FLOATS + (cb & 1) * T::XB_FLOATS);

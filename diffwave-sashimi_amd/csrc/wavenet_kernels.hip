@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     f32x4 a_cur[2 * MP], a_nxt[2 * MP];
 #pragma unroll
     for (int m = 0; m < 2 * MP; ++m) a_cur[m] = buf_load_f4(rA1, lane16, (mt1[m] * NKG1) * 1024);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
     __syncthreads();
 
     for (int cb = 0; cb < T::NCB; ++cb) {
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
 #pragma unroll
             for (int m = 0; m < 2 * MP; ++m) a_cur[m] = a_nxt[m];
         }
-        __syncthreads();  // (LDS-DMA of chunk cb+1 has landed: the barrier's release waits vmcnt(0))
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
+        __syncthreads();  // LDS-DMA of chunk cb+1 has landed (the only younger loads are the next k-group's A fragments)
     }
     // extra k-group: step-embedding correction rows
     {

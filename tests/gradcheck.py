@@ -133,15 +133,17 @@ def compare(got, ref, truth64, fp32_impls=(), label="", kink=None, max_widened=3
     return worst, worst_k
 
 
-def smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed, tries=6, kink_tol=1e-4):
+def smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed, tries=3, kink_tol=1e-4, start=0):
     """Seeded test inputs WITHOUT a ReLU pre-activation within fp32 rounding of its kink: tries (aseed, gseed),
     (aseed + 1000, gseed + 1000), ... and keeps the first whose `kink_noise` stays below `kink_tol` for every tensor
     (falls back to the smoothest one tried).  A gate that fp32 rounding may decide either way moves EVERY gradient by a
     fixed amount (2.8e-3 on the old d32 inputs, reproduced to three digits by `kink_noise`); picking inputs away from the
-    kinks lets the engine be held to the plain 1e-3 instead of a widened bound.
+    kinks lets the engine be held to the plain 1e-3 instead of a widened bound.  `start` skips tries already known to sit
+    on a kink (each try costs four float64 evaluations of the oracle); models with hundreds of thousands of ReLU inputs
+    (d_model = 128) have no kink-free inputs in reach -- those cases take `tries=1` and the bound of `compare`.
     Returns (audio, generator seed, loss_of, float64 gradients, kink noise, try index)."""
     best = None
-    for i in range(tries):
+    for i in range(start, start + tries):
         a, g = aseed + 1000 * i, gseed + 1000 * i
         audio = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(a)) * 0.3
         loss_of = mse_training_loss(audio, dh, mel, generator=torch.Generator().manual_seed(g))

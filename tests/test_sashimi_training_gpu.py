@@ -22,7 +22,7 @@ TRAIN_CASES = {
 }
 
 
-def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None):
+def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None, start=0, tries=3):
     """Engine gradients, the oracle's fp32 autograd and its FLOAT64 autograd (the rounding-noise yardstick of
     tests/gradcheck.py) on the same weights, audio, steps and noise."""
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
@@ -34,7 +34,7 @@ def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None):
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
     # inputs away from every ReLU kink (tests/gradcheck.py: smooth_case), so that the plain 1e-3 bound applies
-    audio, gseed, loss_of, truth, kink, tried = gradcheck.smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed)
+    audio, gseed, loss_of, truth, kink, tried = gradcheck.smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed, start=start, tries=tries)
     print(f"inputs: try {tried} (audio seed {aseed + 1000 * tried}), largest kink noise {max(kink.values()):.1e}")
     net = net.to(gpu).train()
     loss = training_loss(net, nn.MSELoss(), audio.to(gpu), dh, mel_spec=None if mel is None else mel.to(gpu),
@@ -55,7 +55,10 @@ def test_sashimi_parameter_gradients_match_autograd(gpu, name):
     cancelling sums where the oracle's own fp32 autograd is further than that from its float64 evaluation."""
     from tests import gradcheck
     cfg, B = TRAIN_CASES[name]
-    net, got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, gpu, 15, 19, 23)
+    # where the search for kink-free inputs starts / how long it may go on (found once with tests/gradcheck.smooth_case;
+    # d128: 390 k ReLU inputs, none of six tries is kink-free, so the first one is taken)
+    start, tries = {"d32": (2, 2), "d128": (0, 1)}.get(name, (0, 3))
+    net, got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, gpu, 15, 19, 23, start=start, tries=tries)
     assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
     worst, worst_k = gradcheck.compare(got, o32, truth, label=name, kink=kink)
     e64 = gradcheck.errors(got, truth)
@@ -94,7 +97,8 @@ def test_conditional_sashimi_gradients_match_autograd(gpu):
                        diffusion_step_embed_dim_mid=64)
     B, Tmel = 2, 4
     mel = torch.cat([cases.mel_inputs(1, Tmel, 41 + i) for i in range(B)])
-    net, got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, gpu, 35, 39, 43, mel=mel)
+    # (the LeakyReLU upsamplers see thousands of mel values: no kink-free inputs within reach -- first try, widened bound)
+    net, got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, gpu, 35, 39, 43, mel=mel, start=0, tries=1)
     assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
     worst, worst_k = gradcheck.compare(got, o32, truth, label="conditional", kink=kink)
     seen_cond = sum(("upsample_conv2d" in k or "mel_conv" in k) and float(v.abs().max()) > 0 for k, v in o32.items())

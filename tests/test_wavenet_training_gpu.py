@@ -23,7 +23,7 @@ TRAIN_CASES = {
 }
 
 
-def _engine_and_oracle(cfg, B, L, gpu, wseed, aseed, gseed, mel=None):
+def _engine_and_oracle(cfg, B, L, gpu, wseed, aseed, gseed, mel=None, start=0, tries=1):
     """Engine gradients, the oracle's fp32 autograd and its FLOAT64 autograd (rounding-noise yardstick,
     tests/gradcheck.py) on the same weights, audio, steps and noise."""
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
@@ -33,7 +33,7 @@ def _engine_and_oracle(cfg, B, L, gpu, wseed, aseed, gseed, mel=None):
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
     # inputs away from every ReLU kink (tests/gradcheck.py: smooth_case), so that the plain 1e-3 bound applies
-    audio, gseed, loss_of, truth, kink, tried = gradcheck.smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed)
+    audio, gseed, loss_of, truth, kink, tried = gradcheck.smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed, start=start, tries=tries)
     print(f"inputs: try {tried} (audio seed {aseed + 1000 * tried}), largest kink noise {max(kink.values()):.1e}")
     net = net.to(gpu).train()
     loss = training_loss(net, nn.MSELoss(), audio.to(gpu), dh, mel_spec=None if mel is None else mel.to(gpu),
@@ -49,7 +49,9 @@ def test_wavenet_parameter_gradients_match_autograd(gpu, name):
     """Per tensor 1e-3 of its largest gradient (widened to 3x the measured fp32 noise where that is larger)."""
     from tests import gradcheck
     cfg, B, L = TRAIN_CASES[name]
-    got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, L, gpu, 5, 9, 21)
+    # first try of tests/gradcheck.smooth_case whose inputs sit furthest from the ReLU kinks (found once, six tries each)
+    start = {"c128_s256": 4, "c256": 1}.get(name, 0)
+    got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, L, gpu, 5, 9, 21, start=start)
     assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
     worst, k = gradcheck.compare(got, o32, truth, label=name, kink=kink)
     print(f"{name}: worst parameter-gradient rel err {worst:.3e} ({k})")
@@ -93,7 +95,7 @@ def test_conditional_wavenet_gradients_match_autograd(gpu, name):
     from tests import gradcheck
     cfg, B, L, Tmel = COND_TRAIN_CASES[name]
     mel = torch.cat([cases.mel_inputs(1, Tmel, 31 + i) for i in range(B)])          # one mel per clip
-    got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, L, gpu, 25, 29, 33, mel=mel)
+    got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, L, gpu, 25, 29, 33, mel=mel, start=4)
     assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
     worst, k = gradcheck.compare(got, o32, truth, label=name, kink=kink)
     seen_cond = sum(("upsample_conv2d" in k or "mel_conv" in k) and float(v.abs().max()) > 0 for k, v in o32.items())
