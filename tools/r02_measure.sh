@@ -7,7 +7,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for what in "$@"; do
   case $what in
-    c2) ARGS="--config wnet_h256_d36_T200 --steps 20 --warmup 3";;
+    c2) ARGS="--config wnet_h256_d36_T200 --steps 20 --warmup 3 --no-extra";;
     c3) ARGS="--config unet_d64_n6_T200 --steps 20 --warmup 3";;
     c4) ARGS="--config unet_d32_n6_T50_cond --steps 20 --warmup 3";;
     d128) ARGS="--config unet_d128_n6_T200 --steps 10 --warmup 2";;
