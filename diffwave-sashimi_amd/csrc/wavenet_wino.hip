@@ -409,6 +409,17 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     // ---- GEMM2: [res; skip][(C+S) x 64] = [Wr; Ws][(C+S) x C] . g[C x 64] (+ bias k-step);  this wave: res tile `wave`
     // (accumulating onto x) and its skip tiles
     __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 4, 0x00020000);
+    const float rs = 0.70710678118654752440f;
+    const bool first = a.first_layer, last = a.last_layer;
+    __amdgpu_buffer_rsrc_t rXo = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x_out + (size_t)b * C * L), 0, C * L * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rSk = __builtin_amdgcn_make_buffer_rsrc((void*)(a.skip + (size_t)b * S * L), 0, S * L * 4, 0x00020000);
+    const int L4 = L * 4;
+    const char* gb = reinterpret_cast<const char*>(gt) + lane * 8;
+    int voffn[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) voffn[n] = (p + n * dil < L) ? (4 * lhi * L + p + n * dil) * 4 : 0x7ffffff0;
+    // (Measured and dropped, same box: one row tile of [res; skip] at a time, so that the x' stores go out under the skip
+    // tile's MFMAs: 58.1 against 58.8 / 59.5 ms per step in back-to-back runs -- inside the run-to-run spread.)
     f32x4 c_cur[1 + MS], c_nxt[1 + MS];
 #pragma unroll
     for (int m = 0; m < 1 + MS; ++m) c_cur[m] = wino_load_f4(rA2, lane16, (mt2[m] * NKG) * 1024);
@@ -420,7 +431,6 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
             for (int n = 0; n < 2; ++n)
                 acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(lhi ? 0.f : av2[m], one, acc2[m][n], 0, 0, 0);
     }
-    const char* gb = reinterpret_cast<const char*>(gt) + lane * 8;
 #pragma unroll 2
     for (int kg = 0; kg < NKG; ++kg) {
         const int kgn = (kg + 1 < NKG) ? kg + 1 : kg;
@@ -445,15 +455,9 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     // no-return float atomic (one add per element and layer, layers are stream-ordered: the same bits as load-add-store,
     // without the load).  Buffer instructions: the row rides in the scalar offset, the lane part is one 32-bit offset per
     // column; a position past L gets an out-of-range offset and is dropped.
-    const float rs = 0.70710678118654752440f;
-    const bool first = a.first_layer, last = a.last_layer;
-    __amdgpu_buffer_rsrc_t rXo = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x_out + (size_t)b * C * L), 0, C * L * 4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rSk = __builtin_amdgcn_make_buffer_rsrc((void*)(a.skip + (size_t)b * S * L), 0, S * L * 4, 0x00020000);
-    const int L4 = L * 4;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int pos = p + n * dil;
-        const int voff = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
+        const int voff = voffn[n];
         if (!last) {
             const int s0 = (wave * 32) * L4;
 #pragma unroll
@@ -542,7 +546,7 @@ static void wino_trace_launch(int nwg, int waves, WnLayerArgs a, hipStream_t s, 
 
 template <int C, int S>
 static int launch_wino_t(const WnLayerArgs& a, int log2d, hipStream_t s) {
-    ProfileScope ps("wn_layer_wino", s);
+    ProfileScope ps("wn_layer_wino_mfma", s);   // ("mfma": counted among the MFMA GEMM launches of the training roofline)
     using T = WinoTile<C, S>;
     const int dil = 1 << log2d;
     const int nblk = (a.L + 2 * dil - 1) / (2 * dil);
