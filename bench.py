@@ -452,6 +452,29 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
     return out
 
 
+def profiled_step_ms(lib, run_eager_steps, name, nprof, per_step):
+    """ms one step spends in the kernels whose name contains `name`: `nprof` eager steps are timed launch by launch
+    (HIP events on the launch stream) and every launch position of the step takes its MEDIAN over the repeats -- the
+    first eager step after graph replays carries cold caches and lazily created events.  None if the launch count is
+    not nprof * per_step."""
+    import ctypes
+    from diffwave_sashimi_amd import _lib
+    _lib.check(lib.dws_profile_enable(name))
+    run_eager_steps(nprof)
+    torch.cuda.synchronize()
+    n = ctypes.c_int64()
+    buf = (ctypes.c_double * (nprof * per_step))()
+    _lib.check(lib.dws_profile_query_each(buf, nprof * per_step, ctypes.byref(n)))
+    lib.dws_profile_disable()
+    if n.value != nprof * per_step:
+        return None
+    tot = 0.0
+    for i in range(per_step):
+        v = sorted(buf[r * per_step + i] for r in range(nprof))
+        tot += v[len(v) // 2]
+    return tot
+
+
 def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
     """One sampling measurement (the headline, or an extra leg): returns the result line as a dict (rank 0 prints it)."""
     import ctypes
@@ -558,33 +581,23 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
     if rank == 0 and not args.no_roofline and cfg["model"]["_name_"] == "sashimi":
         # dominant kernel family: the fused S4 tail (three GEMMs + GLU + LN + GELU per block), all stages together
         flops, bytes_, nblocks = sashimi_tail_work(cfg)
-        _lib.check(lib.dws_profile_enable(b"s4_tail"))
-        nprof = 3
-        _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, nprof, seed, 0, stream))
-        torch.cuda.synchronize()
-        n_launch, tot_ms = ctypes.c_int64(), ctypes.c_double()
-        _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
-        lib.dws_profile_disable()
-        if n_launch.value == nprof * nblocks:
-            step_ms = tot_ms.value / nprof
+        nprof = 5
+        eager = lambda k: _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, k, seed, 0, stream))
+        step_ms = profiled_step_ms(lib, eager, b"s4_tail", nprof, nblocks)
+        if step_ms is not None:
             ach = flops / (step_ms * 1e-3) / 1e12
             result["roofline"] = {
                 "kernel": "s4_tail_mfma_kernel<H,...> (all %d block launches of a step)" % nblocks, "bound": "mfma",
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "ms_per_step_in_kernel": step_ms, "launches_timed": n_launch.value,
+                "traffic": None, "ms_per_step_in_kernel": step_ms, "launches_timed": nprof * nblocks,
                 "algorithmic_flops_per_step": flops, "algorithmic_bytes_per_step": bytes_,
                 "hbm_achieved_GBs": bytes_ / (step_ms * 1e-3) / 1e9,
                 "note": "fp32 MFMA and VALU do not co-issue on gfx950 (DESIGN.md 6): the GELU/GLU/LN VALU work of the "
                         "tail adds to the MFMA time"}
         # second kernel family of the step: the fused FFT long convolution, HBM-bound by design (8 H L bytes per block:
         # the row is read once and written once), in fact limited by its LDS passes and butterflies
-        _lib.check(lib.dws_profile_enable(b"fftconv"))
-        _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, nprof, seed, 0, stream))
-        torch.cuda.synchronize()
-        _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
-        lib.dws_profile_disable()
-        if n_launch.value == nprof * nblocks and "roofline" in result:
-            fc_ms = tot_ms.value / nprof
+        fc_ms = profiled_step_ms(lib, eager, b"fftconv", nprof, nblocks)
+        if fc_ms is not None and "roofline" in result:
             fc_bytes = bytes_ * 8 // 12          # 8 H L per block against the tail's 12 H L
             result["roofline"]["fftconv"] = {
                 "kernel": "fftconv_kernel<log2 M, M/16> (all %d block launches of a step)" % nblocks, "bound": "hbm",
