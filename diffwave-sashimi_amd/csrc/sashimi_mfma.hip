@@ -490,7 +490,9 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
         }
     }
     switch (H) {
-        case 32: return launch_tail_t<32, 1, 2, 1, 4, true>(a, s);    // 124.7 us (C4) against 127.9 for <32,1,4,1,2>
+        case 32: return launch_tail_t<32, 1, 2, 1, 4, true>(a, s);    // 124.7 us (C4) against 127.9 for <32,1,4,1,2>; two position
+                    // tiles per wave (NT = 2, each A fragment feeding two MFMAs; round 3, same box): <32,1,2,2,4> 177, <32,1,1,2,4> 161,
+                    // <32,1,4,2,2> 170 us against 126 -- at H = 32 the tile's VALU / barrier phases, not the fragment reuse, are the time
         case 64: return launch_tail_t<64, 2, 2, 1, 4, true>(a, s);    // 141.9 / 89.2 us (C3 / C4) against 157.2 / 109.2 for <64,2,2,2,2>
         case 128:   // 32-position tiles on short stages only: 72.5 us against 77.0 at L = 1000 x 32 clips (C4), 128.6 against
                     // 126.9 at 4000 x 16 (C3), 17.96 against 17.91 ms per config-5 sampling step at 16000 x 16.  The choice
