@@ -214,11 +214,24 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     //    dword form -- each LDS-DMA costs ~100 cycles of issue beside MFMAs (nodma ablation: 4 k cycles per tile);
     //  * otherwise: one dword per lane through one descriptor per channel row (num_records = L*4 bounds the row), one
     //    instruction = two shifts of one row.
-    const bool x4 = (L % 4 == 0) && log2d >= 2;
+    //  * d <= 16 (and L % 4 == 0): the four shifted copies of a tile overlap almost entirely -- the tile is one contiguous
+    //    block of 64 positions -- so ONE contiguous row piece [base - 32, base + 96) is staged per channel (16-byte LDS-DMA,
+    //    two rows per instruction, 512 contiguous bytes per row) and the transform picks its four inputs out of it
+    //    (per-dilation times before: d = 1, 2 on the dword path 1.71 ms, d = 4, 8 1.66 ms, d >= 16 1.60 ms).
+    const bool contig = (L % 4 == 0) && log2d <= 4;
+    const bool x4 = contig || ((L % 4 == 0) && log2d >= 2);
     constexpr int RPW = KC / WAVES;                // channel rows per wave and chunk (as pairs of adjacent rows)
     __amdgpu_buffer_rsrc_t rXall = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
+    // element offsets of this lane's column inside a staged row: shift s (0..3 = -d, 0, +d, +2d) sits at ob + s * os
+    const int pbase = (q0 >> log2d) << (log2d + 1);          // first position of the tile's block (d < 32: a multiple of 64)
+    const int ob = contig ? 32 + (p - pbase) - dil : l31;
+    const int os = contig ? dil : 32;
     int voffA, voffB;
-    if (x4) {   // lane = (row parity, shift, column quad)
+    if (contig) {   // lane = (row parity, 4-float piece of [pbase - 32, pbase + 96))
+        const int pp = pbase - 32 + 4 * (lane & 31);
+        voffA = ((unsigned)pp < (unsigned)L) ? (lhi * L + pp) * 4 : 0x7ffffff0;
+        voffB = 0;
+    } else if (x4) {   // lane = (row parity, shift, column quad)
         const int s4 = (lane >> 3) & 3, qq = q0 + 4 * (lane & 7);
         const int pp = ((qq >> log2d) << (log2d + 1)) + (qq & (dil - 1)) + (s4 - 1) * dil;
         voffA = ((unsigned)pp < (unsigned)L) ? (lhi * L + pp) * 4 : 0x7ffffff0;
@@ -265,20 +278,20 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
         for (int k = 0; k < T::ITEMS; ++k) {
             const int i = tid + NTH * k;
             const int cc = i >> 5, j = i & 31;
-            const float* xr = xs + cc * 128 + j;
-            const float d0 = xr[0], d1 = xr[32], d2 = xr[64], d3 = xr[96];
+            const float* xr = xs + cc * 128 + ob;      // (j = tid & 31 = this lane's column in every item)
+            const float d0 = xr[0], d1 = xr[os], d2 = xr[2 * os], d3 = xr[3 * os];
             f32x4 t;
             t[0] = d0 - d2; t[1] = d1 + d2; t[2] = d2 - d1; t[3] = d1 - d3;
             tt[i] = t;
         }
         if (KC >= 32) {
             if ((wave * 32) / KC == c1) {         // the chunk holds all 32 res rows of this wave
-                const float* xw = xs + ((wave * 32) % KC) * 128 + l31;
+                const float* xw = xs + ((wave * 32) % KC) * 128 + ob;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float* xr = xw + ((r & 3) + 8 * (r >> 2) + 4 * lhi) * 128;
-                    acc2[0][0][r] = xr[32];
-                    acc2[0][1][r] = xr[64];
+                    acc2[0][0][r] = xr[os];
+                    acc2[0][1][r] = xr[2 * os];
                 }
             }
         } else if ((c1 * KC) / 32 == wave) {      // KC < 32: the wave's rows span 32 / KC chunks
@@ -286,9 +299,9 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
             for (int r = 0; r < 16; ++r) {
                 const int ch = (r & 3) + 8 * (r >> 2);            // + 4*lhi: never crosses a multiple of 8
                 if ((ch % 32) / KC == c1 % ((32 / KC) > 0 ? (32 / KC) : 1)) {   // compile-time per r once c1's parity is known
-                    const float* xr = xs + ((ch % KC) + 4 * lhi) * 128 + l31;
-                    acc2[0][0][r] = xr[32];
-                    acc2[0][1][r] = xr[64];
+                    const float* xr = xs + ((ch % KC) + 4 * lhi) * 128 + ob;
+                    acc2[0][0][r] = xr[os];
+                    acc2[0][1][r] = xr[2 * os];
                 }
             }
         }
@@ -307,7 +320,15 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) a_cur[m][j] = wino_load_f4(rA1, lane16, ((mt1[m] * NKG) * 4 + j) * 1024);
-    __syncthreads();   // chunks 0 and 1 have landed
+    // chunk 0 has landed (this wave's part; the barrier makes it everyone's): all but the loads issued after it -- chunk 1
+    // (RPW/2 or 2 RPW LDS-DMA instructions) and the 8 A fragments.  hipcc does not make a barrier wait for LDS-DMA.
+    if (NCB > 1) {
+        if (x4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((RPW / 2 + 8) & 15) | (((RPW / 2 + 8) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * RPW + 8) & 15) | (((2 * RPW + 8) >> 4) << 14));
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+    }
+    __syncthreads();
     stamp(1);
     {
         const float v0 = ((unsigned)(p - dil) < (unsigned)L) ? 1.f : 0.f;
@@ -331,7 +352,8 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
             }
     }
     transform(0);
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);   // chunk 1 has landed too (younger: only the 8 A fragments)
+    __syncthreads();                          // transformed chunk 0 visible, raw chunk 1 complete
 
     // (Measured and dropped, same box: doing the staging / transform of the two waves of a SIMD at different k-groups, so
     // that one's non-MFMA work sits beside the other's MFMAs: 61.3 against 58.4 ms per step.)
