@@ -28,6 +28,10 @@ struct S4TailArgs {
     const float* e_next;  // next block's step-embedding projection: e_next[b * e_stride + h]
     int e_stride;
     int B, L;
+    // H <= 64: the same three weights with their columns in chain order (sashimi_chain.hip), A-fragment packed
+    const float* Ao_c;
+    const float* A1_c;
+    const float* A2_c;
 };
 
 struct PwMfmaArgs {
@@ -41,6 +45,9 @@ struct PwMfmaArgs {
 
 bool s4_tail_mfma_supported(int H, int ff);
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s);
+bool s4_tail_chain_supported(int H, int ff);
+int launch_s4_tail_chain(int H, const S4TailArgs& a, hipStream_t s);
+int launch_chain_permute_cols(const float* w, float* out, int M, int K, hipStream_t s);
 int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s);
 bool pw_mfma_supported(int mode, int K, int M, int p);
 int launch_pw_mfma(int mode, const PwMfmaArgs& a, hipStream_t s);

@@ -483,6 +483,10 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     // four of them per CU hide each other's staging, LayerNorm and epilogue phases better than two); at H = 256 the
     // A-fragment reuse of NT = 2 is worth more.  DWS_TAIL_CFG=1 selects the round-1 shapes.
     const int alt = getenv("DWS_TAIL_CFG") ? atoi(getenv("DWS_TAIL_CFG")) : 0;
+    // H <= 64: the register-chained kernel (sashimi_chain.hip: a wave owns 32 positions, no LDS round trip between the
+    // GEMMs, no barrier); DWS_TAIL_NO_CHAIN=1 keeps the LDS-tile kernel below (A/B runs, tests)
+    if (alt == 0 && a.Ao_c && s4_tail_chain_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr)
+        return launch_s4_tail_chain(H, a, s);
     if (alt == 1) {
         switch (H) {
             case 32: return launch_tail_t<32, 1, 4, 1, 2, true>(a, s);

@@ -103,6 +103,7 @@ struct SLayer {
     int stage = 0;        // index into per-(H,L) workspaces
     DevBuf W1, W2, Wp;    // folded ff / pool weights
     DevBuf Ao, A1, A2, rs1, Ap;  // MFMA-packed copies (+ row sums of W1 for the folded LayerNorm)
+    DevBuf Ao_c, A1_c, A2_c;     // H <= 64: the same weights with chain-ordered columns (sashimi_chain.hip)
     bool mfma = false, mfma2 = false;
     DevBuf Kf;            // rocFFT path: [H][L+1] complex spectrum of the two-sided kernel (n = 2L)
     DevBuf kfa, kfb, kfs; // fused path: pair-ordered spectrum at the power-of-two size (fftconv.h)
@@ -158,7 +159,7 @@ struct SashimiModel : dws_model {
     int64_t melBm = 0;
     // training path
     std::vector<Exec> plan;
-    DevBuf dx_init, ty, ta1, ta2, tAfT, tmp_pack, wpart, dWfold, lnpart, pool_scr, dpt, dh2, dh1, dWt_all, dbt_all;
+    DevBuf dx_init, ty, ta1, ta2, tAfT, tmp_pack, wpart, dWfold, lnpart, pool_scr, chain_tmp, dpt, dh2, dh1, dWt_all, dbt_all;
     DevBuf bpart, fpart, dKf, dKt, dkt, dkf, cgr, cgv, cgw, cpdt, dyb, dnf;
     uint64_t commit_version = 0, train_pack_version = ~0ull;
     bool keep_cauchy = false;         // set by the first forward_train: build_kernel then fills the per-block caches
@@ -464,6 +465,18 @@ struct SashimiModel : dws_model {
                     DWS_TRY(launch_pack_a_frag(l->W1.f(), l->A1.f(), FF * H, H, s));
                     DWS_TRY(launch_pack_a_frag(l->W2.f(), l->A2.f(), H, FF * H, s));
                     DWS_TRY(launch_row_sum(l->W1.f(), l->rs1.f(), FF * H, H, s));
+                    if (s4_tail_chain_supported(H, FF)) {   // chain-ordered columns for the register-chained tail kernel
+                        DWS_TRY(chain_tmp.ensure((size_t)FF * H * H * 4));
+                        DWS_TRY(l->Ao_c.ensure((size_t)2 * H * H * 4));
+                        DWS_TRY(l->A1_c.ensure((size_t)FF * H * H * 4));
+                        DWS_TRY(l->A2_c.ensure((size_t)FF * H * H * 4));
+                        DWS_TRY(launch_chain_permute_cols(P(l->prefix + ".layer.output_linear.0.weight"), chain_tmp.f(), 2 * H, H, s));
+                        DWS_TRY(launch_pack_a_frag(chain_tmp.f(), l->Ao_c.f(), 2 * H, H, s));
+                        DWS_TRY(launch_chain_permute_cols(l->W1.f(), chain_tmp.f(), FF * H, H, s));
+                        DWS_TRY(launch_pack_a_frag(chain_tmp.f(), l->A1_c.f(), FF * H, H, s));
+                        DWS_TRY(launch_chain_permute_cols(l->W2.f(), chain_tmp.f(), H, FF * H, s));
+                        DWS_TRY(launch_pack_a_frag(chain_tmp.f(), l->A2_c.f(), H, FF * H, s));
+                    }
                 }
                 DWS_TRY(build_kernel(l, s));
                 if (cond) {
@@ -667,6 +680,7 @@ struct SashimiModel : dws_model {
             t.A1 = l->A1.f(); t.b1 = P(p + ".ff.ff.0.conv.bias"); t.rs1 = l->rs1.f();
             t.A2 = l->A2.f(); t.b2 = P(p + ".ff.ff.2.conv.bias");
             t.addend = addend; t.out = l->out.f(); t.B = nB; t.L = Ls;
+            t.Ao_c = l->Ao_c.f(); t.A1_c = l->A1_c.f(); t.A2_c = l->A2_c.f();
             if (next) {     // feeds_next(l, next) holds: the stage's y buffer is free once this block's convolution ran
                 t.ynext = st->y.f();
                 t.n1_m = P(next->prefix + ".norm1.m"); t.n1_s = P(next->prefix + ".norm1.s");

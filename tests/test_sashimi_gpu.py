@@ -230,10 +230,11 @@ def test_fused_next_block_layernorm_agrees_with_the_separate_pass(gpu, name):
 
 
 @pytest.mark.parametrize("name", ["ss_d64_short", "ss_d128_short", "ss_cond_d32"])
-@pytest.mark.parametrize("switch", ["DWS_TAIL_CFG", "DWS_TAIL_NO_VEC"])
+@pytest.mark.parametrize("switch", ["DWS_TAIL_CFG", "DWS_TAIL_NO_VEC", "DWS_TAIL_NO_CHAIN"])
 def test_tail_kernel_variants_agree(gpu, name, switch):
-    """The fused tail kernel (`sashimi.py:177-184`) in its other tile shapes (DWS_TAIL_CFG=1: 128-position tiles) and with
-    per-lane dword instead of 16-byte global traffic (DWS_TAIL_NO_VEC=1, the path L % 4 != 0 takes) -- same weights, same
+    """The fused tail kernel (`sashimi.py:177-184`) in its other tile shapes (DWS_TAIL_CFG=1: 128-position tiles), with
+    per-lane dword instead of 16-byte global traffic (DWS_TAIL_NO_VEC=1, the path L % 4 != 0 takes), and the LDS-tile
+    kernel where the default is the register-chained one (DWS_TAIL_NO_CHAIN=1: H = 32 / 64 stages) -- same weights, same
     inputs (the conditional case with its mel term); only the order of the LayerNorm partial sums differs between shapes."""
     import os
     mel = None
