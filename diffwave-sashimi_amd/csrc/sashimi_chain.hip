@@ -101,8 +101,10 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
     const float invH = 1.f / (float)H;
 
 #define CH_SOFF(t, r) ((32 * (t) + ((r) & 3) + 8 * ((r) >> 2)) * L4)
-    // (Requesting g and x of the NEXT tile under the current tile's GEMM-2 was measured: 141.7 vs 135.7 us at H = 64, 90.0 vs
-    // 88.9 at H = 32 -- the extra 32-64 live registers cost more than the round trip they hide.)
+    // (Requesting g and x -- or g alone -- of the NEXT tile under the current tile's GEMM-2 was measured: 141.7 / 138.5 vs
+    // 135.7 / 139.4 us at H = 64, 90.0 vs 88.9 at H = 32: no gain.  Counters (profiles/r03_c*_chain*_pmc.txt): MFMA busy 66 % /
+    // 52 % of the cycles at H = 64 / 32, the non-MFMA VALU work -- GELU is half of it -- another 18 % / 25 %: the kernel is
+    // arithmetic-bound (fp32 MFMA and VALU share the pipe), not latency-bound.)
     for (int tile = blockIdx.x * T::WAVES + wave; tile < ntiles; tile += gridDim.x * T::WAVES) {
         const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
         const int l0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
@@ -139,18 +141,27 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
             ao[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, one, z, 0, 0, 0);
         }
+        {   // A fragments of k-group kg+1 are read from LDS before the MFMAs of k-group kg (a wave has one or three partners
+            // on its SIMD: the ~120-cycle LDS round trip per k-group showed); the fences keep hipcc from hoisting ALL reads
+            f32x4 af[2][TO];
 #pragma unroll
-        for (int kg = 0; kg < H / 8; ++kg) {
-            __builtin_amdgcn_sched_barrier(0);   // (fully unrolled: without the fence hipcc hoists every fragment read)
-            f32x4 af[TO];
+            for (int m = 0; m < TO; ++m) af[0][m] = *reinterpret_cast<const f32x4*>(wo + ((m * (H / 8)) * 64 + lane) * 4);
 #pragma unroll
-            for (int m = 0; m < TO; ++m) af[m] = *reinterpret_cast<const f32x4*>(wo + ((m * (H / 8) + kg) * 64 + lane) * 4);
+            for (int kg = 0; kg < H / 8; ++kg) {
+                if (kg + 1 < H / 8) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kappa = kg * 4 + j;
+                    for (int m = 0; m < TO; ++m)
+                        af[(kg + 1) & 1][m] = *reinterpret_cast<const f32x4*>(wo + ((m * (H / 8) + kg + 1) * 64 + lane) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < TO; ++m)
-                    ao[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], g[kappa >> 4][kappa & 15], ao[m], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int kappa = kg * 4 + j;
+#pragma unroll
+                    for (int m = 0; m < TO; ++m)
+                        ao[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][m][j], g[kappa >> 4][kappa & 15], ao[m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -189,18 +200,26 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
             u[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, one, z, 0, 0, 0);
         }
+        {
+            f32x4 af[2][TF];
 #pragma unroll
-        for (int kg = 0; kg < H / 8; ++kg) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 af[TF];
+            for (int m = 0; m < TF; ++m) af[0][m] = *reinterpret_cast<const f32x4*>(w1 + ((m * (H / 8)) * 64 + lane) * 4);
 #pragma unroll
-            for (int m = 0; m < TF; ++m) af[m] = *reinterpret_cast<const f32x4*>(w1 + ((m * (H / 8) + kg) * 64 + lane) * 4);
+            for (int kg = 0; kg < H / 8; ++kg) {
+                if (kg + 1 < H / 8) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kappa = kg * 4 + j;
+                    for (int m = 0; m < TF; ++m)
+                        af[(kg + 1) & 1][m] = *reinterpret_cast<const f32x4*>(w1 + ((m * (H / 8) + kg + 1) * 64 + lane) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < TF; ++m)
-                    u[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], y[kappa >> 4][kappa & 15], u[m], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int kappa = kg * 4 + j;
+#pragma unroll
+                    for (int m = 0; m < TF; ++m)
+                        u[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][m][j], y[kappa >> 4][kappa & 15], u[m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -230,18 +249,27 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
             f[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, one, z, 0, 0, 0);
         }
+        {
+            constexpr int NKG2 = FFE * H / 8;
+            f32x4 af[2][TH];
 #pragma unroll
-        for (int kg = 0; kg < FFE * H / 8; ++kg) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 af[TH];
+            for (int m = 0; m < TH; ++m) af[0][m] = *reinterpret_cast<const f32x4*>(w2 + ((m * NKG2) * 64 + lane) * 4);
 #pragma unroll
-            for (int m = 0; m < TH; ++m) af[m] = *reinterpret_cast<const f32x4*>(w2 + ((m * (FFE * H / 8) + kg) * 64 + lane) * 4);
+            for (int kg = 0; kg < NKG2; ++kg) {
+                if (kg + 1 < NKG2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kappa = kg * 4 + j;
+                    for (int m = 0; m < TH; ++m)
+                        af[(kg + 1) & 1][m] = *reinterpret_cast<const f32x4*>(w2 + ((m * NKG2 + kg + 1) * 64 + lane) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < TH; ++m)
-                    f[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], u[kappa >> 4][kappa & 15], f[m], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int kappa = kg * 4 + j;
+#pragma unroll
+                    for (int m = 0; m < TH; ++m)
+                        f[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][m][j], u[kappa >> 4][kappa & 15], f[m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
