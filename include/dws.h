@@ -129,7 +129,11 @@ int dws_model_update_params(dws_model* m, int32_t count, const char* const* name
  *   "precision" = "f32"    (default) exact-f32 MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain
  *               = "bf16x3" WaveNet residual layers on the bf16 matrix cores with a 3-term hi/lo split
  *                          (W_hi x_hi + W_hi x_lo + W_lo x_hi, fp32 accumulate): ~1e-5 relative, 5.3x the
- *                          matrix rate.  Not part of the reference surface. */
+ *                          matrix rate.  Not part of the reference surface.
+ *   "conv_algo" = "winograd" (default) WaveNet residual layers (precision f32) with the dilated 3-tap convolution in
+ *                          Winograd F(2,3) form along the dilation stride: 8 C^2 instead of 12 C^2 flop per position,
+ *                          one extra fp32 rounding in the weights and in the inputs (same 1e-6 class error)
+ *               = "direct" the direct three-tap form (A/B runs). */
 int dws_model_set_option(dws_model* m, const char* key, const char* value);
 
 /* Fold / pack everything that depends only on the weights.  Called implicitly

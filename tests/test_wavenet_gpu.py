@@ -147,3 +147,31 @@ def test_shape_errors_are_loud(gpu):
     bad["init_conv.0.conv.bias"] = torch.zeros(17)
     with pytest.raises(RuntimeError):
         net.load_state_dict(bad)
+
+
+@pytest.mark.parametrize("name", ["wn_c64", "wn_c128", "wn_h256_d36"])
+def test_winograd_and_direct_layer_kernels_agree(gpu, name):
+    """The default fused layer computes the dilated conv in Winograd F(2,3) form along the dilation stride
+    (`csrc/wavenet_wino.hip`); `conv_algo=direct` is the three-tap form.  Same weights, same inputs: the two must agree
+    far inside the 1e-3 bound -- at every staging variant of the Winograd kernel: 16-byte LDS-DMA (L % 4 == 0, d >= 4),
+    the contiguous-row form (d <= 16), the dword form (L % 4 != 0), positions past L in the last pair block, d > L."""
+    cfg, B, L, wseed, iseed, _ = cases.WAVENET_CASES[name]
+    net = cases.build_ours(cfg, wseed + 9).to(gpu)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for L2, B2 in ((1, 1), (63, 2), (600, 2), (1001, 1), (4096, 1), (4100, 2)):
+        audio, steps = cases.wavenet_inputs(B2, L2, 1, iseed + L2)
+        with torch.no_grad():
+            net.set_option("conv_algo", "winograd")
+            w = net((audio.to(gpu), steps.to(gpu)))
+            w2 = net((audio.to(gpu), steps.to(gpu)))
+            net.set_option("conv_algo", "direct")
+            d = net((audio.to(gpu), steps.to(gpu)))
+        assert torch.equal(w, w2)                                  # deterministic (the skip atomics are one add per element)
+        assert not torch.equal(w, d)                               # two different arithmetic paths
+        assert rel_err(w, d) < 2e-5, (name, L2, B2, rel_err(w, d))
+        if L2 <= 1001 and name != "wn_h256_d36":
+            with torch.no_grad():
+                ref = own.wavenet_forward(sd, cfg, audio, steps)
+            assert rel_err(w, ref) < REL_TOL / 10, (name, L2, B2)
+    with pytest.raises(RuntimeError):
+        net.set_option("conv_algo", "fft")
