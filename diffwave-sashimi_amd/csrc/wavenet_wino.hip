@@ -530,8 +530,7 @@ static void wino_trace_launch(int nwg, int waves, WnLayerArgs a, hipStream_t s, 
     static double chunk[8][32];
     for (auto& c : chunk) for (double& v : c) v = 0;
     double g2[8] = {0}, ep[8] = {0};
-    unsigned long long tmin = ~0ull, tmax = 0;
-    double wgspan = 0;
+    double wgspan = 0;   // (s_memtime is per XCD: only differences inside one workgroup mean anything)
     for (int g = 0; g < nwg; ++g) {
         unsigned long long g0 = ~0ull, g1 = 0;
         for (int w = 0; w < waves; ++w) {
@@ -545,13 +544,10 @@ static void wino_trace_launch(int nwg, int waves, WnLayerArgs a, hipStream_t s, 
             if (t[7] > g1) g1 = t[7];
         }
         wgspan += (double)(g1 - g0);
-        if (g0 < tmin) tmin = g0;
-        if (g1 > tmax) tmax = g1;
     }
     const double nw = (double)nwg * waves;
-    fprintf(stderr, "[wino trace] d=%d wgs=%d kernel span %.0f ticks (100 MHz: %.1f us); per-wave mean ticks: prologue %.0f gemm1 %.0f "
-            "extra+gate %.0f barrier %.0f gemm2 %.0f epilogue %.0f drain %.0f; mean WG span %.0f\n", a.dilation, nwg,
-            (double)(tmax - tmin), (double)(tmax - tmin) / 100.0, ph[1] / nw, ph[2] / nw, ph[3] / nw, ph[4] / nw, ph[5] / nw,
+    fprintf(stderr, "[wino trace] d=%d wgs=%d per-wave mean cycles: prologue %.0f gemm1 %.0f "
+            "extra+gate %.0f barrier %.0f gemm2 %.0f epilogue %.0f drain %.0f; mean workgroup span %.0f\n", a.dilation, nwg, ph[1] / nw, ph[2] / nw, ph[3] / nw, ph[4] / nw, ph[5] / nw,
             ph[6] / nw, ph[7] / nw, wgspan / nwg);
     if (std::getenv("DWS_WINO_TRACE_CHUNKS")) {
         fprintf(stderr, "  per-wave gemm2 / epilogue ticks:");
