@@ -104,7 +104,10 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
     // (Requesting g and x -- or g alone -- of the NEXT tile under the current tile's GEMM-2 was measured: 141.7 / 138.5 vs
     // 135.7 / 139.4 us at H = 64, 90.0 vs 88.9 at H = 32: no gain.  Counters (profiles/r03_c*_chain*_pmc.txt): MFMA busy 66 % /
     // 52 % of the cycles at H = 64 / 32, the non-MFMA VALU work -- GELU is half of it -- another 18 % / 25 %: the kernel is
-    // arithmetic-bound (fp32 MFMA and VALU share the pipe), not latency-bound.)
+    // arithmetic-bound (fp32 MFMA and VALU share the pipe; SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.4 cycles per VALU
+    // instruction), not latency-bound.  Also measured: all tile I/O as 16-byte accesses through a per-wave 32 x 32 LDS
+    // scratch tile (24 instead of 96-112 VMEM instructions per tile at H = 32): 90.5 vs 88.9 us -- the address path was not
+    // the limit either.)
     for (int tile = blockIdx.x * T::WAVES + wave; tile < ntiles; tile += gridDim.x * T::WAVES) {
         const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
         const int l0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
