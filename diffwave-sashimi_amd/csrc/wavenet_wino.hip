@@ -591,6 +591,9 @@ int launch_wn_layer_wino(int C, int S, const WnLayerArgs& a, hipStream_t s) {
     while ((1 << log2d) < a.dilation) ++log2d;
     DWS_CHECK((1 << log2d) == a.dilation, DWS_ERR_UNSUPPORTED, "wn_layer_wino: dilation %d is not a power of two", a.dilation);
     DWS_CHECK((int64_t)a.L + 4 * (int64_t)a.dilation < ((int64_t)1 << 28), DWS_ERR_UNSUPPORTED, "wn_layer_wino: L too large");
+    // one buffer descriptor spans a batch element's [C][L] (or [S][L]) tensor: 32-bit byte offsets
+    DWS_CHECK((int64_t)(C > S ? C : S) * a.L * 4 < ((int64_t)1 << 31), DWS_ERR_UNSUPPORTED,
+              "wn_layer_wino: %d channels x L=%d exceed a 2 GiB tensor per clip", C > S ? C : S, a.L);
     if (C == 64 && S == 64) return launch_wino_t<64, 64>(a, log2d, s);
     if (C == 128 && S == 128) return launch_wino_t<128, 128>(a, log2d, s);
     if (C == 128 && S == 256) return launch_wino_t<128, 256>(a, log2d, s);
