@@ -418,7 +418,8 @@ def main():
     result = sample_bench(args, cfg, world, rank, dev, ddist, red_dev)
     if (rank == 0 and world == 1 and not args.no_extra and args.config == "wnet_h256_d36_T200" and not args.batch
             and args.precision == "f32"):
-        # the other BASELINE configs, short legs in the same process (NOT `value`): C3, C4 sampling, C5's per-GPU training step
+        # the other BASELINE configs, short legs in the same process (NOT `value`): C3, C4 sampling, C5's per-GPU training step.
+        # A failing leg must not take the headline line with it: it is reported as an error string instead.
         result["extra_configs"] = extra_legs(args, world, rank, dev, ddist, red_dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg)
@@ -438,17 +439,26 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
         a = copy.copy(args)
         a.config, a.steps, a.warmup = name, steps, warmup
         t0 = time.perf_counter()
-        r = sample_bench(a, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False)
-        out[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")
-                     if k in r}
+        try:
+            r = sample_bench(a, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False)
+            out[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")
+                         if k in r}
+        except Exception as e:      # noqa: BLE001 -- reported, not swallowed
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
         out[name]["leg_seconds"] = time.perf_counter() - t0
     a = copy.copy(args)
     a.config, a.steps, a.warmup, a.mode, a.batch = "unet_d128_n6_T200", 4, 2, "train", None
     t0 = time.perf_counter()
-    r = train_bench(a, dict(CONFIGS[a.config]), world, rank, dev, ddist, red_dev, emit=False)
-    out["unet_d128_n6_T200 --mode train"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
-                                                                "dtype", "config", "roofline", "final_loss") if k in r}
-    out["unet_d128_n6_T200 --mode train"]["leg_seconds"] = time.perf_counter() - t0
+    key = "unet_d128_n6_T200 --mode train"
+    try:
+        r = train_bench(a, dict(CONFIGS[a.config]), world, rank, dev, ddist, red_dev, emit=False)
+        out[key] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
+                                      "final_loss") if k in r}
+    except Exception as e:      # noqa: BLE001
+        out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    out[key]["leg_seconds"] = time.perf_counter() - t0
     return out
 
 
