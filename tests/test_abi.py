@@ -92,3 +92,21 @@ def test_cauchy_mult_module_is_importable_by_its_reference_name():
     with pytest.raises(RuntimeError):      # CHECK_DEVICE of `cauchy.cpp:6` without touching a GPU
         m.cauchy_mult_sym_fwd(torch.zeros(1, 4, dtype=torch.complex64), torch.zeros(3, dtype=torch.complex64),
                               torch.zeros(1, 4, dtype=torch.complex64))
+
+
+def test_bench_executed_flops_formula_matches_the_counter():
+    """`bench.py: wino_executed_work` (tile counts x MFMAs per wave x 4096) against what the hardware counted for the same
+    launch (`SQ_INSTS_MFMA` per dispatch, profiles/r03_wavenet_traffic.json): the figure `roofline.frac` is priced on."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    rec = json.load(open(os.path.join(root, "profiles", "r03_wavenet_traffic.json")))
+    cfg = bench.CONFIGS["wnet_h256_d36_T200"]
+    formula = bench.wino_executed_work(cfg)
+    counted = rec["sq_insts_mfma_per_launch"] * 4096
+    assert abs(formula - counted) < 5e-3 * counted, (formula, counted)
+    algorithmic, _ = bench.layer_algorithmic_work(cfg)
+    assert 0.74 < formula / algorithmic < 0.78          # (10 C^2 + 2 C S + padding) / (14 C^2 + 2 C S)
