@@ -508,6 +508,14 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
         gm = torch.Generator().manual_seed(4321 + rank)
         mel = (torch.rand(B, 80, cfg["Tmel"], generator=gm) * 13.5 - 11.5).to(dev)
         net._set_condition(mel)
+        # the conditioner runs once per batch of utterances, not per reverse step: timed on its own (outside `value`,
+        # whose unit is the per-step rate) so that the end-to-end rate of a whole T-step run can be stated beside it
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(3):
+            net._set_condition(mel + 0.0)   # a new tensor each time: the module caches on the mel it was given
+        torch.cuda.synchronize()
+        cond_ms = (time.perf_counter() - tc) / 3 * 1e3
     x = torch.randn(B, 1, L, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     stream = _lib.current_stream()
     seed = ddist.rank_seed(1234, rank)
@@ -547,6 +555,11 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
         "per_rank_seed": [int(v) for v in ddist.gather_over_ranks(float(seed), red_dev)],
         "per_rank_state_digest": ddist.gather_over_ranks(float(x.double().abs().sum()), red_dev),
     }
+
+    if "Tmel" in cfg:
+        result["conditioner_ms_per_batch"] = cond_ms
+        result["end_to_end_samples_per_s_incl_conditioner"] = ddist.aggregate_throughput(
+            B * L, world, T * ms_per_step * 1e-3 + cond_ms * 1e-3)
 
     if rank == 0 and not args.no_roofline and cfg["model"]["_name_"] == "wavenet":
         # dominant kernel: the fused residual layer.  Timed with HIP events on its own

@@ -42,23 +42,63 @@ int launch_mel_upsample(const float* in, const float* W, const float* bias, floa
 
 // out[b, o, l] = bias[o] + sum_k W[o, k] * in[b, k, l]   for l < L (in rows have stride Lin >= L:
 // the truncation `mel_spec[:, :, :L]` of `wavenet.py:106-108`).
-__global__ void conv1x1_trunc_kernel(const float* __restrict__ in, const float* __restrict__ W,
-                                     const float* __restrict__ bias, float* __restrict__ out, int K, int O, int Lin,
-                                     int L) {
-    const int b = blockIdx.z, o = blockIdx.y;
+// A workgroup owns OT output channels x 1024 positions: the weight tile sits in LDS as [k][OT] (one broadcast
+// ds_read_b128 feeds four FMAs of every lane), a thread keeps OT accumulators for four positions 256 apart, so the
+// input rows are read O / OT times instead of O times.  Summation order over k as in the definition (k ascending).
+template <int OT>
+__global__ __launch_bounds__(256) void conv1x1_trunc_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int K, int O, int Lin, int L) {
+    constexpr int KC = 64, NP = 4;
+    __shared__ __attribute__((aligned(16))) float Ws[KC * OT];
+    const int b = blockIdx.z, o0 = blockIdx.y * OT, tid = threadIdx.x;
     const float* inb = in + (size_t)b * K * Lin;
-    const float* w = W + (size_t)o * K;
-    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
-        float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc = fmaf(w[k], inb[(size_t)k * Lin + l], acc);
-        out[((size_t)b * O + o) * L + l] = acc + bias[o];
+    const int l0 = blockIdx.x * (256 * NP) + tid;
+    float acc[NP][OT];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int j = 0; j < OT; ++j) acc[p][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kn = min(KC, K - k0);
+        __syncthreads();
+        for (int i = tid; i < kn * OT; i += 256) {
+            const int k = i / OT, j = i % OT;
+            Ws[i] = (o0 + j < O) ? W[(size_t)(o0 + j) * K + k0 + k] : 0.f;
+        }
+        __syncthreads();
+        for (int k = 0; k < kn; ++k) {
+            float x[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int l = l0 + 256 * p;
+                x[p] = l < L ? inb[(size_t)(k0 + k) * Lin + l] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < OT; ++j) {
+                const float w = Ws[k * OT + j];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[p][j] = fmaf(w, x[p], acc[p][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < OT; ++j) {
+        if (o0 + j >= O) break;
+        const float bj = bias[o0 + j];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int l = l0 + 256 * p;
+            if (l < L) out[((size_t)b * O + o0 + j) * L + l] = acc[p][j] + bj;
+        }
     }
 }
 
 int launch_conv1x1_trunc(const float* in, const float* W, const float* bias, float* out, int Bm, int K, int O,
                          int Lin, int L, hipStream_t st) {
-    dim3 grid(min(ceil_div(L, 256), 256), O, Bm);
-    hipLaunchKernelGGL(conv1x1_trunc_kernel, grid, dim3(256), 0, st, in, W, bias, out, K, O, Lin, L);
+    constexpr int OT = 16;
+    dim3 grid(ceil_div(L, 1024), ceil_div(O, OT), Bm);
+    hipLaunchKernelGGL(conv1x1_trunc_kernel<OT>, grid, dim3(256), 0, st, in, W, bias, out, K, O, Lin, L);
     return DWS_OK;
 }
 
