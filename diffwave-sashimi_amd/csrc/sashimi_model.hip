@@ -166,6 +166,7 @@ struct SashimiModel : dws_model {
     bool trained_fwd = false;
     const float* train_audio = nullptr;
     DevBuf mel_in;                    // copy of the installed mel [Bm][MB][Tmel] (conditioner adjoint)
+    DevBuf mel_u0, mel_u1;            // upsampler scratch of set_condition (kept: no allocation / wait per utterance)
     int mel_T = 0;
     CondTrainWs cws;
     DevBuf gW0f, gW1f, gWcf;
@@ -589,7 +590,8 @@ struct SashimiModel : dws_model {
         if (dirty) DWS_TRY(commit(s));
         const int s0 = d.mel_upsample[0], s1 = d.mel_upsample[1];
         const int T0 = mel_upsampled_len((int)Tmel, s0), T1 = mel_upsampled_len(T0, s1);
-        DevBuf u0, u1;
+        DevBuf& u0 = mel_u0;
+        DevBuf& u1 = mel_u1;
         DWS_TRY(u0.ensure((size_t)Bm * MB * T0 * 4));
         DWS_TRY(u1.ensure((size_t)Bm * MB * T1 * 4));
         for (auto* l : all) {
@@ -604,7 +606,6 @@ struct SashimiModel : dws_model {
             DWS_TRY(launch_conv1x1_trunc(u1.f(), l->melWc.f(), P(l->prefix + ".mel_conv.conv.bias"), l->melc.f(), (int)Bm,
                                          MB, l->H, T1, l->L, s));
         }
-        DWS_HIP(hipStreamSynchronize(s));  // u0/u1 are freed on return
         DWS_TRY(mel_in.ensure((size_t)Bm * MB * Tmel * 4));
         DWS_HIP(hipMemcpyAsync(mel_in.p, mel, (size_t)Bm * MB * Tmel * 4, hipMemcpyDeviceToDevice, s));
         mel_T = (int)Tmel;
