@@ -66,6 +66,34 @@ def test_cauchy_golden_vectors(gpu, N, L):
     assert rel_err(torch.view_as_real(dw), torch.view_as_real(torch.from_numpy(g[f"{t}/dw"]))) < 1e-4
 
 
+@pytest.mark.parametrize("B,NH,L", [(11, 3, 37), (9, 5, 1500), (1, 1, 5000), (17, 13, 4097), (8, 9, 4096), (3, 7, 1024)])
+def test_cauchy_ragged_shapes(gpu, B, NH, L):
+    """Shapes off the kernels' granules: row counts that are not multiples of 8 (the backward pads its XCD-local block order),
+    state sizes that are not multiples of the 8 n a backward thread owns (or of the packed pairs), row lengths on both
+    sides of the 1024 / 4096-bin block-shape switches and of the forward's outputs-per-thread choice."""
+    from diffwave_sashimi_amd.extensions import cauchy as ext
+    g = torch.Generator().manual_seed(100 * B + NH)
+    v = torch.randn(B, NH, dtype=torch.complex64, generator=g)
+    w = torch.randn(B, NH, dtype=torch.complex64, generator=g)
+    w = torch.complex(-w.real.abs() - 0.05, w.imag)
+    z = torch.exp(1j * torch.randn(L, dtype=torch.float32, generator=g))
+    dout = torch.randn(B, L, dtype=torch.complex64, generator=g)
+    vg, zg, wg, dg = v.to(gpu), z.to(gpu), w.to(gpu), dout.to(gpu)
+    ref = oc.cauchy_sym_direct(v.cdouble(), z.cdouble(), w.cdouble())
+    dv_ref, dw_ref = oc.cauchy_sym_bwd(v.cdouble(), z.cdouble(), w.cdouble(), dout.cdouble())
+    out = ext.cauchy_mult_sym_fwd(vg, zg, wg)
+    dv, dw = ext.cauchy_mult_sym_bwd(vg, zg, wg, dg)
+    for got, want in ((out, ref), (dv, dv_ref), (dw, dw_ref)):
+        assert got.shape == want.shape
+        assert rel_err(torch.view_as_real(got), torch.view_as_real(want.to(torch.complex64))) < 1e-4
+    ref = oc.cauchy_direct(v.cdouble(), z.cdouble(), w.cdouble())
+    dv_ref, dw_ref = oc.cauchy_bwd(v.cdouble(), z.cdouble(), w.cdouble(), dout.cdouble())
+    out = ext.cauchy_mult(vg, zg, wg, symmetric=False)
+    dv, dw = ext.cauchy_mult_bwd(vg, zg, wg, dg)
+    for got, want in ((out, ref), (dv, dv_ref), (dw, dw_ref)):
+        assert rel_err(torch.view_as_real(got), torch.view_as_real(want.to(torch.complex64))) < 1e-4
+
+
 def test_cauchy_broadcast_front_end_and_errors(gpu):
     from diffwave_sashimi_amd.extensions import cauchy as ext
     g = torch.Generator().manual_seed(1)
