@@ -238,3 +238,25 @@ def test_build_notices_changed_compile_flags(monkeypatch):
     assert build.needs_build()
     src = os.path.join(build.CSRC, "common.hip")
     assert build._cmd_changed("hipcc", src) and not build._cmd_changed("hipcc", os.path.join(build.CSRC, "api.hip"))
+
+
+def test_build_staleness_follows_contents_not_mtimes(monkeypatch, tmp_path):
+    """The built library travels to another machine inside a copied tree whose modification times say nothing: an object
+    is stale when the CONTENTS of its source or of a header differ from what its sidecar recorded, and only then."""
+    from diffwave_sashimi_amd import build
+    if not os.path.exists(build.LIB):
+        pytest.skip("libdws.so not built")
+    assert not build.needs_build()
+    src = os.path.join(build.CSRC, "common.hip")
+    st = os.stat(src)
+    try:
+        os.utime(src, (st.st_atime, st.st_mtime + 10 ** 6))      # "newer" than the library: same bytes, nothing to do
+        assert not build.needs_build()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    extra = tmp_path / "extra.h"
+    extra.write_text("// a header that was not there when the objects were built\n")
+    real = build._headers()
+    monkeypatch.setattr(build, "_headers", lambda: real + [str(extra)])
+    assert build.needs_build()
+    assert all(build._cmd_changed("hipcc", s) for s in build.sources())
