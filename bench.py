@@ -112,6 +112,21 @@ def wino_executed_work(cfg):
     return tot / len(dil)
 
 
+def wino_dgrad_executed_work(cfg):
+    """MFMA flops the Winograd data-gradient kernel of the dilated conv (csrc/wavenet_backward_wino.hip) executes per
+    launch, averaged over the dilations: workgroups(d) = B * ceil(ceil(L / 2d) * d / 64) tiles of 64 position pairs x
+    C / (128 MT) row blocks, 8 waves x C k-steps (K = 2C) x 4 Winograd products x MT row tiles each = 1024 C^2 flop per
+    tile column block.  (The direct form: 12 C^2 flop per position.)"""
+    m = cfg["model"]
+    C, B, L = m["res_channels"], cfg["B"], cfg["L"]
+    tot = 0
+    dil = [1 << (n % m["dilation_cycle"]) for n in range(m["num_res_layers"])]
+    for d in dil:
+        nblk = -(-L // (2 * d))
+        tot += B * (-(-(nblk * d) // 64)) * 1024 * C * C
+    return tot / len(dil)
+
+
 def sashimi_tail_work(cfg):
     """All S4-tail launches of one step: per block 12 H^2 flops and 12 H bytes per position
     (read g and x, write out; the three GEMMs Wo, W1, W2), summed over the U-Net's blocks."""
@@ -298,6 +313,9 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
         if cfg["model"]["_name_"] == "wavenet" and os.environ.get("DWS_WN_DIRECT") is None:
             m = cfg["model"]
             executed = flops - m["num_res_layers"] * (layer_algorithmic_work(dict(cfg, B=B))[0] - wino_executed_work(dict(cfg, B=B)))
+            if m["res_channels"] % 128 == 0 and os.environ.get("DWS_TAPCONV_DIRECT") is None:   # the data gradient too
+                C = m["res_channels"]
+                executed -= m["num_res_layers"] * (B * cfg["L"] * 12 * C * C - wino_dgrad_executed_work(dict(cfg, B=B)))
         if n_launch.value > 0:
             ach = executed / (tot_ms.value * 1e-3) / 1e12
             roofline = {"kernel": "all MFMA GEMM launches of one training step (tapconv_mfma / wgrad_mfma / forward layer): "

@@ -44,6 +44,11 @@ bool tapconv_glu_supported(int M, int K, int L);   // epilogue 6 (GLU + residual
 int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s);
 int launch_tapconv_pack_transposed(const float* W, float* out, int O, int C, int T, int ldo, int coff, float scale,
                                    hipStream_t s);
+// Winograd F(2,3) form of the T = 3, sign = -1 data gradient (wavenet_backward_wino.hip): A = fragments of the [M][4 K]
+// transformed weights (launch_tapwino_pack_transposed + pack_a_frag), nkg_total = K / 2; power-of-two dilations
+bool tapwino_mfma_supported(int M, int K, int dil);
+int launch_tapwino_mfma(const TapConvArgs& a, hipStream_t s);
+int launch_tapwino_pack_transposed(const float* W, float* out, int O, int C, hipStream_t s);
 
 struct WgradArgs {
     const float* dY;             // [B][O][L]

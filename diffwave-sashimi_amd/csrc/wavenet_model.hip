@@ -44,6 +44,7 @@ struct WaveNetModel : dws_model {
     // embedding MLP, gradient scratch
     std::vector<DevBuf> tx, tH;
     std::vector<DevBuf> ATd, ATg;    // transposed-weight A fragments of the adjoint GEMMs (training only)
+    std::vector<DevBuf> ATw;         // the dilated conv's adjoint in Winograd F(2,3) form (wavenet_backward_wino.hip)
     DevBuf ATf, wpart, bpart;               // same for final_conv[0]; split-N partials of the weight gradients
     bool mfma_bwd = false;
     uint64_t commit_version = 0, bwd_pack_version = ~0ull;
@@ -200,12 +201,17 @@ struct WaveNetModel : dws_model {
     // Transposed weights of the adjoint GEMMs in A-fragment order (rebuilt after every commit).
     int pack_bwd(hipStream_t s) {
         const float r2 = 0.70710678118654752440f;
-        ATd.resize(NL); ATg.resize(NL);
-        DWS_TRY(tmp_pack.ensure((size_t)std::max(std::max(6 * C * C, (S + C) * C), S * S) * 4));
+        ATd.resize(NL); ATg.resize(NL); ATw.resize(NL);
+        DWS_TRY(tmp_pack.ensure((size_t)std::max(std::max(8 * C * C, (S + C) * C), S * S) * 4));
         for (int n = 0; n < NL; ++n) {
             DWS_TRY(ATd[n].ensure((size_t)6 * C * C * 4));
             DWS_TRY(launch_tapconv_pack_transposed(Wd(n), tmp_pack.f(), 2 * C, C, 3, 6 * C, 0, 1.f, s));
             DWS_TRY(launch_pack_a_frag(tmp_pack.f(), ATd[n].f(), C, 6 * C, s));
+            if (tapwino_mfma_supported(C, 2 * C, 1 << (n % cycle))) {   // Winograd form of the same adjoint: [C][4 * 2C]
+                DWS_TRY(ATw[n].ensure((size_t)8 * C * C * 4));
+                DWS_TRY(launch_tapwino_pack_transposed(Wd(n), tmp_pack.f(), 2 * C, C, s));
+                DWS_TRY(launch_pack_a_frag(tmp_pack.f(), ATw[n].f(), C, 8 * C, s));
+            }
             DWS_TRY(ATg[n].ensure((size_t)(S + C) * C * 4));
             DWS_TRY(launch_tapconv_pack_transposed(Wrs[n].f() + (size_t)C * C, tmp_pack.f(), S, C, 1, S + C, 0, 1.f, s));
             DWS_TRY(launch_tapconv_pack_transposed(Wrs[n].f(), tmp_pack.f(), C, C, 1, S + C, S, r2, s));
@@ -465,7 +471,12 @@ struct WaveNetModel : dws_model {
                 TapConvArgs q{};
                 q.src0 = dHb.f(); q.K0 = 2 * C; q.A = ATd[n].f(); q.nkg_total = 6 * C / 8; q.M = C; q.T = 3; q.dil = dil;
                 q.sign = -1; q.out = dh; q.B = nB; q.L = nL;
-                DWS_TRY(launch_tapconv_mfma(q, s));
+                if (wino_opt && tapwino_mfma_supported(C, 2 * C, dil) && ATw[n].p) {   // conv_algo covers the adjoint too
+                    q.A = ATw[n].f(); q.nkg_total = C;
+                    DWS_TRY(launch_tapwino_mfma(q, s));
+                } else {
+                    DWS_TRY(launch_tapconv_mfma(q, s));
+                }
             } else {
                 DWS_TRY(launch_conv_t(dHb.f(), Wd(n), dh, nB, 2 * C, C, nL, 3, dil, 1.f, 0, s));
             }

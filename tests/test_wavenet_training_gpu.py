@@ -57,6 +57,44 @@ def test_wavenet_parameter_gradients_match_autograd(gpu, name):
     print(f"{name}: worst parameter-gradient rel err {worst:.3e} ({k})")
 
 
+AB_CASES = {
+    # 2 M-tiles per wave (C = 256), dilations 1..64, ragged L, B > 1
+    "c256": (TRAIN_CASES["c256"][0], 2, 333),
+    # 1 M-tile per wave (C = 128), L over several 64-column pair tiles
+    "c128_s256": (TRAIN_CASES["c128_s256"][0], 1, 1030),
+    # a full dilation cycle: d = 1 .. 2048 with d > L in the last layers, positions past L in the last pair block
+    "cycle12": (cases.wn_cfg(res_channels=128, skip_channels=128, num_res_layers=12, dilation_cycle=12), 1, 600),
+}
+
+
+@pytest.mark.parametrize("name", list(AB_CASES))
+def test_winograd_and_direct_training_paths_agree(gpu, name):
+    """`conv_algo` selects the form of the dilated conv in the training forward AND of its data gradient
+    (`csrc/wavenet_backward_wino.hip`: Winograd F(2,3) along the dilation stride; `direct`: three shifted taps).  Same
+    weights, same batch: every parameter gradient must agree far inside the 1e-3 gate."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from diffwave_sashimi_amd.training import training_loss
+    cfg, B, L = AB_CASES[name]
+    dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
+    audio = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(77))
+    grads = {}
+    for algo in ("winograd", "direct"):
+        net = cases.build_ours(cfg, 5).to(gpu).train()
+        net.set_option("conv_algo", algo)
+        loss = training_loss(net, nn.MSELoss(), audio.to(gpu), dh, generator=torch.Generator().manual_seed(3))
+        loss.backward()
+        grads[algo] = ({k: p.grad.detach().cpu() for k, p in net.named_parameters()}, float(loss))
+    (gw, lw), (gd, ld) = grads["winograd"], grads["direct"]
+    assert abs(lw - ld) < 1e-5 * max(1.0, abs(ld))
+    # (init_conv's weight_v has ONE input channel: its weight-norm gradient is analytically zero, what is left is 1e-10
+    # of rounding -- tensors that far below the others carry no signal to compare)
+    top = max(float(g.abs().max()) for g in gd.values())
+    worst = max((rel_err(gw[k], gd[k]), k) for k in gd if float(gd[k].abs().max()) > 1e-6 * top)
+    print(f"{name}: largest winograd-vs-direct gradient difference {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < 2e-4, worst
+    assert any(not torch.equal(gw[k], gd[k]) for k in gd)          # two different arithmetic paths
+
+
 def test_training_step_reduces_the_loss_and_eval_path_still_works(gpu):
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
     from diffwave_sashimi_amd.training import training_loss
