@@ -127,6 +127,19 @@ def wino_dgrad_executed_work(cfg):
     return tot / len(dil)
 
 
+def wino_wgrad_executed_work(cfg):
+    """MFMA flops of the dilated conv's weight gradient in the Winograd pairing (wgrad_wino_kernel): four [2C x C] GEMMs
+    over the pair columns, chunks of 64, instead of three over all positions (12 C^2 flop per position)."""
+    m = cfg["model"]
+    C, B, L = m["res_channels"], cfg["B"], cfg["L"]
+    tot = 0
+    dil = [1 << (n % m["dilation_cycle"]) for n in range(m["num_res_layers"])]
+    for d in dil:
+        nblk = -(-L // (2 * d))
+        tot += B * (-(-(nblk * d) // 64)) * 64 * 16 * C * C
+    return tot / len(dil)
+
+
 def sashimi_tail_work(cfg):
     """All S4-tail launches of one step: per block 12 H^2 flops and 12 H bytes per position
     (read g and x, write out; the three GEMMs Wo, W1, W2), summed over the U-Net's blocks."""
@@ -316,6 +329,9 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
             if m["res_channels"] % 128 == 0 and os.environ.get("DWS_TAPCONV_DIRECT") is None:   # the data gradient too
                 C = m["res_channels"]
                 executed -= m["num_res_layers"] * (B * cfg["L"] * 12 * C * C - wino_dgrad_executed_work(dict(cfg, B=B)))
+            if os.environ.get("DWS_WGRAD_DIRECT") is None:   # and the weight gradient (any channel count)
+                C = m["res_channels"]
+                executed -= m["num_res_layers"] * (B * cfg["L"] * 12 * C * C - wino_wgrad_executed_work(dict(cfg, B=B)))
         if n_launch.value > 0:
             ach = executed / (tot_ms.value * 1e-3) / 1e12
             roofline = {"kernel": "all MFMA GEMM launches of one training step (tapconv_mfma / wgrad_mfma / forward layer): "

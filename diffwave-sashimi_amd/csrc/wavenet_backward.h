@@ -63,4 +63,8 @@ struct WgradArgs {
 };
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T);
 int launch_wgrad_mfma(const WgradArgs& a, int T, float scale, float* dW, hipStream_t s);
+// The T = 3 weight gradient in Winograd F(2,3) pairing (wavenet_backward_wino.hip): partial is [nsplit][O][C][4]
+bool wgrad_wino_supported(const WgradArgs& a);
+int wgrad_wino_nsplit(int B, int O, int C, int L, int dil);
+int launch_wgrad_wino(const WgradArgs& a, float scale, float* dW, hipStream_t s);
 }  // namespace dws

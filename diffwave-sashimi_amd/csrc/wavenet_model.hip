@@ -234,13 +234,15 @@ struct WaveNetModel : dws_model {
         WgradArgs w{};
         w.dY = dY; w.X = X; w.addc = addc; w.addc_bstride = addc_bs;
         w.B = (int)B; w.O = O; w.C = Cc; w.L = (int)L; w.dil = dil;
-        w.nsplit = wgrad_mfma_nsplit((int)B, O, Cc, (int)L, T);
-        DWS_TRY(wpart.ensure((size_t)w.nsplit * O * Cc * T * 4));
+        const bool wino_w = T == 3 && wino_opt && wgrad_wino_supported(w);   // conv_algo covers this adjoint too
+        w.nsplit = wino_w ? wgrad_wino_nsplit((int)B, O, Cc, (int)L, dil) : wgrad_mfma_nsplit((int)B, O, Cc, (int)L, T);
+        DWS_TRY(wpart.ensure((size_t)w.nsplit * O * Cc * (wino_w ? 4 : T) * 4));
         w.partial = wpart.f();
         if (db) {
             DWS_TRY(bpart.ensure((size_t)w.nsplit * O * 4));
             w.bias_part = bpart.f(); w.dbias = db; w.bias_scale = bscale;
         }
+        if (wino_w) return launch_wgrad_wino(w, scale, dW, s);
         return launch_wgrad_mfma(w, T, scale, dW, s);
     }
 

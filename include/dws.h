@@ -133,8 +133,8 @@ int dws_model_update_params(dws_model* m, int32_t count, const char* const* name
  *   "conv_algo" = "winograd" (default) WaveNet residual layers (precision f32) with the dilated 3-tap convolution in
  *                          Winograd F(2,3) form along the dilation stride: 8 C^2 instead of 12 C^2 flop per position,
  *                          one extra fp32 rounding in the weights and in the inputs (same 1e-6 class error); the
- *                          training step's data gradient of that convolution runs the same form
- *               = "direct" the direct three-tap form, forward and data gradient (A/B runs). */
+ *                          training step's data and weight gradients of that convolution run the same pairing
+ *               = "direct" the direct three-tap form, forward and both adjoints (A/B runs). */
 int dws_model_set_option(dws_model* m, const char* key, const char* value);
 
 /* Fold / pack everything that depends only on the weights.  Called implicitly
