@@ -204,13 +204,17 @@ struct WaveNetModel : dws_model {
         ATd.resize(NL); ATg.resize(NL); ATw.resize(NL);
         DWS_TRY(tmp_pack.ensure((size_t)std::max(std::max(8 * C * C, (S + C) * C), S * S) * 4));
         for (int n = 0; n < NL; ++n) {
-            DWS_TRY(ATd[n].ensure((size_t)6 * C * C * 4));
-            DWS_TRY(launch_tapconv_pack_transposed(Wd(n), tmp_pack.f(), 2 * C, C, 3, 6 * C, 0, 1.f, s));
-            DWS_TRY(launch_pack_a_frag(tmp_pack.f(), ATd[n].f(), C, 6 * C, s));
-            if (tapwino_mfma_supported(C, 2 * C, 1 << (n % cycle))) {   // Winograd form of the same adjoint: [C][4 * 2C]
+            // the dilated conv's adjoint weights in the form the step will use (re-packed after every optimizer step):
+            // Winograd [C][4 * 2C] or direct [C][3 * 2C]; a conv_algo change goes through commit and lands here again
+            if (wino_opt && tapwino_mfma_supported(C, 2 * C, 1 << (n % cycle))) {
                 DWS_TRY(ATw[n].ensure((size_t)8 * C * C * 4));
                 DWS_TRY(launch_tapwino_pack_transposed(Wd(n), tmp_pack.f(), 2 * C, C, s));
                 DWS_TRY(launch_pack_a_frag(tmp_pack.f(), ATw[n].f(), C, 8 * C, s));
+            } else {
+                ATw[n].release();
+                DWS_TRY(ATd[n].ensure((size_t)6 * C * C * 4));
+                DWS_TRY(launch_tapconv_pack_transposed(Wd(n), tmp_pack.f(), 2 * C, C, 3, 6 * C, 0, 1.f, s));
+                DWS_TRY(launch_pack_a_frag(tmp_pack.f(), ATd[n].f(), C, 6 * C, s));
             }
             DWS_TRY(ATg[n].ensure((size_t)(S + C) * C * 4));
             DWS_TRY(launch_tapconv_pack_transposed(Wrs[n].f() + (size_t)C * C, tmp_pack.f(), S, C, 1, S + C, 0, 1.f, s));
