@@ -1,6 +1,8 @@
 // Mel-spectrogram conditioner (`models/wavenet.py:98-111` == `models/sashimi.py:160-175`).
 // Constant per utterance, so it is evaluated once in dws_model_set_condition()
 // instead of in every block on every reverse step as the reference does.
+#include <cstdlib>
+
 #include "conditioner.h"
 
 namespace dws {
@@ -33,8 +35,54 @@ __global__ void mel_upsample_kernel(const float* __restrict__ in, const float* _
     }
 }
 
+// The same sum when the stride is a power of two (the usual hop = 16 x 16): output x receives exactly two input
+// columns, ix0 = (x + s/2) >> log2 s with kernel column kx0 = (x + s/2) & (s - 1) and ix0 - 1 with kx0 + s (a third
+// candidate always falls outside the 2s-wide kernel), so the column search, its bounds tests and the integer division
+// of the general kernel go away; four outputs per thread.  Same order of additions (ix descending, ky ascending):
+// bit-identical results.
+__global__ __launch_bounds__(256) void mel_upsample_pow2_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                int M, int Tin, int Tout, int log2s, float slope) {
+    const int bm = blockIdx.z, m = blockIdx.y, s = 1 << log2s, pad = s >> 1, kw = 2 * s;
+    const float* inb = in + (size_t)bm * M * Tin;
+    const float b0 = bias[0];
+    // rows m+1, m, m-1 (ky = 0, 1, 2); a row outside [0, M) contributes nothing
+    const bool r0 = m + 1 < M, r2 = m >= 1;
+    const float* i0 = inb + (size_t)(r0 ? m + 1 : m) * Tin;
+    const float* i1 = inb + (size_t)m * Tin;
+    const float* i2 = inb + (size_t)(r2 ? m - 1 : m) * Tin;
+    float* ob = out + ((size_t)bm * M + m) * Tout;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int x = (blockIdx.x * 4 + u) * 256 + threadIdx.x;
+        if (x >= Tout) break;
+        const int xp = x + pad, ixa = xp >> log2s, kxa = xp & (s - 1);
+        float acc = b0;
+        if (ixa < Tin) {
+            if (r0) acc = fmaf(i0[ixa], W[kxa], acc);
+            acc = fmaf(i1[ixa], W[kw + kxa], acc);
+            if (r2) acc = fmaf(i2[ixa], W[2 * kw + kxa], acc);
+        }
+        const int ixb = ixa - 1, kxb = kxa + s;
+        if (ixb >= 0 && ixb < Tin) {
+            if (r0) acc = fmaf(i0[ixb], W[kxb], acc);
+            acc = fmaf(i1[ixb], W[kw + kxb], acc);
+            if (r2) acc = fmaf(i2[ixb], W[2 * kw + kxb], acc);
+        }
+        ob[x] = acc > 0.f ? acc : acc * slope;
+    }
+}
+
 int launch_mel_upsample(const float* in, const float* W, const float* bias, float* out, int Bm, int M, int Tin,
                         int Tout, int s, float slope, hipStream_t st) {
+    static const bool generic = getenv("DWS_MEL_UPSAMPLE_GENERIC") != nullptr;
+    if (!generic && s >= 2 && (s & (s - 1)) == 0) {
+        int log2s = 0;
+        while ((1 << log2s) < s) ++log2s;
+        dim3 grid(ceil_div(Tout, 1024), M, Bm);
+        hipLaunchKernelGGL(mel_upsample_pow2_kernel, grid, dim3(256), 0, st, in, W, bias, out, M, Tin, Tout, log2s, slope);
+        return DWS_OK;
+    }
     dim3 grid(min(ceil_div(Tout, 256), 1024), M, Bm);
     hipLaunchKernelGGL(mel_upsample_kernel, grid, dim3(256), 0, st, in, W, bias, out, M, Tin, Tout, s, slope);
     return DWS_OK;
