@@ -475,8 +475,8 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
         t0 = time.perf_counter()
         try:
             r = sample_bench(a, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False)
-            out[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")
-                         if k in r}
+            out[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
+                                           "conditioner_ms_per_batch", "end_to_end_samples_per_s_incl_conditioner") if k in r}
         except Exception as e:      # noqa: BLE001 -- reported, not swallowed
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
