@@ -476,7 +476,8 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
         try:
             r = sample_bench(a, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False)
             out[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
-                                           "conditioner_ms_per_batch", "end_to_end_samples_per_s_incl_conditioner") if k in r}
+                                           "conditioner_ms_per_batch", "conditioner_ms_all_calls",
+                                           "end_to_end_samples_per_s_incl_conditioner") if k in r}
         except Exception as e:      # noqa: BLE001 -- reported, not swallowed
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
@@ -544,12 +545,15 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
         net._set_condition(mel)
         # the conditioner runs once per batch of utterances, not per reverse step: timed on its own (outside `value`,
         # whose unit is the per-step rate) so that the end-to-end rate of a whole T-step run can be stated beside it
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        for _ in range(3):
-            net._set_condition(mel + 0.0)   # a new tensor each time: the module caches on the mel it was given
-        torch.cuda.synchronize()
-        cond_ms = (time.perf_counter() - tc) / 3 * 1e3
+        cond_all = []
+        for _ in range(6):
+            m2 = mel + 0.0                  # a new tensor each time: the module caches on the mel it was given
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            net._set_condition(m2)
+            torch.cuda.synchronize()
+            cond_all.append((time.perf_counter() - tc) * 1e3)
+        cond_ms = sorted(cond_all[1:])[len(cond_all[1:]) // 2]      # median of five after one more untimed call
     x = torch.randn(B, 1, L, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     stream = _lib.current_stream()
     seed = ddist.rank_seed(1234, rank)
@@ -592,6 +596,7 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
 
     if "Tmel" in cfg:
         result["conditioner_ms_per_batch"] = cond_ms
+        result["conditioner_ms_all_calls"] = cond_all
         result["end_to_end_samples_per_s_incl_conditioner"] = ddist.aggregate_throughput(
             B * L, world, T * ms_per_step * 1e-3 + cond_ms * 1e-3)
 
