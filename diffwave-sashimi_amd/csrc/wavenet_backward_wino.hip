@@ -61,11 +61,27 @@ __global__ __launch_bounds__(512, 1) void tapwino_mfma_kernel(TapConvArgs a, int
     if (pos_of(q0) >= L) return;                                    // d > L: the columns past the row (uniform)
     const int K = a.K0, ncb = K / KC;
 
-    // staging: row (j, cc) of a chunk = x[k0 + cc, p(q0 + lane) + (j - 1) d]; a wave moves 16 of the 128 rows
+    // staging: row (j, cc) of a chunk = x[k0 + cc, p(q0 + lane) + (j - 1) d]; a wave moves 16 of the 128 rows.
+    // L % 4 == 0 and d >= 4: four consecutive pair columns are four consecutive, 16-byte aligned positions at every shift,
+    // so the chunk moves as 16-byte LDS-DMA -- four whole rows (4 x 64 columns) per instruction, 4 instructions per wave and
+    // chunk instead of 16; a quad outside [0, L) gets an offset past the chunk's descriptor (reads 0).
     const int pv = pos_of(q0 + lane) * 4;
+    const bool x4 = (L % 4 == 0) && log2d >= 2 && ((size_t)a.src0 % 16 == 0);
+    const int p4 = pos_of(q0 + 4 * (lane & 15));
     auto stage_dma = [&](int cb, int buf) {
         float* xs = lds + buf * (ROWS * P);
         const float* base = a.src0 + ((size_t)b * K + (size_t)cb * KC) * L;
+        if (x4) {
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, KC * L * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ii = wave + 8 * i, j = ii >> 3, r4 = ii & 7;
+                const int pos = p4 + (j - 1) * d;
+                const int voff = ((unsigned)pos < (unsigned)L) ? ((4 * r4 + (lane >> 4)) * L + pos) * 4 : 0x7ffffff0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + (j * KC + 4 * r4) * P, 16, voff, 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < ROWS / 8; ++i) {
             const int row = wave + 8 * i;

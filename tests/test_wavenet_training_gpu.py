@@ -60,6 +60,8 @@ def test_wavenet_parameter_gradients_match_autograd(gpu, name):
 AB_CASES = {
     # 2 M-tiles per wave (C = 256), dilations 1..64, ragged L, B > 1
     "c256": (TRAIN_CASES["c256"][0], 2, 333),
+    # the same with L % 4 == 0: the 16-byte LDS-DMA staging of the Winograd data gradient at d >= 4
+    "c256_x4": (TRAIN_CASES["c256"][0], 2, 336),
     # 1 M-tile per wave (C = 128), L over several 64-column pair tiles
     "c128_s256": (TRAIN_CASES["c128_s256"][0], 1, 1030),
     # a full dilation cycle: d = 1 .. 2048 with d > L in the last layers, positions past L in the last pair block
