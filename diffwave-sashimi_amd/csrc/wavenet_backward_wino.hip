@@ -364,7 +364,10 @@ int wgrad_wino_nsplit(int B, int O, int C, int L, int dil) {
     const int nq = (int)((((long long)L + 2 * dil - 1) >> (log2d + 1)) << log2d);
     const int tiles = ceil_div(O, 128) * ceil_div(C, 128) * 4;
     const int chunks = B * ceil_div(nq, 64);
-    return std::min(std::max(1, 512 / tiles), chunks);     // two workgroups per CU, as the three-tap kernel
+    // workgroups to aim for (experiments: DWS_WGRAD_WINO_TARGET).  Same box, WaveNet training step: 512 -> 59.4 ms,
+    // 768 -> 61.7, 1024 -> 60.0, 256 -> 63.6
+    static const int target = getenv("DWS_WGRAD_WINO_TARGET") ? atoi(getenv("DWS_WGRAD_WINO_TARGET")) : 512;
+    return std::min(std::max(1, target / tiles), chunks);  // two workgroups per CU, as the three-tap kernel
 }
 
 // a.partial: [nsplit][O][C][4] floats, a.nsplit from wgrad_wino_nsplit
