@@ -176,11 +176,12 @@ def forward_gemm_flops(cfg, B):
     return flops + 2 * m["d_model"] ** 2 * L * B
 
 
-def cpu_baseline(cfg, seconds_budget=25.0):
+def cpu_baseline(cfg, seconds_budget=25.0, light=False):
     """The oracle (reference-equivalent PyTorch-CPU graph: conv1d per layer, weight-norm
     per call, no hoisting) timed on this box's host cores at B=1; bounded sample.
     MKL-DNN convolutions of this size get *slower* with hundreds of threads, so a few
-    thread counts are probed first and the best one is used (`cores` = threads used)."""
+    thread counts are probed first and the best one is used (`cores` = threads used).
+    light: the short form beside an extra_configs leg (B=1 only, at least two timed steps, no single-thread leg)."""
     from oracle import sashimi as osa
     from oracle import wavenet as own
     from diffwave_sashimi_amd.models import construct_model
@@ -215,7 +216,7 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     torch.set_num_threads(best)
     one()
     times = []
-    while len(times) < 3 or (time.perf_counter() - t_begin < seconds_budget and len(times) < 10):
+    while len(times) < (2 if light else 3) or (time.perf_counter() - t_begin < seconds_budget and len(times) < 10):
         times.append(one())
         if time.perf_counter() - t_begin > 2 * seconds_budget:
             break
@@ -226,6 +227,8 @@ def cpu_baseline(cfg, seconds_budget=25.0):
            "ms_per_step_b1": per_step * 1e3, "cpu_model": _cpu_model()}
     # the config's own batch (SURVEY.md 8d asks for B=1 and the config's B): one warm-up + up to 2 timed steps, bounded
     Bc = cfg["B"]
+    if light:
+        return out
     if Bc > 1 and per_step * Bc < 40.0:
         audio_b, steps_b = torch.randn(Bc, 1, L), torch.full((Bc, 1), float(T - 1))
         mel_b = None if mel is None else mel.expand(Bc, -1, -1).contiguous()
@@ -251,6 +254,52 @@ def cpu_baseline(cfg, seconds_budget=25.0):
         out["single_thread_value"] = L / (T * t1)
         torch.set_num_threads(best)
     return out
+
+
+def cpu_train_baseline(cfg, seconds_budget=30.0):
+    """One `train.py:118-143`-style step of the oracle on the host cores at B=1: q-sample, forward, MSE against the noise,
+    backward through torch autograd of the reference-equivalent CPU graph (no optimizer: its cost is negligible beside
+    the backward).  Bounded sample: a first step that already takes > 8 s IS the sample (it includes the one-time
+    allocator warm-up), otherwise a second step is timed."""
+    from oracle import sashimi as osa
+    from oracle import wavenet as own
+    from diffwave_sashimi_amd.models import construct_model
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    ncpu = os.cpu_count() or 1
+    th = min(32, ncpu)
+    torch.set_num_threads(th)
+    torch.manual_seed(0)
+    net = construct_model(dict(cfg["model"]))
+    leaf = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v.clone())
+            for k, v in net.state_dict().items()}
+    fwd = own.wavenet_forward if cfg["model"]["_name_"] == "wavenet" else osa.sashimi_forward
+    L, T = cfg["L"], cfg["diffusion"]["T"]
+    dh = calc_diffusion_hyperparams(**cfg["diffusion"])
+    g = torch.Generator().manual_seed(7)
+    audio = (torch.rand(1, 1, L, generator=g) * 2 - 1) * 0.3
+
+    def one():
+        t0 = time.perf_counter()
+        for v in leaf.values():
+            if v.is_floating_point():
+                v.grad = None
+        ts = torch.randint(T, (1, 1, 1), generator=g)
+        z = torch.randn(audio.shape, generator=g)
+        ab = dh["Alpha_bar"][ts]
+        xt = torch.sqrt(ab) * audio + torch.sqrt(1 - ab) * z          # `train.py:221`
+        eps = fwd(leaf, cfg["model"], xt, ts.view(1, 1))
+        loss = torch.nn.functional.mse_loss(eps, z)
+        loss.backward()
+        return time.perf_counter() - t0
+
+    times = [one()]
+    if times[0] < 8.0 or times[0] * 2 < seconds_budget:
+        times.append(one())
+    t = times[-1]
+    return {"value": L / t, "unit": "training audio samples/s", "cores": th, "host_cpus": ncpu, "kind": "port",
+            "sample": "%d training step(s) (q-sample + forward + MSE + autograd backward of the oracle) at B=1, L=%d with %d "
+                      "threads; the last one is reported" % (len(times), L, th),
+            "ms_per_step_b1": t * 1e3, "steps_ms": [x * 1e3 for x in times], "cpu_model": _cpu_model()}
 
 
 def _cpu_model():
@@ -476,12 +525,30 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
         try:
             r = sample_bench(a, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False)
             out[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
-                                           "conditioner_ms_per_batch", "conditioner_ms_all_calls",
+                                           "full_loop", "hbm_bytes_in_use", "conditioner_ms_per_batch", "conditioner_ms_all_calls",
                                            "end_to_end_samples_per_s_incl_conditioner") if k in r}
+            if not args.no_cpu_baseline:     # the oracle on this box's host cores beside the leg (B = 1, bounded)
+                out[name]["cpu_baseline"] = cpu_baseline(dict(CONFIGS[name]), seconds_budget=10.0, light=True)
+                out[name]["gpu_over_cpu"] = out[name]["value"] / out[name]["cpu_baseline"]["value"]
         except Exception as e:      # noqa: BLE001 -- reported, not swallowed
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
         out[name]["leg_seconds"] = time.perf_counter() - t0
+    # the reference's own documented operating points (`README.md:215`: unet_d128 sampled at B = 128 per GPU, "the largest
+    # batch that fits on an A100"; `README.md:228`: unet_d64 at B = 256): short legs, with the HBM actually in use
+    for name, bsz, steps in (("unet_d128_n6_T200", 128, 6), ("unet_d64_n6_T200", 256, 8)):
+        a = copy.copy(args)
+        a.config, a.steps, a.warmup, a.no_roofline = name, steps, 2, True
+        key = "%s B=%d (README operating point)" % (name, bsz)
+        t0 = time.perf_counter()
+        try:
+            r = sample_bench(a, dict(CONFIGS[name], B=bsz), world, rank, dev, ddist, red_dev, extras=False, full=False)
+            out[key] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
+                                          "hbm_bytes_in_use") if k in r}
+        except Exception as e:      # noqa: BLE001
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+        out[key]["leg_seconds"] = time.perf_counter() - t0
     a = copy.copy(args)
     a.config, a.steps, a.warmup, a.mode, a.batch = "unet_d128_n6_T200", 4, 2, "train", None
     t0 = time.perf_counter()
@@ -490,6 +557,9 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
         r = train_bench(a, dict(CONFIGS[a.config]), world, rank, dev, ddist, red_dev, emit=False)
         out[key] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
                                       "final_loss") if k in r}
+        if not args.no_cpu_baseline:
+            out[key]["cpu_baseline"] = cpu_train_baseline(dict(CONFIGS[a.config]))
+            out[key]["gpu_over_cpu"] = out[key]["value"] / out[key]["cpu_baseline"]["value"]
     except Exception as e:      # noqa: BLE001
         out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
@@ -520,7 +590,7 @@ def profiled_step_ms(lib, run_eager_steps, name, nprof, per_step):
     return tot
 
 
-def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
+def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=True):
     """One sampling measurement (the headline, or an extra leg): returns the result line as a dict (rank 0 prints it)."""
     import ctypes
     import numpy as np
@@ -594,6 +664,22 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
         "per_rank_state_digest": ddist.gather_over_ranks(float(x.double().abs().sum()), red_dev),
     }
 
+    free_b, total_b = torch.cuda.mem_get_info()
+    result["hbm_bytes_in_use"] = int(total_b - free_b)     # device-wide (engine workspaces are hipMalloc'ed, not torch's)
+
+    if rank == 0 and full:
+        # the metric as `generate.py:49-54` defines it: ONE complete T-step loop -- Philox draw of x_T, then T replays of the
+        # captured step -- wall-clocked end to end on this rank (launch to synchronize), beside the per-step rate above
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        _lib.check(lib.dws_sampler_run(net._handle, x.data_ptr(), *ptabs, T, None, seed, 1, 1, stream))
+        torch.cuda.synchronize()
+        loop_ms = (time.perf_counter() - tl) * 1e3
+        result["full_loop"] = {
+            "what": "one complete dws_sampler_run: on-device Philox x_T + T=%d graph replays, host wall clock" % T,
+            "ms": loop_ms, "T": T, "ms_per_step": loop_ms / T, "ratio_to_timed_ms_per_step": loop_ms / T / ms_per_step,
+            "samples_per_s_this_rank": B * L / (loop_ms * 1e-3), "finite": bool(torch.isfinite(x).all())}
+
     if "Tmel" in cfg:
         result["conditioner_ms_per_batch"] = cond_ms
         result["conditioner_ms_all_calls"] = cond_all
@@ -620,17 +706,29 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True):
         executed = wino_executed_work(cfg) if wino else flops
         ach = executed / (avg_ms * 1e-3) / 1e12
         eff = flops / (avg_ms * 1e-3) / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r03_wavenet_traffic.json" if wino else "r02_wavenet_traffic.json")
-        if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and os.path.exists(tfile):
-            # PMC-derived HBM bytes per launch of this kernel (collected with rocprofv3 in
-            # separate --pmc passes on the same command; corrected as the guide prescribes)
-            traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
         kname = ("wn_layer_wino_kernel" if wino else "wn_layer_mfma_kernel") if args.precision == "f32" else "wn_layer_bf16x3_kernel"
+        traffic, traffic_note = None, None
+        if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and args.precision == "f32":
+            # PMC-derived HBM bytes per launch of this kernel (tools/r04_traffic.sh: rocprofv3 in separate --pmc passes on
+            # the same command, corrected as the guide prescribes).  The newest profiles/r*_wavenet_traffic.json is used
+            # only if it was measured on THIS kernel: same name, and SQ_INSTS_MFMA x 4096 within 1 % of the executed flops
+            # computed above -- a file left over from another kernel version is refused, not silently reported.
+            import glob
+            for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wavenet_traffic.json")), reverse=True):
+                tj = json.load(open(tfile))
+                cnt = tj.get("sq_insts_mfma_per_launch")
+                if not tj.get("kernel", "").startswith(kname):
+                    traffic_note = "%s refused: measured on %s" % (os.path.basename(tfile), tj.get("kernel"))
+                elif cnt is None or abs(cnt * 4096 / executed - 1) > 0.01:
+                    traffic_note = "%s refused: SQ_INSTS_MFMA x 4096 = %s vs executed flops %.4g" % (
+                        os.path.basename(tfile), cnt and "%.4g" % (cnt * 4096), executed)
+                else:
+                    traffic, traffic_note = tj["hbm_bytes_per_launch"], os.path.basename(tfile)
+                break
         result["roofline"] = {
             "kernel": "%s<%d,%d>" % (kname, cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": traffic if args.precision == "f32" else None,
+            "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_note,
             "executed_flops_per_launch": executed,
             "effective_TFLOPs_on_direct_conv_flops": eff, "effective_frac": eff / peak,
             "algorithm": ("Winograd F(2,3) along the dilation stride (4 K=C products per position pair instead of 6)"

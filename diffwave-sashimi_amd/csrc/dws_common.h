@@ -49,6 +49,12 @@ bool profile_active();
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Step-table mode of the sampler: element offset of row *idx (the device-resident step counter) of a [T][stride] table;
+// 0 when the kernel runs on per-clip rows (idx == nullptr).  idx is a kernel argument: the load is scalar.
+__device__ __forceinline__ size_t step_row_off(const int* __restrict__ idx, int stride) {
+    return idx ? (size_t)__builtin_amdgcn_readfirstlane(*idx) * (size_t)stride : (size_t)0;
+}
+
 // ---------------------------------------------------------------------------
 // Fast transcendental forms on v_exp_f32 / v_rcp_f32 (1 ulp each).
 // GELU(erf) via Abramowitz-Stegun 7.1.26 for erfc (|eps| <= 1.5e-7):

@@ -103,7 +103,7 @@ struct dws_model {
     std::vector<float> smp_host_tables;  // host copy of what is resident (upload skipped when identical)
     dws::DevBuf smp_state;    // int32 step index
     dws::DevBuf smp_eps;      // eps[B, Cout, L]
-    dws::DevBuf smp_steps;    // float steps[B]
+    const int* step_idx = nullptr;   // set by the sampler around forward(): step-table mode, row *step_idx (device memory)
     hipGraphExec_t smp_graph = nullptr;
     hipStream_t smp_stream = nullptr;  // capture/replay stream (the caller's may be the null stream)
     hipEvent_t smp_ev_in = nullptr, smp_ev_out = nullptr;
@@ -124,7 +124,10 @@ struct dws_model {
     virtual int commit(hipStream_t s) = 0;
     virtual int prepare(int64_t B, int64_t L) = 0;
     virtual int set_condition(const float* mel, int64_t Bm, int64_t Tmel, hipStream_t s) = 0;
+    // steps may be null only while step_idx is set (sampler): the step-only terms then come from the step table
     virtual int forward(const float* audio, const float* steps, float* out, hipStream_t s) = 0;
+    // evaluate everything that depends on the diffusion step only for t = 0..T-1 (kept until the weights or T change)
+    virtual int build_step_table(int T, hipStream_t s) = 0;
     virtual int read_tap(const char* tap, float* dst, int64_t capacity, hipStream_t s) = 0;
     // training path: forward that keeps what backward needs; backward fills ParamSpec::grad of every parameter
     virtual int forward_train(const float* audio, const float* steps, float* out, hipStream_t s);

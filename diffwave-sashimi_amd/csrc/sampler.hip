@@ -43,13 +43,8 @@ __device__ __forceinline__ void normal4(uint64_t seed, uint32_t t, uint64_t g, f
     z[2] = rb * c; z[3] = rb * s;
 }
 
-__global__ void smp_set_step_kernel(int* t_dev, int t) { *t_dev = t; }
-__global__ void smp_dec_step_kernel(int* t_dev) { *t_dev = *t_dev - 1; }
-
-__global__ void smp_fill_steps_kernel(float* steps, const int* __restrict__ t_dev, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) steps[b] = (float)(*t_dev);  // `generate.py:50`
-}
+// sampler state in device memory: [0] the step index t, [1] number of update blocks that have finished this step
+__global__ void smp_set_step_kernel(int* t_dev, int t) { t_dev[0] = t; t_dev[1] = 0; }
 
 __global__ void smp_fill_normal_kernel(float* __restrict__ x, size_t n, uint64_t seed, uint32_t stream_id) {
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g * 4 < n; g += (size_t)gridDim.x * blockDim.x) {
@@ -64,10 +59,12 @@ __global__ void smp_fill_normal_kernel(float* __restrict__ x, size_t n, uint64_t
 // x <- (x - c1[t]*eps) / c2[t]  (+ sigma[t]*z if t > 0); products and sums are
 // rounded separately (no fma contraction) to match the reference's op-by-op
 // fp32 evaluation (`generate.py:52,54`).
+// The last block to finish moves the step index on (t <- t - 1): every block has read t by then, and the next kernel
+// that reads it is stream-ordered behind this one -- no separate one-thread launch per step.
 __global__ void smp_update_kernel(float* __restrict__ x, const float* __restrict__ eps,
-                                  const float* __restrict__ tables, const int* __restrict__ t_dev,
+                                  const float* __restrict__ tables, int* __restrict__ t_dev,
                                   const float* __restrict__ noise, uint64_t seed, size_t n, int T) {
-    const int t = *t_dev;
+    const int t = __builtin_amdgcn_readfirstlane(*(volatile int*)t_dev);
     const float c1 = tables[t], c2 = tables[T + t], sg = tables[2 * T + t];
     const float* nz = noise ? noise + (size_t)t * n : nullptr;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g * 4 < n; g += (size_t)gridDim.x * blockDim.x) {
@@ -80,6 +77,13 @@ __global__ void smp_update_kernel(float* __restrict__ x, const float* __restrict
             float v = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(c1, eps[i])), c2);
             if (t > 0) v = __fadd_rn(v, __fmul_rn(sg, nz ? nz[i] : z[j]));
             x[i] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(reinterpret_cast<unsigned*>(t_dev + 1), 1u) == gridDim.x - 1) {
+            t_dev[1] = 0;
+            t_dev[0] = t - 1;
         }
     }
 }
@@ -98,7 +102,7 @@ static int upload_tables(dws_model* m, const float* alpha, const float* alpha_ba
     // the device copy is keyed on the table CONTENTS (same T with another beta schedule must not reuse it)
     if (m->smp_T == T && m->smp_host_tables == h) return DWS_OK;
     DWS_TRY(m->smp_tables.ensure(h.size() * 4));
-    DWS_TRY(m->smp_state.ensure(4));
+    DWS_TRY(m->smp_state.ensure(8));
     DWS_HIP(hipMemcpyAsync(m->smp_tables.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
     DWS_HIP(hipStreamSynchronize(s));
     m->smp_T = T;
@@ -109,13 +113,14 @@ static int upload_tables(dws_model* m, const float* alpha, const float* alpha_ba
 static int one_step(dws_model* m, float* x, const float* noise, uint64_t seed, int T, hipStream_t s) {
     const size_t n = (size_t)m->B * m->d.out_channels * m->L;
     int* t_dev = static_cast<int*>(m->smp_state.p);
-    hipLaunchKernelGGL(smp_fill_steps_kernel, dim3(ceil_div(m->B, 64)), dim3(64), 0, s, m->smp_steps.f(), t_dev,
-                       (int)m->B);
-    DWS_TRY(m->forward(x, m->smp_steps.f(), m->smp_eps.f(), s));
+    // every clip is at step t (`generate.py:50`): the network reads row t of the step table built at sampler entry
+    m->step_idx = t_dev;
+    const int st = m->forward(x, nullptr, m->smp_eps.f(), s);
+    m->step_idx = nullptr;
+    DWS_TRY(st);
     const int blocks = (int)std::min<size_t>(ceil_div(n, 4 * 256), 4096);
     hipLaunchKernelGGL(smp_update_kernel, dim3(blocks), dim3(256), 0, s, x, m->smp_eps.f(), m->smp_tables.f(), t_dev,
                        noise, seed, n, T);
-    hipLaunchKernelGGL(smp_dec_step_kernel, dim3(1), dim3(1), 0, s, t_dev);
     return DWS_OK;
 }
 
@@ -128,7 +133,7 @@ static int run_steps(dws_model* m, float* x, int T, int t_start, int n_steps, co
     if (m->dirty) DWS_TRY(m->commit(s));
     const size_t n = (size_t)m->B * m->d.out_channels * m->L;
     DWS_TRY(m->smp_eps.ensure(n * 4));
-    DWS_TRY(m->smp_steps.ensure((size_t)m->B * 4));
+    DWS_TRY(m->build_step_table(T, s));   // step-only part of the network for t = 0..T-1 (kept while weights and T stay)
     int* t_dev = static_cast<int*>(m->smp_state.p);
 
     if (!use_graph) {

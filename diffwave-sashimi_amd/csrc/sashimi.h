@@ -8,8 +8,9 @@ int launch_s4_prep(const float* C, const float* Bp, const float* P, const float*
 int launch_s4_woodbury(const float* r, const float* omega, const float* dt, float* kf, int H, int Lh, int n_even,
                        hipStream_t s);
 int launch_s4_twosided(const float* k, float* K, int H, int L, int Lk, int Lt, hipStream_t s);
+// step_idx != null (sampler's step-table mode): part_t is row 0 of a [T][pt_tstride] table, the kernel adds row *step_idx
 int launch_ln(const float* x, const float* m_p, const float* s_p, const float* part_t, int pt_bstride, float* out,
-              int B, int H, int L, size_t ostride, hipStream_t s);
+              int B, int H, int L, size_t ostride, hipStream_t s, const int* step_idx = nullptr, int pt_tstride = 0);
 int launch_spec_mul(float* uf, const float* kf, int B, int H, int Lf, hipStream_t s);
 int launch_s4_post(const float* yc, const float* u, const float* D, float* g, int B, int H, int L, hipStream_t s);
 int launch_pw_conv(const float* in, const float* W, const float* bias, float* out, int B, int K, int O, int L, int act,

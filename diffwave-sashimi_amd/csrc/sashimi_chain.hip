@@ -291,7 +291,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
             // ---- the next block's S4 input: LN1_next down the columns of the output + its step-embedding projection, which
             // enters as a rank-1 product (A = e column, B = row of ones): one MFMA per row tile puts e[row] into every column
             __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
-            const float* eb = a.e_next + (size_t)b * a.e_stride;
+            const float* eb = a.e_next + (size_t)b * a.e_stride + step_row_off(a.e_step, a.e_tstride);
             const float m2 = xhalf_sum(so) * invH;
             float sv2 = 0.f;
 #pragma unroll

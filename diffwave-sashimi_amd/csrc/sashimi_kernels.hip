@@ -118,10 +118,11 @@ int launch_s4_twosided(const float* k, float* K, int H, int L, int Lk, int Lt, h
 // FFT buffer (rows of length 2L).
 __global__ void ln_kernel(const float* __restrict__ x, const float* __restrict__ m_p, const float* __restrict__ s_p,
                           const float* __restrict__ part_t, int pt_bstride, float* __restrict__ out, int H, int L,
-                          size_t ostride) {
+                          size_t ostride, const int* __restrict__ step_idx, int pt_tstride) {
     const int b = blockIdx.y;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= L) return;
+    if (part_t) part_t += (size_t)b * pt_bstride + step_row_off(step_idx, pt_tstride);
     const float* xb = x + (size_t)b * H * L + l;
     float sum = 0.f;
     for (int h = 0; h < H; ++h) sum += xb[(size_t)h * L];
@@ -136,7 +137,7 @@ __global__ void ln_kernel(const float* __restrict__ x, const float* __restrict__
     float* ob = out + (size_t)b * H * ostride + l;
     for (int h = 0; h < H; ++h) {
         float y = scale * (xb[(size_t)h * L] + shift);
-        if (part_t) y += part_t[(size_t)b * pt_bstride + h];
+        if (part_t) y += part_t[h];
         ob[(size_t)h * ostride] = y;
     }
 }
@@ -147,9 +148,10 @@ template <int RPT>   // rows (channels) held per thread: H <= 4 * RPT
 __global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ m_p,
                                                       const float* __restrict__ s_p, const float* __restrict__ part_t,
                                                       int pt_bstride, float* __restrict__ out, int H, int L,
-                                                      size_t ostride) {
+                                                      size_t ostride, const int* __restrict__ step_idx, int pt_tstride) {
     __shared__ float red[2][4][64];
     const int b = blockIdx.y, col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    if (part_t) part_t += (size_t)b * pt_bstride + step_row_off(step_idx, pt_tstride);
     const int l = blockIdx.x * 64 + col;
     const bool ok = l < L;
     const float* __restrict__ xb = x + (size_t)b * H * L + (ok ? l : 0);
@@ -182,27 +184,27 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ 
         const int h = i * 4 + part;
         if (h < H && ok) {
             float y = scale * (v[i] + shift);
-            if (part_t) y += part_t[(size_t)b * pt_bstride + h];
+            if (part_t) y += part_t[h];
             ob[(size_t)h * ostride] = y;
         }
     }
 }
 
 int launch_ln(const float* x, const float* m_p, const float* s_p, const float* part_t, int pt_bstride, float* out,
-              int B, int H, int L, size_t ostride, hipStream_t s) {
+              int B, int H, int L, size_t ostride, hipStream_t s, const int* step_idx, int pt_tstride) {
     ProfileScope ps("ln_kernel", s);
     if (H <= 128)
         hipLaunchKernelGGL(ln_tile_kernel<32>, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, m_p, s_p, part_t,
-                           pt_bstride, out, H, L, ostride);
+                           pt_bstride, out, H, L, ostride, step_idx, pt_tstride);
     else if (H <= 256)
         hipLaunchKernelGGL(ln_tile_kernel<64>, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, m_p, s_p, part_t,
-                           pt_bstride, out, H, L, ostride);
+                           pt_bstride, out, H, L, ostride, step_idx, pt_tstride);
     else if (H <= 512)
         hipLaunchKernelGGL(ln_tile_kernel<128>, dim3(ceil_div(L, 64), B), dim3(256), 0, s, x, m_p, s_p, part_t,
-                           pt_bstride, out, H, L, ostride);
+                           pt_bstride, out, H, L, ostride, step_idx, pt_tstride);
     else
         hipLaunchKernelGGL(ln_kernel, dim3(ceil_div(L, 64), B), dim3(64), 0, s, x, m_p, s_p, part_t, pt_bstride, out,
-                           H, L, ostride);
+                           H, L, ostride, step_idx, pt_tstride);
     return DWS_OK;
 }
 

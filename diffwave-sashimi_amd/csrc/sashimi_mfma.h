@@ -27,6 +27,8 @@ struct S4TailArgs {
     const float* n1_s;
     const float* e_next;  // next block's step-embedding projection: e_next[b * e_stride + h]
     int e_stride;
+    const int* e_step;    // nullable: step-table mode (sampler) -- e_next is row 0 of a [T][e_tstride] table, the kernel
+    int e_tstride;        // adds row *e_step (device-resident step counter; e_stride is 0 then)
     int B, L;
     // H <= 64: the same three weights with their columns in chain order (sashimi_chain.hip), A-fragment packed
     const float* Ao_c;

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
 
         // ---- the next block's S4 input: LN1_next down the columns of the output tile + its step-embedding projection
         __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e_next + (size_t)b * a.e_stride), 0, H * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e_next + (size_t)b * a.e_stride + step_row_off(a.e_step, a.e_tstride)), 0, H * 4, 0x00020000);
         float ev[NPASS];
 #pragma unroll
         for (int i = 0; i < NPASS; ++i)
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         column_stats<H, P, PARTS>(tile, red, colmean, colalpha, a.n1_s[0], tid);
         {
             __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
-            __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e_next + (size_t)b * a.e_stride), 0, H * 4, 0x00020000);
+            __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e_next + (size_t)b * a.e_stride + step_row_off(a.e_step, a.e_tstride)), 0, H * 4, 0x00020000);
             const float n1m = a.n1_m[0];
     #pragma unroll
             for (int m = 0; m < MT; ++m) {

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "conditioner.h"
 #include "fftconv.h"
@@ -41,26 +42,31 @@ struct RocfftPlan {
     DevBuf work;
 };
 
+// rocfft_setup() / rocfft_cleanup() act on process-global state (plan repository, RTC cache, logging): set up once per
+// process; never torn down from a model's destructor -- another model in the process may still hold plans.
+static int rocfft_setup_once() {
+    static std::once_flag once;
+    static rocfft_status st = rocfft_status_success;
+    std::call_once(once, [] { st = rocfft_setup(); });
+    if (st != rocfft_status_success) return set_error(DWS_ERR_HIP, "rocfft_setup failed: rocfft_status %d", (int)st);
+    return DWS_OK;
+}
+
 struct FftPlans {
     std::map<std::tuple<int, int, int>, RocfftPlan*> plans;  // (type, n, batch)
-    bool setup_done = false;
     ~FftPlans() {
         for (auto& kv : plans) {
             if (kv.second->info) rocfft_execution_info_destroy(kv.second->info);
             if (kv.second->plan) rocfft_plan_destroy(kv.second->plan);
             delete kv.second;
         }
-        if (setup_done) rocfft_cleanup();
     }
     // type 0: R2C rows of n reals (dist n) -> n/2+1 complex; type 1: C2R n/2+1 complex -> n reals (dist n)
     int get(int type, int n, int batch, RocfftPlan** out) {
         auto key = std::make_tuple(type, n, batch);
         auto it = plans.find(key);
         if (it == plans.end()) {
-            if (!setup_done) {
-                DWS_FFT(rocfft_setup());
-                setup_done = true;
-            }
+            DWS_TRY(rocfft_setup_once());
             RocfftPlan* p = new RocfftPlan();
             it = plans.emplace(key, p).first;      // owned by the map from here on (freed with it, also after an error)
             const size_t len[1] = {(size_t)n};
@@ -133,6 +139,9 @@ struct Stage {
     int H, L, L0 = 0;
     bool rocfft = false;  // some block of this stage needs the rocFFT path
     bool seg = false;     // stage runs the segmented fused convolution (L > 16384)
+    bool force_rocfft = false;   // resolve_segmented_stages(): a checkpoint's kernels carry more taps than one segment holds, so
+                                 // this stage runs on rocFFT whatever prepare() would pick from the configured length; holds
+                                 // until the run length changes (the decision depends on L and the `L` buffers only, not on B)
     DevBuf U, Uf, Y, g, x1, n2, ffu, y;
     DevBuf d2, dh, dx1, du;  // training path gradients: [B][max(2,FF) H][L], [B][H][L] x 3
 };
@@ -339,16 +348,25 @@ struct SashimiModel : dws_model {
     // prepare() picks the segmented convolution from the CONFIGURED stage length; a checkpoint whose kernels were set
     // up for a longer l_max (its `L` buffers) can carry more taps than one segment holds: such a stage runs on rocFFT
     int resolve_segmented_stages(hipStream_t s) {
-        for (auto* l : all) {
-            if (l->kind != L_BLOCK) continue;
-            Stage* st = stages[l->stage];
-            if (!st->seg) continue;
-            int64_t Lk = 0;
-            DWS_TRY(kernel_len(l, s, &Lk));
-            if (Lk > 0 && !fftconv_seg_supported(st->L, (int)std::min<int64_t>(st->L, Lk))) {
+        for (auto* st : stages) {
+            if (!st->seg && !st->force_rocfft) continue;
+            bool fits = true;
+            for (auto* l : all) {
+                if (l->kind != L_BLOCK || stages[l->stage] != st) continue;
+                int64_t Lk = 0;
+                DWS_TRY(kernel_len(l, s, &Lk));
+                if (Lk > 0 && !fftconv_seg_supported(st->L, (int)std::min<int64_t>(st->L, Lk))) fits = false;
+            }
+            if (!fits && st->seg) {
                 st->seg = false;
+                st->force_rocfft = true;      // prepare() keeps this stage on rocFFT (also for another B) until L changes
                 drop_graph();
                 DWS_TRY(ensure_rocfft_stage(st));
+            } else if (fits && st->force_rocfft) {   // the `L` buffers were re-sent with shorter kernels: back to the segmented path
+                st->force_rocfft = false;
+                st->seg = true;
+                drop_graph();
+                DWS_TRY(st->y.ensure((size_t)B * st->H * st->L * 4));
             }
         }
         return DWS_OK;
@@ -543,7 +561,10 @@ struct SashimiModel : dws_model {
                 l->L = (int)((int64_t)l->L0 * nL / d.L);
                 l->Lout = (int)((int64_t)l->Lout0 * nL / d.L);
             }
-            for (auto* st : stages) { st->L = (int)((int64_t)st->L0 * nL / d.L); st->rocfft = false; st->seg = false; }
+            for (auto* st : stages) {
+                st->L = (int)((int64_t)st->L0 * nL / d.L);
+                st->rocfft = false; st->seg = false; st->force_rocfft = false;
+            }
             dirty = true;   // K_f depends on the run length (two-sided assembly, transform size)
         }
         B = nB; L = nL;
@@ -553,7 +574,8 @@ struct SashimiModel : dws_model {
             const bool no_fused = !fftconv_supported((int)Ls, &lg) || getenv("DWS_SASHIMI_ROCFFT");
             // beyond the largest LDS transform: segmented fused path when the kernels (at most the configured stage
             // length of taps per direction, s4.py:1387) fit one segment
-            st->seg = no_fused && !getenv("DWS_SASHIMI_ROCFFT") && fftconv_seg_supported((int)Ls, std::min((int)Ls, st->L0));
+            st->seg = no_fused && !st->force_rocfft && !getenv("DWS_SASHIMI_ROCFFT") &&
+                      fftconv_seg_supported((int)Ls, std::min((int)Ls, st->L0));
             const bool need_rocfft = no_fused && !st->seg;
             if (need_rocfft) {
                 B = nB;
@@ -628,8 +650,8 @@ struct SashimiModel : dws_model {
         const std::string& p = l->prefix;
         if (l->log2m > 0) {
             if (!y_ready)
-                DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->y.f(), nB,
-                                  H, Ls, (size_t)Ls, s));
+                DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), pt_base() + l->pt_off, pt_bstride(), st->y.f(), nB,
+                                  H, Ls, (size_t)Ls, s, step_idx, pt_total));
             FftTables* t = tables[l->log2m];
             FftConvArgs fa{};
             fa.u = st->y.f(); fa.g = st->g.f(); fa.D = P(p + ".layer.D");
@@ -641,8 +663,8 @@ struct SashimiModel : dws_model {
         }
         if (l->seg) {
             if (!y_ready)
-                DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->y.f(), nB,
-                                  H, Ls, (size_t)Ls, s));
+                DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), pt_base() + l->pt_off, pt_bstride(), st->y.f(), nB,
+                                  H, Ls, (size_t)Ls, s, step_idx, pt_total));
             FftTables* t = tables[FFTCONV_SEG_LOG2M];
             FftConvSegArgs fa{};
             fa.u = st->y.f(); fa.g = st->g.f(); fa.D = P(p + ".layer.D");
@@ -654,8 +676,8 @@ struct SashimiModel : dws_model {
             DWS_TRY(launch_fftconv_seg(fa, s));
             return run_tail(l, st, x, addend, next, s);
         }
-        DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, st->U.f(), nB, H, Ls,
-                          (size_t)2 * Ls, s));
+        DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), pt_base() + l->pt_off, pt_bstride(), st->U.f(), nB, H, Ls,
+                          (size_t)2 * Ls, s, step_idx, pt_total));
         {
             ProfileScope ps("rocfft_r2c", s);
             DWS_TRY(fft.exec(0, 2 * Ls, nB * H, st->U.p, st->Uf.p, s));
@@ -685,7 +707,8 @@ struct SashimiModel : dws_model {
             if (next) {     // feeds_next(l, next) holds: the stage's y buffer is free once this block's convolution ran
                 t.ynext = st->y.f();
                 t.n1_m = P(next->prefix + ".norm1.m"); t.n1_s = P(next->prefix + ".norm1.s");
-                t.e_next = part_t.f() + next->pt_off; t.e_stride = pt_total;
+                t.e_next = pt_base() + next->pt_off; t.e_stride = pt_bstride();
+                t.e_step = step_idx; t.e_tstride = pt_total;
             }
             return launch_s4_tail_mfma(H, t, s);
         }
@@ -737,16 +760,50 @@ struct SashimiModel : dws_model {
 
     const float* last_x = nullptr;
 
+    // everything of the forward that depends on the diffusion step only (`sashimi.py:287-289,151`; a1, a2 of SURVEY 8):
+    // embedding -> MLP -> every block's fc_t as one stacked GEMV, for `rows` step values (one wave per output row: a row's
+    // result does not depend on how many rows the launch carries)
+    int embed_rows(const float* steps, int rows, float* emb_, float* h1_, float* h2_, float* pt, hipStream_t s) {
+        DWS_TRY(launch_step_embed(steps, freq.f(), emb_, rows, Ein / 2, s));
+        DWS_TRY(launch_linear_rows(emb_, P("fc_t1.weight"), P("fc_t1.bias"), h1_, rows, Ein, Emid, 1, s));
+        DWS_TRY(launch_linear_rows(h1_, P("fc_t2.weight"), P("fc_t2.bias"), h2_, rows, Emid, Eout, 1, s));
+        DWS_TRY(launch_linear_rows(h2_, Wt_all.f(), bt_all.f(), pt, rows, Eout, pt_total, 0, s));
+        return DWS_OK;
+    }
+
+    // Step table of a sampler run (sampler.hip): every clip of a reverse step is at the same t (`generate.py:50`), so the
+    // projections are evaluated once for t = 0..T-1 -- tab_pt [T][pt_total] -- and the captured step's LayerNorm / tail
+    // kernels read row *step_idx: no embedding kernels in a replay.
+    DevBuf tab_steps, tab_emb, tab_h1, tab_h2, tab_pt;
+    int tab_T = 0;
+    uint64_t tab_version = ~0ull;
+    const float* pt_base() const { return step_idx ? tab_pt.f() : part_t.f(); }
+    int pt_bstride() const { return step_idx ? 0 : pt_total; }
+    int build_step_table(int T, hipStream_t s) override {
+        if (dirty) DWS_TRY(commit(s));
+        if (tab_T == T && tab_version == commit_version) return DWS_OK;
+        drop_graph();   // a captured step holds pointers into the old table
+        DWS_TRY(tab_steps.ensure((size_t)T * 4));
+        DWS_TRY(tab_emb.ensure((size_t)T * Ein * 4));
+        DWS_TRY(tab_h1.ensure((size_t)T * Emid * 4));
+        DWS_TRY(tab_h2.ensure((size_t)T * Eout * 4));
+        DWS_TRY(tab_pt.ensure((size_t)T * pt_total * 4));
+        DWS_TRY(launch_iota_f32(tab_steps.f(), T, s));   // steps[t] = float(t), as `generate.py:50` feeds them
+        DWS_TRY(embed_rows(tab_steps.f(), T, tab_emb.f(), tab_h1.f(), tab_h2.f(), tab_pt.f(), s));
+        tab_T = T;
+        tab_version = commit_version;
+        return DWS_OK;
+    }
+
     // Sashimi.forward (sashimi.py:277-313)
     int forward(const float* audio, const float* steps, float* out, hipStream_t s) override {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
         trained_fwd = false;   // this forward (eval call, or a step of the sampler) overwrites the activations a pending backward needs
         if (dirty) DWS_TRY(commit(s));
         DWS_TRY(launch_init_conv(audio, Wi.f(), P("init_conv.0.conv.bias"), x_init.f(), (int)B, Cin, D, (int)L, s));
-        DWS_TRY(launch_step_embed(steps, freq.f(), emb.f(), (int)B, Ein / 2, s));
-        DWS_TRY(launch_linear_rows(emb.f(), P("fc_t1.weight"), P("fc_t1.bias"), h1.f(), (int)B, Ein, Emid, 1, s));
-        DWS_TRY(launch_linear_rows(h1.f(), P("fc_t2.weight"), P("fc_t2.bias"), h2.f(), (int)B, Emid, Eout, 1, s));
-        DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), (int)B, Eout, pt_total, 0, s));
+        DWS_CHECK(!step_idx || (tab_T > 0 && tab_version == commit_version), DWS_ERR_STATE, "step-table forward without a current table");
+        DWS_CHECK(step_idx || steps, DWS_ERR_INVALID, "forward: steps == null");
+        if (!step_idx) DWS_TRY(embed_rows(steps, (int)B, emb.f(), h1.f(), h2.f(), part_t.f(), s));
         std::vector<const float*> stack;  // LIFO skip stack (sashimi.py:293-307)
         const float* x = x_init.f();
         // execution order; a block whose successor is a fused block of the same stage also writes that block's S4 input

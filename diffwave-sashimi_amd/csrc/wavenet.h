@@ -16,6 +16,11 @@ struct WnLayerArgs {
     const float* A1;       // packed dilated-conv weights (MFMA path)
     const float* A2;       // packed [res; skip] weights   (MFMA path)
     const float* Abt;      // MFMA path: step-embedding correction fragments of this layer [B][2C/32][64][4]
+    int abt_bstride;       // floats between two clips' Abt rows (0 in step-table mode: every clip shares the row of step t)
+    // step-table mode (the sampler: every clip is at the same step t, `generate.py:50`): Abt / part_t point at row 0 of this
+    // layer's [T][...] table built once per sampler run; the kernels add *step_idx * tstride (a scalar load)
+    const int* step_idx;   // nullable: device-resident step counter
+    int abt_tstride, part_t_tstride;
     const float* Wd;       // folded [2C][C][3]            (generic path)
     const float* Wr;       // folded [C][C]
     const float* Ws;       // folded [S][C]
@@ -47,6 +52,7 @@ int launch_permute_dconv(const float* w, float* out, int C, int KC, hipStream_t 
 int launch_pack_a_frag(const float* w, float* out, int M, int K, hipStream_t s);
 int launch_pack_a_frag_t(const float* w, float* out, int O, int K, hipStream_t s);   // fragments of W^T from row-major W[O][K]
 int launch_step_embed(const float* steps, const float* freq, float* emb, int B, int half, hipStream_t s);
+int launch_iota_f32(float* out, int n, hipStream_t s);
 int launch_linear_rows(const float* in, const float* W, const float* bias, float* out, int B, int K, int O,
                        int act, hipStream_t s, float* pre_out = nullptr);
 int launch_init_conv(const float* audio, const float* W, const float* bias, float* x, int B, int Cin, int C, int L,

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * WV) void wn_layer_bf16x3_kernel(WnLayerArgs a)
     // step-embedding correction rows (bf16 hi/lo fragments from wn_bias_tap_bf16_kernel); the
     // indicator operand is exact in bf16, so only (hi + lo) x ind is needed
     {
-        const u32x4* Abt = reinterpret_cast<const u32x4*>(a.Abt) + (size_t)b * (2 * C / 32) * 2 * 64;
+        const u32x4* Abt = reinterpret_cast<const u32x4*>(a.Abt + (size_t)b * a.abt_bstride + step_row_off(a.step_idx, a.abt_tstride));
 #pragma unroll
         for (int m = 0; m < 2 * MP; ++m) {
             ahi[m] = __builtin_bit_cast(bf16x8, Abt[(mt1[m] * 2 + 0) * 64 + lane]);

@@ -117,6 +117,16 @@ __global__ void step_embed_kernel(const float* __restrict__ steps, const float* 
     }
 }
 
+__global__ void iota_f32_kernel(float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)i;
+}
+// out[i] = float(i): the step values t = 0..T-1 of a sampler's step table, as `generate.py:50` feeds them to the network
+int launch_iota_f32(float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(iota_f32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, out, n);
+    return DWS_OK;
+}
+
 int launch_step_embed(const float* steps, const float* freq, float* emb, int B, int half, hipStream_t s) {
     hipLaunchKernelGGL(step_embed_kernel, dim3(B), dim3(64), 0, s, steps, freq, emb, half);
     return DWS_OK;
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_mfma_kernel(WnLayerArgs a) {
     }
     // extra k-group: step-embedding correction rows
     {
-        const f32x4* Abt = reinterpret_cast<const f32x4*>(a.Abt) + (size_t)b * (2 * C / 32) * 64;
+        const f32x4* Abt = reinterpret_cast<const f32x4*>(a.Abt + (size_t)b * a.abt_bstride + step_row_off(a.step_idx, a.abt_tstride));
         f32x4 ab[2 * MP];
 #pragma unroll
         for (int m = 0; m < 2 * MP; ++m) ab[m] = Abt[mt1[m] * 64 + lane];
@@ -591,7 +601,7 @@ __global__ void wn_gate_generic_kernel(WnLayerArgs a, int C) {
     const int b = blockIdx.z, c = blockIdx.y;
     const int L = a.L, d = a.dilation;
     const float* xb = a.x_in + (size_t)b * C * L;
-    const float* pt = a.part_t + (size_t)b * a.part_t_bstride;
+    const float* pt = a.part_t + (size_t)b * a.part_t_bstride + step_row_off(a.step_idx, a.part_t_tstride);
     const float* wt = a.Wd + (size_t)c * C * 3;        // folded [2C][C][3]
     const float* ws = a.Wd + (size_t)(C + c) * C * 3;
     const float* melb = a.melc ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;

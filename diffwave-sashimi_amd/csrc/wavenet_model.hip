@@ -15,7 +15,13 @@ struct WaveNetModel : dws_model {
     bool cond, mfma_layer, mfma_final;
     bool bf16x3 = false;             // precision option (see include/dws.h)
     bool wino_opt = true;            // conv_algo option: Winograd F(2,3) along the dilation stride (f32 path) or direct
-    bool wino() const { return wino_opt && mfma_layer && !bf16x3 && wn_layer_wino_supported(C, S); }
+    // the Winograd launcher addresses a clip's [C][L] tensor through one 32-bit buffer descriptor: over-long clips
+    // (L >= ~2.1 M samples at C = 256) stay on the direct kernel, which has no such bound.  prepare() marks the model
+    // dirty when the answer flips (the A1 / Abt layouts follow the choice).
+    bool wino_fits(int64_t nL) const {
+        return (int64_t)std::max(C, S) * nL * 4 < ((int64_t)1 << 31) && nL + 4 * ((int64_t)1 << (cycle - 1)) < ((int64_t)1 << 28);
+    }
+    bool wino() const { return wino_opt && mfma_layer && !bf16x3 && wn_layer_wino_supported(C, S) && (L == 0 || wino_fits(L)); }
 
     // folded / packed weights
     DevBuf Wi;                       // init conv [C][Cin]
@@ -103,17 +109,18 @@ struct WaveNetModel : dws_model {
 
     int set_option(const std::string& key, const std::string& value) override {
         if (key == "precision") {
-            if (value == "f32") { bf16x3 = false; dirty = true; return DWS_OK; }
+            if (value == "f32") { bf16x3 = false; dirty = true; trained_fwd = false; return DWS_OK; }
             if (value == "bf16x3") {
                 DWS_CHECK(wn_layer_bf16x3_supported(C, S), DWS_ERR_UNSUPPORTED,
                           "precision=bf16x3 is not built for (res_channels=%d, skip_channels=%d)", C, S);
-                bf16x3 = true; dirty = true;
+                bf16x3 = true; dirty = true; trained_fwd = false;
                 return DWS_OK;
             }
         }
         if (key == "conv_algo") {
-            if (value == "winograd") { wino_opt = true; dirty = true; return DWS_OK; }
-            if (value == "direct") { wino_opt = false; dirty = true; return DWS_OK; }
+            // a pending backward was packed (pack_bwd) and saved for the other algorithm: it may not run against this one
+            if (value == "winograd") { wino_opt = true; dirty = true; trained_fwd = false; return DWS_OK; }
+            if (value == "direct") { wino_opt = false; dirty = true; trained_fwd = false; return DWS_OK; }
         }
         return dws_model::set_option(key, value);
     }
@@ -254,6 +261,7 @@ struct WaveNetModel : dws_model {
         DWS_CHECK(nB > 0 && nL > 0, DWS_ERR_INVALID, "prepare: B=%lld L=%lld", (long long)nB, (long long)nL);
         DWS_CHECK(nB * nL * (int64_t)std::max(2 * C, S) < (int64_t)1 << 40, DWS_ERR_UNSUPPORTED, "workspace too large");
         if (nB != B || nL != L) { drop_graph(); melBm = 0; trained_fwd = false; }
+        if ((L == 0 || wino_fits(L)) != wino_fits(nL)) dirty = true;   // the layer kernel (and with it the A1 / Abt layout) changes
         B = nB; L = nL;
         const size_t act = (size_t)B * C * L * 4;
         DWS_TRY(x0.ensure(act));
@@ -336,20 +344,65 @@ struct WaveNetModel : dws_model {
 
     const float* train_audio = nullptr;
 
+    // floats of one (layer, clip) row of the step-embedding correction fragments, by layer kernel
+    int abt_row() const { return wino() ? 4 * 2 * C : (2 * C / 32) * (bf16x3 ? 512 : 256); }
+
+    // everything of the forward that depends on the diffusion step only (`wavenet.py:153-155,89`; a1, a2 of SURVEY 8):
+    // embedding -> MLP -> every layer's fc_t (one stacked GEMV) -> the layer kernels' correction fragments, for `rows`
+    // step values.  Row results do not depend on how many rows a launch carries (one wave per output row).
+    int embed_rows(const float* steps, int rows, float* emb_, float* h1_, float* h2_, float* pt, void* abt, float* pre1,
+                   float* pre2, hipStream_t s) {
+        DWS_TRY(launch_step_embed(steps, freq.f(), emb_, rows, Ein / 2, s));
+        DWS_TRY(launch_linear_rows(emb_, P("residual_layer.fc_t1.weight"), P("residual_layer.fc_t1.bias"), h1_, rows, Ein, Emid,
+                                   1, s, pre1));
+        DWS_TRY(launch_linear_rows(h1_, P("residual_layer.fc_t2.weight"), P("residual_layer.fc_t2.bias"), h2_, rows, Emid, Eout,
+                                   1, s, pre2));
+        DWS_TRY(launch_linear_rows(h2_, Wt_all.f(), bt_all.f(), pt, rows, Eout, NL * C, 0, s));
+        if (mfma_layer && bf16x3) DWS_TRY(launch_wn_bias_tap_bf16(Wd_all.f(), pt, b1_all.f(), abt, NL, rows, C, s));
+        else if (wino()) DWS_TRY(launch_wn_wino_bias(Wd_all.f(), pt, (float*)abt, NL, rows, C, s));
+        else if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), pt, (float*)abt, NL, rows, C, s));
+        return DWS_OK;
+    }
+
+    // Step table of a sampler run (sampler.hip): in sampling every clip is at the same step (`generate.py:50`), so the
+    // step-only part of the forward is evaluated ONCE for t = 0..T-1 -- tab_pt [T][NL*C], tab_abt [NL][T][abt_row] -- and
+    // the captured reverse step reads row *step_idx: no embedding kernels in a replay.
+    DevBuf tab_steps, tab_emb, tab_h1, tab_h2, tab_pt, tab_abt;
+    int tab_T = 0;
+    uint64_t tab_version = ~0ull;
+    int build_step_table(int T, hipStream_t s) override {
+        if (dirty) DWS_TRY(commit(s));
+        if (tab_T == T && tab_version == commit_version) return DWS_OK;
+        drop_graph();   // a captured step holds pointers into the old table
+        DWS_TRY(tab_steps.ensure((size_t)T * 4));
+        DWS_TRY(tab_emb.ensure((size_t)T * Ein * 4));
+        DWS_TRY(tab_h1.ensure((size_t)T * Emid * 4));
+        DWS_TRY(tab_h2.ensure((size_t)T * Eout * 4));
+        DWS_TRY(tab_pt.ensure((size_t)T * NL * C * 4));
+        if (mfma_layer) {
+            const size_t n = (size_t)NL * T * abt_row() * 4;
+            DWS_TRY(tab_abt.ensure(n));
+            DWS_HIP(hipMemsetAsync(tab_abt.p, 0, n, s));   // unused k entries of the correction k-group stay zero
+        }
+        DWS_TRY(launch_iota_f32(tab_steps.f(), T, s));   // steps[t] = float(t), as `generate.py:50` feeds them
+        DWS_TRY(embed_rows(tab_steps.f(), T, tab_emb.f(), tab_h1.f(), tab_h2.f(), tab_pt.f(), tab_abt.p, nullptr, nullptr, s));
+        tab_T = T;
+        tab_version = commit_version;
+        return DWS_OK;
+    }
+
     int run_forward(const float* audio, const float* steps, float* out, bool train, hipStream_t s) {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
         if (dirty) DWS_TRY(commit(s));
+        const bool tab = step_idx != nullptr && !train;
+        DWS_CHECK(!tab || (tab_T > 0 && tab_version == commit_version), DWS_ERR_STATE, "step-table forward without a current table");
+        DWS_CHECK(tab || steps, DWS_ERR_INVALID, "forward: steps == null");
         float* xfirst = train ? tx[0].f() : x0.f();
         DWS_TRY(launch_init_conv(audio, Wi.f(), P("init_conv.0.conv.bias"), xfirst, (int)B, Cin, C, (int)L, s));
-        DWS_TRY(launch_step_embed(steps, freq.f(), emb.f(), (int)B, Ein / 2, s));
-        DWS_TRY(launch_linear_rows(emb.f(), P("residual_layer.fc_t1.weight"), P("residual_layer.fc_t1.bias"), h1.f(),
-                                   (int)B, Ein, Emid, 1, s, train ? ta1.f() : nullptr));
-        DWS_TRY(launch_linear_rows(h1.f(), P("residual_layer.fc_t2.weight"), P("residual_layer.fc_t2.bias"), h2.f(),
-                                   (int)B, Emid, Eout, 1, s, train ? ta2.f() : nullptr));
-        DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), (int)B, Eout, NL * C, 0, s));
-        if (mfma_layer && bf16x3) DWS_TRY(launch_wn_bias_tap_bf16(Wd_all.f(), part_t.f(), b1_all.f(), Abt.p, NL, (int)B, C, s));
-        else if (wino()) DWS_TRY(launch_wn_wino_bias(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
-        else if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), part_t.f(), Abt.f(), NL, (int)B, C, s));
+        if (!tab)
+            DWS_TRY(embed_rows(steps, (int)B, emb.f(), h1.f(), h2.f(), part_t.f(), Abt.p, train ? ta1.f() : nullptr,
+                               train ? ta2.f() : nullptr, s));
+        const int arow = abt_row();
         for (int n = 0; n < NL; ++n) {
             const std::string p = "residual_layer.residual_blocks." + std::to_string(n);
             WnLayerArgs a{};
@@ -357,11 +410,15 @@ struct WaveNetModel : dws_model {
             a.x_out = train ? tx[n + 1].f() : ((n & 1) ? x0.f() : x1.f());
             a.hsave = train ? tH[n].f() : nullptr;
             a.skip = skip.f();
-            a.part_t = part_t.f() + (size_t)n * C;
-            a.part_t_bstride = NL * C;
             a.A1 = A1[n].f(); a.A2 = A2[n].f();
-            a.Abt = !mfma_layer ? nullptr : wino() ? Abt.f() + (size_t)n * B * 4 * 2 * C
-                                                   : Abt.f() + (size_t)n * B * (2 * C / 32) * (bf16x3 ? 512 : 256);
+            if (tab) {
+                a.part_t = tab_pt.f() + (size_t)n * C; a.part_t_bstride = 0; a.part_t_tstride = NL * C;
+                a.Abt = mfma_layer ? tab_abt.f() + (size_t)n * tab_T * arow : nullptr; a.abt_bstride = 0; a.abt_tstride = arow;
+                a.step_idx = step_idx;
+            } else {
+                a.part_t = part_t.f() + (size_t)n * C; a.part_t_bstride = NL * C;
+                a.Abt = mfma_layer ? Abt.f() + (size_t)n * B * arow : nullptr; a.abt_bstride = arow;
+            }
             a.Wd = Wd(n); a.Wr = Wrs[n].f(); a.Ws = Wrs[n].f() + (size_t)C * C;
             a.bias1 = P(p + ".dilated_conv_layer.conv.bias");
             a.bias2 = bias2[n].f();
@@ -481,6 +538,7 @@ struct WaveNetModel : dws_model {
                     q.A = ATw[n].f(); q.nkg_total = C;
                     DWS_TRY(launch_tapwino_mfma(q, s));
                 } else {
+                    DWS_CHECK(ATd[n].p, DWS_ERR_STATE, "backward: layer %d's direct adjoint weights were not packed", n);
                     DWS_TRY(launch_tapconv_mfma(q, s));
                 }
             } else {

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     for (int m = 0; m < MS; ++m) mt2[1 + m] = C / 32 + wave * MS + m;
     float av1[2][4], av2[1 + MS];
     {
-        const float* Abt = a.Abt + (size_t)b * 4 * 2 * C;
+        const float* Abt = a.Abt + (size_t)b * a.abt_bstride + step_row_off(a.step_idx, a.abt_tstride);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int row = mt1[m] * 32 + l31;
@@ -218,8 +218,11 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     //    block of 64 positions -- so ONE contiguous row piece [base - 32, base + 96) is staged per channel (16-byte LDS-DMA,
     //    two rows per instruction, 512 contiguous bytes per row) and the transform picks its four inputs out of it
     //    (per-dilation times before: d = 1, 2 on the dword path 1.71 ms, d = 4, 8 1.66 ms, d >= 16 1.60 ms).
-    const bool contig = (L % 4 == 0) && log2d <= 4;
-    const bool x4 = contig || ((L % 4 == 0) && log2d >= 2);
+    // 16-byte DMA also needs the clip's base 16-byte aligned (true for every engine buffer when L % 4 == 0; checked so that
+    // an offset pointer handed in through the C ABI falls back to the dword form instead of misaligned b128 accesses)
+    const bool al16 = (L % 4 == 0) && (((size_t)a.x_in & 15) == 0);
+    const bool contig = al16 && log2d <= 4;
+    const bool x4 = contig || (al16 && log2d >= 2);
     constexpr int RPW = KC / WAVES;                // channel rows per wave and chunk (as pairs of adjacent rows)
     __amdgpu_buffer_rsrc_t rXall = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
     // element offsets of this lane's column inside a staged row: shift s (0..3 = -d, 0, +d, +2d) sits at ob + s * os

@@ -96,7 +96,10 @@ MAX_TOL = 3.5e-2        # the adaptive bound never opens wider than this, whatev
                         # fp32 gradient of c_layers.0.norm2.m sits 1.1e-2 from its float64 evaluation: 3x that)
 # the cancelling sums: LayerNorm shifts / scales, 1-input-channel weight_v, and the per-channel step size log_dt (a sum over all
 # frequencies and state indices of the kernel generator; the oracle's own fp32 autograd sits up to 8e-4 from float64 there)
-WIDEN_FAMILIES = ("norm1.m", "norm2.m", "norm.m", "norm1.s", "norm2.s", "norm.s", "weight_v", "kernel.log_dt")
+# `weight_v` only where the conv has ONE input channel (`init_conv.0.conv`, the conditioner's `upsample_conv2d.*`): a bare
+# "weight_v" suffix would match every weight-normed conv of both models
+WIDEN_FAMILIES = ("norm1.m", "norm2.m", "norm.m", "norm1.s", "norm2.s", "norm.s", "init_conv.0.conv.weight_v",
+                  "upsample_conv2d.0.weight_v", "upsample_conv2d.1.weight_v", "kernel.log_dt")
 
 
 def compare(got, ref, truth64, fp32_impls=(), label="", kink=None, max_widened=3, families=WIDEN_FAMILIES):

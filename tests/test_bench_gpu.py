@@ -42,6 +42,10 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline(gpu):
     assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert abs(d["value"] - 16 * 16000 / (200 * d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # the metric as generate.py defines it: one complete T-step loop (x_T draw + T replays), wall-clocked
+    fl = d["full_loop"]
+    assert fl["T"] == 200 and fl["finite"] and abs(fl["ms_per_step"] - fl["ms"] / 200) < 1e-9
+    assert 0.9 < fl["ratio_to_timed_ms_per_step"] < 1.15, fl
 
 
 def test_two_ranks_aggregate(gpu):
@@ -72,13 +76,20 @@ def test_default_headline_line_carries_the_other_baseline_configs(gpu):
     assert abs(rf["achieved"] - rf["executed_flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * rf["achieved"]
     assert rf["effective_TFLOPs_on_direct_conv_flops"] > rf["achieved"]
     ex = d["extra_configs"]
-    assert set(ex) == {"unet_d64_n6_T200", "unet_d32_n6_T50_cond", "unet_d128_n6_T200 --mode train"}
+    ops = {"unet_d128_n6_T200 B=128 (README operating point)", "unet_d64_n6_T200 B=256 (README operating point)"}
+    assert set(ex) == {"unet_d64_n6_T200", "unet_d32_n6_T50_cond", "unet_d128_n6_T200 --mode train"} | ops
     for name, leg in ex.items():
-        assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["dtype"] == "f32", name
-        assert leg["roofline"]["bound"] == "mfma" and 0 < leg["roofline"]["frac"] < 1, name
+        assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["dtype"] == "f32", (name, leg)
+        if name not in ops:
+            assert leg["roofline"]["bound"] == "mfma" and 0 < leg["roofline"]["frac"] < 1, name
+    for name in ops:     # the reference's documented batch sizes: 8x / 16x the tested batch through the same 32-bit offsets
+        assert ex[name]["hbm_bytes_in_use"] > 2 ** 30 and ex[name]["config"]["batch_per_gpu"] in (128, 256)
+    assert d["full_loop"]["T"] == 200 and d["full_loop"]["finite"]
     for name in ("unet_d64_n6_T200", "unet_d32_n6_T50_cond"):
         fc = ex[name]["roofline"]["fftconv"]
         assert fc["bound"] == "hbm" and 0 < fc["frac"] < 1
+        fl = ex[name]["full_loop"]
+        assert fl["finite"] and 0.9 < fl["ratio_to_timed_ms_per_step"] < 1.2, (name, fl)
     c3 = ex["unet_d64_n6_T200"]
     assert abs(c3["value"] - 16 * 16000 / (200 * c3["ms_per_step"] * 1e-3)) < 1e-6 * c3["value"]
     tr = ex["unet_d128_n6_T200 --mode train"]

@@ -63,3 +63,45 @@ def test_philox_noise_is_standard_normal(gpu):
     assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01
     assert abs(float((x ** 4).mean()) - 3.0) < 0.1          # kurtosis
     assert abs(float((x[:, :, 1:] * x[:, :, :-1]).mean())) < 0.01  # lag-1 correlation
+
+
+@pytest.mark.parametrize("backbone", ["wavenet", "sashimi"])
+def test_step_table_sampler_equals_the_per_step_loop(gpu, backbone):
+    """The sampler evaluates the step-only part of the network (embedding, MLP, every layer's fc_t, the layer kernels'
+    correction fragments) once for t = 0..T-1 and lets the captured step read row t (device step counter); the plain
+    forward evaluates it per clip from the steps it is handed.  Same kernels, one output row per wave either way: the
+    sampler's trajectory must equal -- bit for bit -- the loop `generate.py:49-54` written out with module calls."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    if backbone == "wavenet":
+        cfg, B, L, wseed, _, _ = cases.WAVENET_CASES["wn_c64"]
+    else:
+        cfg, B, L, wseed = cases.ss_cfg(d_model=32, n_layers=2, L=1024, diffusion_step_embed_dim_mid=64), 3, 1024, 5
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    T = 5
+    dh = calc_diffusion_hyperparams(T, 1e-4, 0.05)
+    g = torch.Generator().manual_seed(77)
+    x_T, noise = torch.randn(B, 1, L, generator=g), torch.randn(T, B, 1, L, generator=g)
+    got = sampling(net, (B, 1, L), dh, x_T=x_T, noise=noise, use_graph=True)
+    al, ab, sg = (dh[k] for k in ("Alpha", "Alpha_bar", "Sigma"))
+
+    def loop():
+        x = x_T.to(gpu)
+        with torch.no_grad():
+            for t in range(T - 1, -1, -1):
+                eps = net((x, torch.full((B, 1), float(t), device=gpu)))
+                # fp32 scalars evaluated on the host in the reference's order (`generate.py:52`), as the engine's tables are
+                c1, c2 = float((1 - al[t]) / torch.sqrt(1 - ab[t])), float(torch.sqrt(al[t]))
+                x = (x - c1 * eps) / c2
+                if t > 0:
+                    x = x + float(sg[t]) * noise[t].to(gpu)
+        return x
+
+    x = loop()
+    assert torch.equal(got, x), float((got - x).abs().max())
+    # the table follows the weights: new weights, same T -> rebuilt (a stale table would reproduce the old trajectory)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            if p_.is_floating_point():
+                p_.mul_(1.01)
+    got2 = sampling(net, (B, 1, L), dh, x_T=x_T, noise=noise, use_graph=True)
+    assert torch.equal(got2, loop()) and not torch.equal(got2, got)

@@ -277,6 +277,15 @@ def test_checkpoint_with_longer_kernels_than_configured_runs_long_inputs(gpu):
     with torch.no_grad():
         ref = osa.sashimi_forward({k_: v.cpu() for k_, v in net.state_dict().items()}, short_cfg, audio, steps)
     assert rel_err(out.cpu(), ref) < REL_TOL
+    # same length, LARGER batch: the stage must stay on rocFFT with buffers and plans for the new batch (prepare() used
+    # to re-pick the segmented path from the configured length; the layers then ran rocFFT on buffers sized for B = 1)
+    audio3 = torch.cat([audio, torch.randn(2, 1, 65536, generator=gen)])
+    steps3 = torch.tensor([[11.0], [3.0], [40.0]])
+    out3 = _run(net, gpu, audio3, steps3)
+    assert rel_err(out3[:1].cpu(), ref) < REL_TOL
+    with torch.no_grad():
+        ref3 = osa.sashimi_forward({k_: v.cpu() for k_, v in net.state_dict().items()}, short_cfg, audio3[2:], steps3[2:])
+    assert rel_err(out3[2:].cpu(), ref3) < REL_TOL
     # shorter input afterwards: back on the fused paths, still right
     audio2 = torch.randn(1, 1, 16384, generator=gen)
     out2 = _run(net, gpu, audio2, steps)

@@ -1,0 +1,35 @@
+#!/bin/bash
+# GPU box: refresh the counter-derived HBM traffic of the headline kernel (bench.py's `roofline.traffic`).
+#   tools/r04_traffic.sh [tag]      -> gpurun_out/<tag>_wavenet_traffic.json (copy it to profiles/ to have bench.py use it)
+# Separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_MFMA), as MI355X_MICROARCH.md prescribes; the JSON records the
+# kernel name and the MFMA instruction count per launch, and bench.py REFUSES a file whose kernel name or
+# SQ_INSTS_MFMA x 4096 disagrees (> 1 %) with the executed flops it computes for the kernel it is about to time.
+set -u
+TAG=${1:-r04}
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+W=/tmp/traffic_$TAG; rm -rf $W; mkdir -p $W
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra"
+for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_MFMA; do
+  rocprofv3 --pmc $C -d $W/$C -o p -- $CMD > $W/$C.log 2>&1
+done
+python - "$W" "$OUT/${TAG}_wavenet_traffic.json" <<'PY'
+import json, sqlite3, sys
+w, dst = sys.argv[1], sys.argv[2]
+def avg(counter):
+    c = sqlite3.connect("%s/%s/p_results.db" % (w, counter))
+    rows = list(c.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? and "
+                          "kernel_name like '%wn_layer_%' group by kernel_name order by count(*) desc", (counter,)))
+    return rows[0]
+(kn, n, fetch), (_, _, write), (_, _, mfma) = avg("FETCH_SIZE"), avg("WRITE_SIZE"), avg("SQ_INSTS_MFMA")
+short = kn.split("dws::")[-1].split("(")[0].replace(" ", "")
+json.dump({"kernel": short, "dispatches": n,
+           "source": "tools/r04_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_MFMA, separate passes, bench.py --steps 3",
+           "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
+           "gfx950_correction": "FETCH_SIZE reports 1/2 of a wide coalesced read stream on gfx950 (MI355X_MICROARCH.md, HBM "
+                                "section): read bytes = 2 * FETCH_SIZE * 1024",
+           "hbm_bytes_per_launch": int(2 * fetch * 1024 + write * 1024),
+           "sq_insts_mfma_per_launch": mfma, "executed_flops_per_launch_from_counter": mfma * 4096}, open(dst, "w"), indent=2)
+print(open(dst).read())
+PY
+rm -rf $W
