@@ -90,8 +90,9 @@ def test_step_table_sampler_equals_the_per_step_loop(gpu, backbone):
             for t in range(T - 1, -1, -1):
                 eps = net((x, torch.full((B, 1), float(t), device=gpu)))
                 # fp32 scalars evaluated on the host in the reference's order (`generate.py:52`), as the engine's tables are
-                c1, c2 = float((1 - al[t]) / torch.sqrt(1 - ab[t])), float(torch.sqrt(al[t]))
-                x = (x - c1 * eps) / c2
+                c1, c2 = float((1 - al[t]) / torch.sqrt(1 - ab[t])), torch.sqrt(al[t]).to(gpu)
+                x = (x - c1 * eps) / c2      # c2 as a device tensor: a true division (a host scalar divisor is turned
+                                             # into a multiplication by its reciprocal)
                 if t > 0:
                     x = x + float(sg[t]) * noise[t].to(gpu)
         return x
