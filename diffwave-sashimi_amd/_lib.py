@@ -4,7 +4,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdws.so")
+# DWS_LIB: another build of the same library (tools/ab_lib.sh times two builds back to back on one box); the product
+# path is the in-tree libdws.so
+LIB_PATH = os.environ.get("DWS_LIB") or os.path.join(HERE, "libdws.so")
 
 DWS_OK, DWS_ERR_INVALID, DWS_ERR_UNSUPPORTED, DWS_ERR_HIP, DWS_ERR_STATE = 0, -1, -2, -3, -4
 DWS_KIND_WAVENET, DWS_KIND_SASHIMI = 1, 2

@@ -1,19 +1,41 @@
 // In-LDS complex FFT of size M = 2^LOG2M used by the S4 convolution kernels (fftconv_kernels.hip).
 //
-// In-place radix-2 decimation-in-frequency forward whose stages are fused four at a time into radix-16 passes held in
-// registers (a thread owns 16 points; a pass = one LDS round trip), mirrored decimation-in-time inverse.  The forward
-// leaves the spectrum in BIT-REVERSED order, the inverse consumes that order: no reordering pass.  Pass plan for
-// E = LOG2M (even; odd sizes first take one radix-2 pass over the top bit):
+// Both directions are "twiddle first" radix-2 butterflies  x0' = a + w b,  x1' = a - w b = 2 a - x0'  fused four stages at
+// a time into radix-16 passes held in registers (a thread owns 16 points; a pass = one LDS round trip):
+//   forward  natural order in -> BIT-REVERSED order out.  Stage t = 1..LOG2M has span M / 2^t and the twiddle
+//            W_{2^t}^{rev_{t-1}(position >> (LOG2M - t + 1))}: it depends on the bits ABOVE the stage's bit, so the first
+//            stages (where the zero padding of the convolution input is pruned) have unit twiddles;
+//   inverse  bit-reversed in -> natural out, the textbook decimation-in-time order: spans 1, 2, 4 ..., twiddle
+//            conj(W_{2 span}^{position mod span}): it depends on the bits BELOW the stage's bit.
+// The spectrum between them is the DFT in bit-reversed order: no reordering pass.  (Rounds 1-3 ran the forward as
+// decimation-in-frequency, twiddle AFTER the butterfly: (a + b, (a - b) w) costs 8 scalar / 4 packed instructions, the
+// twiddle-first form 3 packed ones.)
+//
+// Arithmetic: complex values live in 64-bit register pairs and every butterfly is THREE v_pk_fma_f32
+//      t  = a + w.x * b            (op_sel broadcasts w.x to both lanes)
+//      x0 = t + w.y * (-b.y, b.x)  (op_sel swaps b's halves, neg_lo negates one)
+//      x1 = 2 a - x0
+// written as inline assembly: hipcc does not fold the half swaps and single-lane negations of complex arithmetic into the
+// op_sel / neg modifiers of packed instructions (it emits v_mov / v_xor for them), and a packed fp32 instruction costs
+// 4.3 cycles against 2.35-3.9 for a scalar one (tools/valu_rate.hip): 12.9 cycles per butterfly instead of ~21.
+// Multiplications by -i / +i (W_4) ride in the same modifiers.
+//
+// Pass plan for E = LOG2M (even; odd sizes first take one radix-2 pass over the top bit):
 //      index bits [E-4, E), [E-8, E-4), ... as radix-16 passes, and a final radix-4 pass over bits [0, 2) if E % 4 == 2
 //      (E = 14: 4+4+4+2, E = 12: 4+4+4, E = 10: 4+4+2).
-// A radix-16 pass over bits [b, b+4) (s = 2^b, a thread's points are base + r*s) is two radix-4 sub-steps; with
-// theta = W_{16 s}^j, j = index mod s:  sub-step 1 butterflies (r0, r0+4, r0+8, r0+12) use w1 = theta * W_16^{r0},
-// sub-step 2 butterflies (4g .. 4g+3) use w1 = theta^4.  theta comes from the table once per thread and pass.
+// A radix-16 pass over bits [b, b+4) (s = 2^b, a thread's points x[r] are base + r*s, r = r3 r2 r1 r0) with tau the pass's
+// base twiddle, in units of W_16 (e >= 4: the twiddle of e - 4 times -i, folded into the operand modifiers):
+//   forward: tau = W_M^{rev(position >> (b+4)) << b}; stages r3, r2, r1, r0 with twiddles tau^8, tau^4 W16^{4 r3},
+//            tau^2 W16^{2 (r3 + 2 r2)}, tau W16^{r3 + 2 r2 + 4 r1};
+//   inverse: tau = W_{16 s}^{position mod s}; stages r0, r1, r2, r3 with the conjugates of tau^8, tau^4 W16^{4 r0},
+//            tau^2 W16^{2 (r & 3)}, tau W16^{r & 7}.
+// The radix-4 pass over bits [0, 2) is the last two (forward) / first two (inverse) stages of the same 16-point
+// transform on a thread's 16 CONTIGUOUS points.
 //
 // LDS rows are padded by one complex per 16 (pidx) so the strided and the 16-contiguous access patterns of every pass
 // are bank-conflict free for ds_read_b64 / ds_write_b64.
 //
-// The file compiles for the host too (tests/fft_core_host.cpp emulates a workgroup thread by thread against numpy).
+// The file compiles for the host too (tests/native/fft_core_host.cpp emulates a workgroup thread by thread against numpy).
 #pragma once
 
 #if defined(__HIPCC__)
@@ -30,94 +52,136 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 namespace dws {
 
-// (Complex arithmetic on float2 ext-vectors -- one v_pk_add_f32 per complex add, v_pk_mul + v_pk_fma per multiply -- was
-// tried for the device side: hipcc does not fold the re/im swaps and single-lane negations into op_sel / neg modifiers
-// (1023 packed instructions + 219 v_mov + 132 v_xor + spills against 2276 scalar ones: no fewer issue cycles at the
-// measured rates, tools/valu_rate.hip), so the helpers stay componentwise.)
-DWS_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-DWS_HD float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-DWS_HD float2 cmul_(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-DWS_HD float2 cmulc(float2 a, float2 b) {  // a * conj(b)
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+// A complex number in one 64-bit register pair (device) / a plain struct (host emulation).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float c2 __attribute__((ext_vector_type(2)));
+DWS_HD c2 mk(float x, float y) { return c2{x, y}; }
+#else
+typedef float2 c2;
+DWS_HD c2 mk(float x, float y) { return make_float2(x, y); }
+#endif
+
+// ---- packed complex primitives -------------------------------------------------------------------------------------
+// Device: one or two VOP3P instructions each, operand halves routed by op_sel / op_sel_hi, signs by neg_lo / neg_hi.
+// (asm without `volatile`: pure functions of their inputs, so the compiler may schedule, combine and drop them.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DWS_PK3(OP, MODS, D, A, B, C) asm(OP " %0, %1, %2, %3 " MODS : "=v"(D) : "v"(A), "v"(B), "v"(C))
+#define DWS_PK2(OP, MODS, D, A, B) asm(OP " %0, %1, %2 " MODS : "=v"(D) : "v"(A), "v"(B))
+// first source in a scalar register pair (compile-time constant twiddles: no vector registers, no v_mov)
+#define DWS_PK3S(OP, MODS, D, A, B, C) asm(OP " %0, %1, %2, %3 " MODS : "=v"(D) : "s"(A), "v"(B), "v"(C))
+#define DWS_PK2S(OP, MODS, D, A, B) asm(OP " %0, %1, %2 " MODS : "=v"(D) : "s"(A), "v"(B))
+DWS_HD c2 cadd(c2 a, c2 b) { c2 r; DWS_PK2("v_pk_add_f32", "", r, a, b); return r; }
+DWS_HD c2 csub(c2 a, c2 b) { c2 r; DWS_PK2("v_pk_add_f32", "neg_lo:[0,1] neg_hi:[0,1]", r, a, b); return r; }
+// a - i b = (a.x + b.y, a.y - b.x);  a + i b = (a.x - b.y, a.y + b.x)
+DWS_HD c2 cadd_mi(c2 a, c2 b) { c2 r; DWS_PK2("v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]", r, a, b); return r; }
+DWS_HD c2 cadd_pi(c2 a, c2 b) { c2 r; DWS_PK2("v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]", r, a, b); return r; }
+// a + W b with W = w (-i)^ROT (forward) or conj(w) i^ROT (inverse): two dependent v_pk_fma_f32
+// WS: w is a compile-time constant, read from a scalar register pair
+template <bool INV, int ROT, bool WS = false>
+DWS_HD c2 cfma(c2 a, c2 w, c2 b) {
+    c2 t, r;
+#define DWS_CFMA(M1, M2)                                   \
+    if constexpr (WS) {                                    \
+        DWS_PK3S("v_pk_fma_f32", M1, t, w, b, a);          \
+        DWS_PK3S("v_pk_fma_f32", M2, r, w, b, t);          \
+    } else {                                               \
+        DWS_PK3("v_pk_fma_f32", M1, t, w, b, a);           \
+        DWS_PK3("v_pk_fma_f32", M2, r, w, b, t);           \
+    }
+    if (!INV && ROT == 0) {
+        DWS_CFMA("op_sel_hi:[0,1,1]", "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]")
+    } else if (!INV && ROT == 1) {     // w (-i b), -i b = (b.y, -b.x)
+        DWS_CFMA("op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]", "op_sel:[1,0,0] op_sel_hi:[1,1,1]")
+    } else if (INV && ROT == 0) {      // conj(w) b
+        DWS_CFMA("op_sel_hi:[0,1,1]", "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]")
+    } else {                           // conj(w) (i b), i b = (-b.y, b.x)
+        DWS_CFMA("op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]", "op_sel:[1,0,0] op_sel_hi:[1,1,1]")
+    }
+#undef DWS_CFMA
+    return r;
 }
-DWS_HD float2 csqr(float2 a) { return make_float2(a.x * a.x - a.y * a.y, 2.f * a.x * a.y); }
-DWS_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-DWS_HD float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-DWS_HD float2 mul_pos_i(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+// 2 a - x0  (the second output of a butterfly whose first output is x0 = a + W b); the inline constant sits in the low
+// half of its 64-bit operand, op_sel_hi = 0 hands it to both lanes
+DWS_HD c2 cmirror(c2 a, c2 x0) {
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(x0));
+    return r;
+}
+// w a and conj(w) a: v_pk_mul_f32 + v_pk_fma_f32
+DWS_HD c2 cmul_(c2 a, c2 w) {
+    c2 t, r;
+    DWS_PK2("v_pk_mul_f32", "op_sel_hi:[0,1]", t, w, a);
+    DWS_PK3("v_pk_fma_f32", "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]", r, w, a, t);
+    return r;
+}
+DWS_HD c2 cmulc(c2 a, c2 w) {  // a * conj(w)
+    c2 t, r;
+    DWS_PK2("v_pk_mul_f32", "op_sel_hi:[0,1]", t, w, a);
+    DWS_PK3("v_pk_fma_f32", "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]", r, w, a, t);
+    return r;
+}
+// k a for a compile-time constant k (scalar register pair)
+DWS_HD c2 cmulk(c2 a, c2 k) {
+    c2 t, r;
+    DWS_PK2S("v_pk_mul_f32", "op_sel_hi:[0,1]", t, k, a);
+    DWS_PK3S("v_pk_fma_f32", "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]", r, k, a, t);
+    return r;
+}
+// s * a for a real scalar s held in the LOW half of `s2`
+DWS_HD c2 cscale(c2 a, c2 s2) { c2 r; DWS_PK2("v_pk_mul_f32", "op_sel_hi:[0,1]", r, s2, a); return r; }
+#undef DWS_PK3
+#undef DWS_PK2
+#undef DWS_PK3S
+#undef DWS_PK2S
+#else
+DWS_HD c2 cadd(c2 a, c2 b) { return mk(a.x + b.x, a.y + b.y); }
+DWS_HD c2 csub(c2 a, c2 b) { return mk(a.x - b.x, a.y - b.y); }
+DWS_HD c2 cadd_mi(c2 a, c2 b) { return mk(a.x + b.y, a.y - b.x); }
+DWS_HD c2 cadd_pi(c2 a, c2 b) { return mk(a.x - b.y, a.y + b.x); }
+template <bool INV, int ROT, bool WS = false>
+DWS_HD c2 cfma(c2 a, c2 w, c2 b) {
+    // the same two fused multiply-adds per lane as the device form
+    if (!INV && ROT == 0) return mk(fmaf(w.y, -b.y, fmaf(w.x, b.x, a.x)), fmaf(w.y, b.x, fmaf(w.x, b.y, a.y)));
+    if (!INV && ROT == 1) return mk(fmaf(w.y, b.x, fmaf(w.x, b.y, a.x)), fmaf(w.y, b.y, fmaf(w.x, -b.x, a.y)));
+    if (INV && ROT == 0) return mk(fmaf(w.y, b.y, fmaf(w.x, b.x, a.x)), fmaf(w.y, -b.x, fmaf(w.x, b.y, a.y)));
+    return mk(fmaf(w.y, b.x, fmaf(w.x, -b.y, a.x)), fmaf(w.y, b.y, fmaf(w.x, b.x, a.y)));
+}
+DWS_HD c2 cmirror(c2 a, c2 x0) { return mk(fmaf(a.x, 2.f, -x0.x), fmaf(a.y, 2.f, -x0.y)); }
+DWS_HD c2 cmul_(c2 a, c2 w) { return mk(fmaf(w.y, -a.y, w.x * a.x), fmaf(w.y, a.x, w.x * a.y)); }
+DWS_HD c2 cmulc(c2 a, c2 w) { return mk(fmaf(w.y, a.y, w.x * a.x), fmaf(w.y, -a.x, w.x * a.y)); }
+DWS_HD c2 cmulk(c2 a, c2 k) { return cmul_(a, k); }
+DWS_HD c2 cscale(c2 a, c2 s2) { return mk(s2.x * a.x, s2.x * a.y); }
+#endif
+
+DWS_HD c2 csqr(c2 a) { return cmul_(a, a); }
+DWS_HD c2 cconj(c2 a) { return mk(a.x, -a.y); }
+DWS_HD c2 mul_neg_i(c2 a) { return mk(a.y, -a.x); }  // a * (-i)
+DWS_HD c2 mul_pos_i(c2 a) { return mk(-a.y, a.x); }  // a * (+i)
 DWS_HD int pidx(int i) { return i + (i >> 4); }
 
-// W_16^k = exp(-2 pi i k / 16), k = 0..3 and W_8^k, as compile-time selected constants
-template <int K>
-DWS_HD float2 w16c() {
-    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r = 0.70710678118654752440f;
-    return K == 0 ? make_float2(1.f, 0.f) : K == 1 ? make_float2(c1, -s1) : K == 2 ? make_float2(r, -r) : make_float2(s1, -c1);
-}
-
-// Radix-4 butterfly of the in-place DIF (forward) / DIT (inverse) on four points spaced s apart:
-// w1 = W_{4s}^j, w2 = w1^2 (forward math as in two fused radix-2 stages: spans 2s then s).
-template <bool INV>
-DWS_HD void bf4(float2& x0, float2& x1, float2& x2, float2& x3, float2 w1, float2 w2) {
-    if (!INV) {
-        const float2 a0 = cadd(x0, x2), a2 = cmul_(csub(x0, x2), w1);
-        const float2 a1 = cadd(x1, x3), a3 = cmul_(mul_neg_i(csub(x1, x3)), w1);
-        x0 = cadd(a0, a1);
-        x1 = cmul_(csub(a0, a1), w2);
-        x2 = cadd(a2, a3);
-        x3 = cmul_(csub(a2, a3), w2);
-    } else {
-        const float2 v1 = cmulc(x1, w2), v3 = cmulc(x3, w2);
-        const float2 a0 = cadd(x0, v1), a1 = csub(x0, v1), a2 = cadd(x2, v3), a3 = csub(x2, v3);
-        const float2 b2 = cmulc(a2, w1), b3 = mul_pos_i(cmulc(a3, w1));
-        x0 = cadd(a0, b2);
-        x2 = csub(a0, b2);
-        x1 = cadd(a1, b3);
-        x3 = csub(a1, b3);
-    }
-}
-
-// Forward butterfly whose upper two inputs are zero (the zero padding of the convolution input: x2 = x3 = 0).
-DWS_HD void bf4_fwd_zero_hi(float2& x0, float2& x1, float2& x2, float2& x3, float2 w1, float2 w2) {
-    const float2 a2 = cmul_(x0, w1), a3 = cmul_(mul_neg_i(x1), w1);
-    const float2 a0 = x0, a1 = x1;
-    x0 = cadd(a0, a1);
-    x1 = cmul_(csub(a0, a1), w2);
-    x2 = cadd(a2, a3);
-    x3 = cmul_(csub(a2, a3), w2);
-}
-
-// Inverse butterfly when only the lower two outputs are needed (the convolution keeps the first half): x2, x3 are left
-// undefined.
-DWS_HD void bf4_inv_lo_only(float2& x0, float2& x1, float2 x2, float2 x3, float2 w1, float2 w2) {
-    const float2 v1 = cmulc(x1, w2), v3 = cmulc(x3, w2);
-    const float2 a0 = cadd(x0, v1), a1 = csub(x0, v1), a2 = cadd(x2, v3), a3 = csub(x2, v3);
-    x0 = cadd(a0, cmulc(a2, w1));
-    x1 = cadd(a1, mul_pos_i(cmulc(a3, w1)));
-}
-
-// Unit-twiddle radix-4 butterfly (index bits [0, 2): w1 = w2 = 1).
-template <bool INV>
-DWS_HD void bf4_unit(float2& x0, float2& x1, float2& x2, float2& x3) {
-    if (!INV) {
-        const float2 a0 = cadd(x0, x2), a2 = csub(x0, x2), a1 = cadd(x1, x3), a3 = mul_neg_i(csub(x1, x3));
-        x0 = cadd(a0, a1);
-        x1 = csub(a0, a1);
-        x2 = cadd(a2, a3);
-        x3 = csub(a2, a3);
-    } else {
-        const float2 a0 = cadd(x0, x1), a1 = csub(x0, x1), a2 = cadd(x2, x3), a3 = mul_pos_i(csub(x2, x3));
-        x0 = cadd(a0, a2);
-        x2 = csub(a0, a2);
-        x1 = cadd(a1, a3);
-        x3 = csub(a1, a3);
-    }
-}
-
-// Keeps a value opaque to the optimiser (device code): the twiddles derived from a pass's theta are loop invariant over
-// the rows a persistent workgroup walks, and hoisting them out of that loop costs ~20 VGPRs per pass for the kernel's
-// whole lifetime (spills at 1024 threads); recomputing them per row is ~10 % of a pass's arithmetic.
-DWS_HD float2 opaque(float2 v) {
+DWS_HD int brev_bits(int k, int bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(v.x), "+v"(v.y));
+    return bits ? (int)(__brev((unsigned)k) >> (32 - bits)) : 0;
+#else
+    unsigned v = (unsigned)k, r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (v & 1u); v >>= 1; }
+    return (int)r;
+#endif
+}
+
+// W_16^k = exp(-2 pi i k / 16), k = 0..3
+template <int K>
+DWS_HD c2 w16c() {
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r = 0.70710678118654752440f;
+    return K == 0 ? mk(1.f, 0.f) : K == 1 ? mk(c1, -s1) : K == 2 ? mk(r, -r) : mk(s1, -c1);
+}
+
+// Keeps a value opaque to the optimiser (device code): the twiddles derived from a pass's base twiddle are loop
+// invariant over the rows a persistent workgroup walks, and hoisting them out of that loop costs ~20 VGPRs per pass for
+// the kernel's whole lifetime (spills at 1024 threads); recomputing them per row is a few packed instructions per pass.
+DWS_HD c2 opaque(c2 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
 #endif
     return v;
 }
@@ -129,54 +193,98 @@ DWS_HD int opaque(int v) {
     return v;
 }
 
-// Twiddle w1 of sub-step-1 butterfly r0: theta * W_16^{r0} (TW = false: theta = 1).
-template <bool TW, int R0>
-DWS_HD float2 tw16(float2 theta) {
-    if (!TW) return w16c<R0>();
-    return R0 == 0 ? theta : cmul_(theta, w16c<R0>());
+// One radix-2 butterfly in place: a <- a + W b, b <- a - W b (HALF: only a is needed), W = w (-i)^ROT / conj(w) i^ROT.
+// UNIT: w = 1 (two packed adds).
+template <bool INV, int ROT, bool UNIT, bool HALF, bool WS = false>
+DWS_HD void bfly(c2& a, c2& b, c2 w) {
+    if (UNIT) {
+        const c2 s = ROT ? (INV ? cadd_pi(a, b) : cadd_mi(a, b)) : cadd(a, b);
+        if (!HALF) b = ROT ? (INV ? cadd_mi(a, b) : cadd_pi(a, b)) : csub(a, b);
+        a = s;
+    } else {
+        const c2 x0 = cfma<INV, ROT, WS>(a, w, b);
+        if (!HALF) b = cmirror(a, x0);
+        a = x0;
+    }
 }
 
-// The four fused stages of a radix-16 pass on registers: x[r] is the point base + r*s, theta = W_{16 s}^j.
-// Sub-step 1: butterflies (r0, r0+4, r0+8, r0+12) with w1 = theta W_16^{r0}, w2 = w1^2; sub-step 2: butterflies
-// (4g .. 4g+3) with w1 = theta^4, w2 = theta^8.  Twiddles are derived just before their butterfly (few live registers).
+// The twiddles of a 16-point transform with base twiddle tau: T1[k] = tau W16^k (k < 4), T2[k] = tau^2 W8^k (k < 2),
+// T4 = tau^4, T8 = tau^8.  TW = false: tau = 1 (compile-time constants; k = 0 entries are never multiplied with).
+template <bool TW>
+struct Tw16 {
+    c2 T1[4], T2[2], T4, T8;
+    DWS_HD explicit Tw16(c2 tau) {
+        if (TW) {
+            T1[0] = tau; T1[1] = cmulk(tau, w16c<1>()); T1[2] = cmulk(tau, w16c<2>()); T1[3] = cmulk(tau, w16c<3>());
+            T2[0] = csqr(tau); T2[1] = cmulk(T2[0], w16c<2>());
+            T4 = csqr(T2[0]); T8 = csqr(T4);
+        } else {
+            T1[0] = w16c<0>(); T1[1] = w16c<1>(); T1[2] = w16c<2>(); T1[3] = w16c<3>();
+            T2[0] = w16c<0>(); T2[1] = w16c<2>();
+            T4 = T8 = w16c<0>();
+        }
+    }
+};
+
+// One stage of the 16-point transform: butterflies (i, i + 2^BIT) over all i with that bit clear.  E(i) = the stage's
+// twiddle exponent in units of W_16 (see the header); POW selects tau^POW's table.
+template <bool INV, bool TW, int BIT, bool HALF, bool COPY>
+DWS_HD void stage16(c2 (&x)[16], const Tw16<TW>& t) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i & (1 << BIT)) continue;
+        const int j = i + (1 << BIT);
+        if (COPY) {            // forward, upper input zero (the convolution's padding): both outputs equal the lower input
+            x[j] = x[i];
+            continue;
+        }
+        // forward: the bits ABOVE this one, reversed; inverse: the bits BELOW it
+        int e;
+        if (!INV) {
+            const int hi = i >> (BIT + 1), nb = 3 - BIT;              // nb bits above
+            int rv = 0;
+            for (int q = 0; q < nb; ++q) rv |= ((hi >> q) & 1) << (nb - 1 - q);
+            e = rv << BIT;
+        } else {
+            e = (i & ((1 << BIT) - 1)) << (3 - BIT);
+        }
+        const int rot = e >> 2, sel = e & 3;
+        // tau-power of this stage: forward stage BIT uses tau^(2^BIT), inverse stage BIT uses tau^(2^(3-BIT))
+        const int pw = INV ? (8 >> BIT) : (1 << BIT);
+        const bool unit = (!TW && sel == 0);
+        const c2 w = pw == 8 ? t.T8 : pw == 4 ? t.T4 : pw == 2 ? t.T2[sel >> 1] : t.T1[sel];
+        // (TW = false: the remaining twiddles are the constants W16^1..3, read from scalar registers)
+        if (rot) {
+            if (unit) bfly<INV, 1, true, HALF>(x[i], x[j], w);
+            else bfly<INV, 1, false, HALF, !TW>(x[i], x[j], w);
+        } else {
+            if (unit) bfly<INV, 0, true, HALF>(x[i], x[j], w);
+            else bfly<INV, 0, false, HALF, !TW>(x[i], x[j], w);
+        }
+    }
+}
+
+// The four fused stages of a radix-16 pass on registers: x[r] is the point base + r*s, tau the pass's base twiddle
+// (TW = false: tau = 1).  TAIL: only the two stages over r1, r0 (the radix-4 pass over index bits [0, 2)).
 // ZERO_HI (forward): x[8..15] are zero on entry.  LO_ONLY (inverse): only x[0..7] are needed on exit.
-template <bool INV, bool TW, bool ZERO_HI = false, bool LO_ONLY = false>
-DWS_HD void fft16(float2 (&x)[16], float2 theta_in) {
-    const float2 theta = TW ? opaque(theta_in) : theta_in;
-    const float2 t2 = csqr(theta), t4 = csqr(t2), t8 = csqr(t4);   // dead code when !TW
-    // w2 of butterfly r0 is w1^2 = theta^2 W_8^{r0}: {1, (1-i)/sqrt2, -i, -(1+i)/sqrt2} are cheaper than a squaring
-    constexpr float RH = 0.70710678118654752440f;
-    const float2 t2w[4] = {t2, make_float2(RH * (t2.x + t2.y), RH * (t2.y - t2.x)), mul_neg_i(t2),
-                           make_float2(RH * (t2.y - t2.x), -RH * (t2.x + t2.y))};
-#define DWS_W2(R0) t2w[R0]
-#define DWS_STEP1(R0)                                                                                   \
-    {                                                                                                   \
-        const float2 w1 = tw16<TW, R0>(theta);                                                          \
-        const float2 w2 = TW ? DWS_W2(R0) : (R0 == 0 ? make_float2(1.f, 0.f) : R0 == 1 ? w16c<2>()         \
-                                          : R0 == 2 ? make_float2(0.f, -1.f) : mul_neg_i(w16c<2>()));   \
-        if (!INV) {                                                                                     \
-            if (ZERO_HI) bf4_fwd_zero_hi(x[R0], x[R0 + 4], x[R0 + 8], x[R0 + 12], w1, w2);              \
-            else bf4<false>(x[R0], x[R0 + 4], x[R0 + 8], x[R0 + 12], w1, w2);                           \
-        } else {                                                                                        \
-            if (LO_ONLY) bf4_inv_lo_only(x[R0], x[R0 + 4], x[R0 + 8], x[R0 + 12], w1, w2);              \
-            else bf4<true>(x[R0], x[R0 + 4], x[R0 + 8], x[R0 + 12], w1, w2);                            \
-        }                                                                                               \
-    }
-#define DWS_STEP2(G)                                                                                    \
-    {                                                                                                   \
-        if (TW) bf4<INV>(x[4 * G], x[4 * G + 1], x[4 * G + 2], x[4 * G + 3], t4, t8);                   \
-        else bf4_unit<INV>(x[4 * G], x[4 * G + 1], x[4 * G + 2], x[4 * G + 3]);                         \
-    }
+template <bool INV, bool TW, bool ZERO_HI = false, bool LO_ONLY = false, bool TAIL = false>
+DWS_HD void fft16(c2 (&x)[16], c2 tau_in) {
+    const Tw16<TW> t(TW ? opaque(tau_in) : tau_in);
     if (!INV) {
-        DWS_STEP1(0) DWS_STEP1(1) DWS_STEP1(2) DWS_STEP1(3)
-        DWS_STEP2(0) DWS_STEP2(1) DWS_STEP2(2) DWS_STEP2(3)
+        if (!TAIL) {
+            stage16<false, TW, 3, false, ZERO_HI>(x, t);
+            stage16<false, TW, 2, false, false>(x, t);
+        }
+        stage16<false, TW, 1, false, false>(x, t);
+        stage16<false, TW, 0, false, false>(x, t);
     } else {
-        DWS_STEP2(0) DWS_STEP2(1) DWS_STEP2(2) DWS_STEP2(3)
-        DWS_STEP1(0) DWS_STEP1(1) DWS_STEP1(2) DWS_STEP1(3)
+        stage16<true, TW, 0, false, false>(x, t);
+        stage16<true, TW, 1, false, false>(x, t);
+        if (!TAIL) {
+            stage16<true, TW, 2, false, false>(x, t);
+            stage16<true, TW, 3, LO_ONLY, false>(x, t);
+        }
     }
-#undef DWS_STEP1
-#undef DWS_STEP2
-#undef DWS_W2
 }
 
 // Pass plan of size 2^LOG2M with THREADS = M/16 (one 16-point group per thread and pass).
@@ -188,24 +296,38 @@ struct FftPlan {
     static constexpr int N16 = E / 4;                        // radix-16 passes, pass p over bits [E-4(p+1), E-4p)
     static constexpr bool TAIL4 = (E % 4) == 2;              // final radix-4 pass over bits [0, 2)
     static constexpr int b0(int p) { return E - 4 * (p + 1); }
+    // does the pass over bits [b, b+4) carry a non-unit base twiddle?  forward: unless no bit lies above it;
+    // inverse: unless none lies below
+    static constexpr bool tw_fwd(int b) { return b + 4 < LOG2M; }
+    static constexpr bool tw_inv(int b) { return b != 0; }
 };
 
-// theta of every radix-16 pass for the 16-point groups g = tid + i*THREADS (i < NG) this thread owns: j = g mod s.
+// Base twiddles of the passes for the 16-point groups g = tid + i*THREADS (i < NG) this thread owns (tw[k] = W_M^k):
+//   theta[p] (inverse)  W_{16 s}^{g mod s},  s = 2^b0(p): loaded once, kept in registers over the rows a workgroup walks;
+//   phi(p)   (forward)  W_M^{rev(g >> b0(p)) << b0(p)}, and the forward radix-4 tail's W_M^{rev(g)} (the thread's 16
+//            contiguous points are group g of a pass over bits [0, 4)): fetched where they are used (one 8-byte load per
+//            pass, an L2 hit) -- kept live beside theta they cost six more registers and spill at M = 16384.
 template <int LOG2M, int NG = 1>
 struct FftTw {
     using P = FftPlan<LOG2M>;
-    float2 theta[P::N16 > 0 ? P::N16 : 1][NG];
-    DWS_HD void load(const float2* __restrict__ tw, int tid) {
+    c2 theta[P::N16 > 0 ? P::N16 : 1][NG];
+    DWS_HD void load(const c2* __restrict__ tw, int tid) {
         constexpr int THREADS = (P::M / 16) / NG;
 #pragma unroll
         for (int p = 0; p < P::N16; ++p) {
             const int b = P::b0(p);
 #pragma unroll
-            for (int i = 0; i < NG; ++i)
-                theta[p][i] = (b == 0) ? make_float2(1.f, 0.f)
-                                       : tw[((tid + i * THREADS) & ((1 << b) - 1)) * (P::M >> (b + 4))];
+            for (int i = 0; i < NG; ++i) {
+                const int g = tid + i * THREADS;
+                theta[p][i] = (b == 0) ? mk(1.f, 0.f) : tw[(g & ((1 << b) - 1)) * (P::M >> (b + 4))];
+            }
         }
     }
+    template <int B0>
+    static DWS_HD c2 phi(const c2* __restrict__ tw, int g) {
+        return !P::tw_fwd(B0) ? mk(1.f, 0.f) : tw[brev_bits(g >> B0, LOG2M - 4 - B0) << B0];
+    }
+    static DWS_HD c2 tail_twiddle(const c2* __restrict__ tw, int g) { return tw[brev_bits(g, LOG2M - 4)]; }
 };
 
 // Point r of the 16-point group `g` of the pass over bits [B0, B0+4): padded LDS index.
@@ -214,50 +336,43 @@ DWS_HD int group_base(int g) {
     return ((g >> B0) << (B0 + 4)) + (g & ((1 << B0) - 1));
 }
 
-// One radix-16 pass LDS -> LDS (group index g = tid when THREADS = M/16).
+// One radix-16 pass LDS -> LDS (group index g = tid when THREADS = M/16); tau = phi (forward) / theta (inverse).
 template <int LOG2M, int B0, bool INV>
-DWS_HD void pass16_lds(float2* __restrict__ X, float2 theta, int g) {
+DWS_HD void pass16_lds(c2* __restrict__ X, c2 tau, int g) {
     constexpr int S = 1 << B0;
+    constexpr bool TW = INV ? FftPlan<LOG2M>::tw_inv(B0) : FftPlan<LOG2M>::tw_fwd(B0);
     const int base = group_base<B0>(g);
-    float2 x[16];
+    c2 x[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = X[pidx(base + r * S)];
-    fft16<INV, (B0 != 0)>(x, theta);
+    fft16<INV, TW>(x, tau);
 #pragma unroll
     for (int r = 0; r < 16; ++r) X[pidx(base + r * S)] = x[r];
 }
 
-// Final (forward) / first (inverse) radix-4 pass over bits [0, 2): thread g owns points 16g .. 16g+15.
+// Final (forward; tau = psi) / first (inverse; unit twiddles) radix-4 pass over bits [0, 2): thread g owns points
+// 16g .. 16g+15.
 template <bool INV>
-DWS_HD void pass4_lds(float2* __restrict__ X, int g) {
-    float2 x[16];
+DWS_HD void pass4_lds(c2* __restrict__ X, c2 tau, int g) {
+    c2 x[16];
 #pragma unroll
     for (int d = 0; d < 16; ++d) x[d] = X[17 * g + d];  // pidx(16 g + d) = 17 g + d
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bf4_unit<INV>(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    if (INV) fft16<true, false, false, false, true>(x, tau);
+    else fft16<false, true, false, false, true>(x, tau);
 #pragma unroll
     for (int d = 0; d < 16; ++d) X[17 * g + d] = x[d];
 }
 
-// Radix-2 pass over the top bit (odd LOG2M only): `it` runs over M/2 butterflies.
+// Radix-2 pass over the top bit (odd LOG2M only): `t` runs over M/2 butterflies.  Forward: the first stage, unit
+// twiddle; inverse: the last stage, conj(W_M^t).
 template <int LOG2M, bool INV>
-DWS_HD void pass2_top(float2* __restrict__ X, const float2* __restrict__ tw, int t) {
+DWS_HD void pass2_top(c2* __restrict__ X, const c2* __restrict__ tw, int t) {
     constexpr int h = (1 << LOG2M) / 2;
-    const float2 u = X[pidx(t)], v = X[pidx(t + h)];
-    if (!INV) {
-        X[pidx(t)] = cadd(u, v);
-        X[pidx(t + h)] = cmul_(csub(u, v), tw[t]);
-    } else {
-        const float2 vv = cmulc(v, tw[t]);
-        X[pidx(t)] = cadd(u, vv);
-        X[pidx(t + h)] = csub(u, vv);
-    }
-}
-
-DWS_HD int brev_bits(int k, int bits) {
-    unsigned v = (unsigned)k, r = 0;
-    for (int i = 0; i < bits; ++i) { r = (r << 1) | (v & 1u); v >>= 1; }
-    return (int)r;
+    c2 u = X[pidx(t)], v = X[pidx(t + h)];
+    if (!INV) bfly<false, 0, true, false>(u, v, u);
+    else bfly<true, 0, false, false>(u, v, tw[t]);
+    X[pidx(t)] = u;
+    X[pidx(t + h)] = v;
 }
 
 // Pointwise stage of the real-input convolution in bit-reversed order for pair q (0 < q < M/2): positions p = 2q
@@ -265,44 +380,44 @@ DWS_HD int brev_bits(int k, int bits) {
 //   Xe = (Zk + conj Zm)/2, Xo = -(i/2)(Zk - conj Zm), t = Wk Xo;  A[k] = Xe + t, A[M-k] = conj(Xe - t);  Y = A * Kf
 //   Ye = (Yk + conj Ym)/2, Yo = (Yk - conj Ym)/2 * conj(Wk);  Zy[k] = Ye + i Yo, Zy[M-k] = conj(Ye - i Yo)
 // csign = -1 multiplies by conj(K_f): the adjoint (correlation) of the convolution.
-DWS_HD void pointwise_pair(float2& zk_io, float2& zm_io, float2 wk, float2 ka, float2 kb, float csign) {
-    const float2 zk = zk_io, zm = zm_io;
-    const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-    const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);           // Zk - conj Zm
-    const float2 xo = make_float2(0.5f * d.y, -0.5f * d.x);           // -(i/2) d
-    const float2 t = cmul_(wk, xo);
-    const float2 ak = cadd(xe, t), am = cconj(csub(xe, t));
-    const float2 yk = cmul_(ak, make_float2(ka.x, csign * ka.y)), ym = cmul_(am, make_float2(kb.x, csign * kb.y));
-    const float2 ye = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
-    const float2 e = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));  // (Yk - conj Ym)/2
-    const float2 iyo = mul_pos_i(cmulc(e, wk));
+DWS_HD void pointwise_pair(c2& zk_io, c2& zm_io, c2 wk, c2 ka, c2 kb, float csign) {
+    const c2 zk = zk_io, zm = zm_io;
+    const c2 xe = mk(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    const c2 d = mk(zk.x - zm.x, zk.y + zm.y);           // Zk - conj Zm
+    const c2 xo = mk(0.5f * d.y, -0.5f * d.x);           // -(i/2) d
+    const c2 t = cmul_(xo, wk);
+    const c2 ak = cadd(xe, t), am = cconj(csub(xe, t));
+    const c2 yk = cmul_(ak, mk(ka.x, csign * ka.y)), ym = cmul_(am, mk(kb.x, csign * kb.y));
+    const c2 ye = mk(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+    const c2 e = mk(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));  // (Yk - conj Ym)/2
+    const c2 iyo = mul_pos_i(cmulc(e, wk));
     zk_io = cadd(ye, iyo);
     zm_io = cconj(csub(ye, iyo));
 }
 
 // The two halves of pointwise_pair on their own (kernels that accumulate several spectra between them):
 // bins A[k], A[M-k] of the real row from the packed spectrum, and the packed form of a real-row spectrum Y[k], Y[M-k].
-DWS_HD void pair_bins(float2 zk, float2 zm, float2 wk, float2& ak, float2& am) {
-    const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-    const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);
-    const float2 t = cmul_(wk, make_float2(0.5f * d.y, -0.5f * d.x));
+DWS_HD void pair_bins(c2 zk, c2 zm, c2 wk, c2& ak, c2& am) {
+    const c2 xe = mk(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    const c2 d = mk(zk.x - zm.x, zk.y + zm.y);
+    const c2 t = cmul_(mk(0.5f * d.y, -0.5f * d.x), wk);
     ak = cadd(xe, t);
     am = cconj(csub(xe, t));
 }
-DWS_HD void pair_repack(float2 yk, float2 ym, float2 wk, float2& zk, float2& zm) {
-    const float2 ye = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
-    const float2 e = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
-    const float2 iyo = mul_pos_i(cmulc(e, wk));
+DWS_HD void pair_repack(c2 yk, c2 ym, c2 wk, c2& zk, c2& zm) {
+    const c2 ye = mk(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+    const c2 e = mk(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+    const c2 iyo = mul_pos_i(cmulc(e, wk));
     zk = cadd(ye, iyo);
     zm = cconj(csub(ye, iyo));
 }
 
 // q = 0: k = 0 (self-paired, carries DC and Nyquist, both real) and k = M/2 (position 1, self-paired).
-DWS_HD void pointwise_self(float2& z0, float2& z1, float2 kf0, float2 kfM, float2 kfh, float csign) {
+DWS_HD void pointwise_self(c2& z0, c2& z1, c2 kf0, c2 kfM, c2 kfh, float csign) {
     const float y0 = (z0.x + z0.y) * kf0.x;   // A[0] = Re + Im; irfft ignores Im of DC / Nyquist
     const float ym = (z0.x - z0.y) * kfM.x;   // A[M] = Re - Im
-    z0 = make_float2(0.5f * (y0 + ym), 0.5f * (y0 - ym));
-    z1 = cmulc(z1, make_float2(kfh.x, csign * kfh.y));  // Zy[M/2] = Z[M/2] * conj(Kf[M/2])
+    z0 = mk(0.5f * (y0 + ym), 0.5f * (y0 - ym));
+    z1 = cmulc(z1, mk(kfh.x, csign * kfh.y));  // Zy[M/2] = Z[M/2] * conj(Kf[M/2])
 }
 
 }  // namespace dws

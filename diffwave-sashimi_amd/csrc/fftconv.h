@@ -3,6 +3,7 @@
 #include <cmath>
 
 #include "dws_common.h"
+#include "fft_core.h"
 
 namespace dws {
 
@@ -10,11 +11,11 @@ struct FftConvArgs {
     const float* u;     // [B,H,L]  S4 input (LN1(x) + fc_t(e))
     float* g;           // [B,H,L]  GELU(conv + D u)
     const float* D;     // [H]
-    const float2* tw;   // exp(-2 pi i k / M), k < M/2
-    const float2* twp;  // exp(-2 pi i brev(2q) / 2M), q < M/2
-    const float2* kfa;  // [H][M/2] K_f at k = brev(2q)
-    const float2* kfb;  // [H][M/2] K_f at M - k
-    const float2* kfs;  // [H][3]   K_f at 0, M, M/2
+    const c2* tw;   // exp(-2 pi i k / M), k < M/2
+    const c2* twp;  // exp(-2 pi i brev(2q) / 2M), q < M/2
+    const c2* kfa;  // [H][M/2] K_f at k = brev(2q)
+    const c2* kfb;  // [H][M/2] K_f at M - k
+    const c2* kfs;  // [H][3]   K_f at 0, M, M/2
     int B, H, L;
     // training variants (0 / null = the sampling path)
     float* pre;         // also store the pre-activation conv + D u
@@ -27,9 +28,9 @@ struct FftConvArgs {
 struct FftCorrArgs {
     const float* u;     // [B,H,L]
     const float* da;    // [B,H,L]
-    float2* part;       // [nbs][H][M+1]
-    const float2* tw;
-    const float2* twp;
+    c2* part;       // [nbs][H][M+1]
+    const c2* tw;
+    const c2* twp;
     int B, H, L, bchunk;
 };
 int launch_fftcorr(int log2m, const FftCorrArgs& a, hipStream_t s);
@@ -42,11 +43,11 @@ struct FftConvSegArgs {
     const float* u;        // [B,H,L]
     float* g;              // [B,H,L]  GELU(conv + D u)
     const float* D;        // [H]
-    const float2* tw;
-    const float2* twp;
-    const float2* kfa[3];  // pair-ordered spectra [H][M/2]: full, causal', anti-causal'
-    const float2* kfb[3];
-    const float2* kfs[3];  // [H][3]
+    const c2* tw;
+    const c2* twp;
+    const c2* kfa[3];  // pair-ordered spectra [H][M/2]: full, causal', anti-causal'
+    const c2* kfb[3];
+    const c2* kfs[3];  // [H][3]
     int B, H, L;
 };
 constexpr int FFTCONV_SEG_LOG2M = 14;

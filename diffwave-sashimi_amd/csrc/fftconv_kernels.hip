@@ -10,10 +10,10 @@
 // the first L outputs are identical up to rounding (alias-free iff n >= 2L).
 //
 // Real FFT of size Nf via a complex FFT of size M = Nf/2 on z[j] = u[2j] + i u[2j+1] (the row
-// reinterpreted as float2).  In-place radix-2 decimation-in-frequency forward (fused in pairs
-// = radix-4 passes through LDS, the lowest four bits as a 16-point transform in registers)
-// leaves the spectrum in BIT-REVERSED order; the pointwise stage works in that order and a
-// mirrored decimation-in-time inverse brings natural order back -- no reordering pass at all.
+// reinterpreted as complex pairs).  The in-place forward (fft_core.h: twiddle-first radix-2 butterflies
+// on packed fp32, fused four at a time into radix-16 register passes) leaves the spectrum in
+// BIT-REVERSED order; the pointwise stage works in that order and a decimation-in-time inverse
+// brings natural order back -- no reordering pass at all.
 // LDS rows are padded by one complex per 16 so both the strided and the 16-contiguous access
 // patterns are bank-conflict free for ds_read_b64 / ds_write_b64.
 #include "fftconv.h"
@@ -23,7 +23,7 @@
 namespace dws {
 
 __device__ __forceinline__ float gelu_f(float x) { return dws_gelu(x); }
-__device__ __forceinline__ int brev(int k, int bits) { return (int)(__brev((unsigned)k) >> (32 - bits)); }
+__device__ __forceinline__ int brev(int k, int bits) { return brev_bits(k, bits); }
 
 // (Round 3, measured and not kept: every pass over bits [B0, B0+4) with B0 <= 6, and the radix-4 tail, is wave-local -- the 64
 // groups of a wave touch exactly the points [1024 w, 1024 w + 1024) -- so the workgroup barriers between those passes can be
@@ -33,27 +33,29 @@ __device__ __forceinline__ int brev(int k, int bits) { return (int)(__brev((unsi
 // Forward passes P0 .. of the plan on an LDS-resident row (a barrier after each).  A thread owns the NG groups
 // g = tid + i*THREADS, THREADS = M/16/NG.
 template <int LOG2M, int NG, int P0>
-__device__ __forceinline__ void fft_forward_from(float2* X, const FftTw<LOG2M, NG>& W, int tid) {
+__device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ tw, const FftTw<LOG2M, NG>& W, int tid) {
     using P = FftPlan<LOG2M>;
     constexpr int THREADS = (P::M / 16) / NG;
     if constexpr (P0 < P::N16) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             if (i) __builtin_amdgcn_sched_barrier(0);   // one group's 16 points in registers at a time
-            pass16_lds<LOG2M, P::b0(P0), false>(X, W.theta[P0][i], tid + i * THREADS);
+            pass16_lds<LOG2M, P::b0(P0), false>(X, FftTw<LOG2M, NG>::template phi<P::b0(P0)>(tw, opaque(tid) + i * THREADS),
+                                                tid + i * THREADS);
         }
         __syncthreads();
-        fft_forward_from<LOG2M, NG, P0 + 1>(X, W, tid);
+        fft_forward_from<LOG2M, NG, P0 + 1>(X, tw, W, tid);
     } else if constexpr (P::TAIL4) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) pass4_lds<false>(X, tid + i * THREADS);
+        for (int i = 0; i < NG; ++i)
+            pass4_lds<false>(X, FftTw<LOG2M, NG>::tail_twiddle(tw, opaque(tid) + i * THREADS), tid + i * THREADS);
         __syncthreads();
     }
 }
 
 // Inverse passes in mirrored order down to (and including) radix-16 pass P0.
 template <int LOG2M, int NG, int P0, int PCUR>
-__device__ __forceinline__ void fft_inverse_passes(float2* X, const FftTw<LOG2M, NG>& W, int tid) {
+__device__ __forceinline__ void fft_inverse_passes(c2* X, const FftTw<LOG2M, NG>& W, int tid) {
     constexpr int THREADS = (FftPlan<LOG2M>::M / 16) / NG;
     if constexpr (PCUR > P0) {
 #pragma unroll
@@ -67,12 +69,12 @@ __device__ __forceinline__ void fft_inverse_passes(float2* X, const FftTw<LOG2M,
 }
 
 template <int LOG2M, int NG, int P0>
-__device__ __forceinline__ void fft_inverse_to(float2* X, const FftTw<LOG2M, NG>& W, int tid) {
+__device__ __forceinline__ void fft_inverse_to(c2* X, const FftTw<LOG2M, NG>& W, int tid) {
     using P = FftPlan<LOG2M>;
     constexpr int THREADS = (P::M / 16) / NG;
     if constexpr (P::TAIL4) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) pass4_lds<true>(X, tid + i * THREADS);
+        for (int i = 0; i < NG; ++i) pass4_lds<true>(X, mk(1.f, 0.f), tid + i * THREADS);
         __syncthreads();
     }
     fft_inverse_passes<LOG2M, NG, P0, P::N16>(X, W, tid);
@@ -80,17 +82,17 @@ __device__ __forceinline__ void fft_inverse_to(float2* X, const FftTw<LOG2M, NG>
 
 // Whole transforms of an LDS-resident row; the caller has synchronised after filling X.
 template <int LOG2M, int NG>
-__device__ __forceinline__ void fft_forward(float2* X, const float2* tw, const FftTw<LOG2M, NG>& W, int tid) {
+__device__ __forceinline__ void fft_forward(c2* X, const c2* tw, const FftTw<LOG2M, NG>& W, int tid) {
     constexpr int THREADS = (1 << LOG2M) / 16 / NG;
     if constexpr (FftPlan<LOG2M>::ODD) {
         for (int t = tid; t < (1 << LOG2M) / 2; t += THREADS) pass2_top<LOG2M, false>(X, tw, t);
         __syncthreads();
     }
-    fft_forward_from<LOG2M, NG, 0>(X, W, tid);
+    fft_forward_from<LOG2M, NG, 0>(X, tw, W, tid);
 }
 
 template <int LOG2M, int NG>
-__device__ __forceinline__ void fft_inverse(float2* X, const float2* tw, const FftTw<LOG2M, NG>& W, int tid) {
+__device__ __forceinline__ void fft_inverse(c2* X, const c2* tw, const FftTw<LOG2M, NG>& W, int tid) {
     constexpr int THREADS = (1 << LOG2M) / 16 / NG;
     fft_inverse_to<LOG2M, NG, 0>(X, W, tid);
     if constexpr (FftPlan<LOG2M>::ODD) {
@@ -104,7 +106,7 @@ __device__ __forceinline__ void fft_inverse(float2* X, const float2* tw, const F
 // g + (M/16) r, of which r >= 8 are padding and never loaded) and only its result goes to LDS; odd sizes stage the row
 // in LDS first.  The caller must have passed a barrier since the last read of X.
 template <int LOG2M, int NG>
-__device__ __forceinline__ void fft_forward_global(float2* X, const float2* __restrict__ src, int n_valid, const float2* tw,
+__device__ __forceinline__ void fft_forward_global(c2* X, const c2* __restrict__ src, int n_valid, const c2* tw,
                                                    const FftTw<LOG2M, NG>& W, int tid) {
     constexpr int M = 1 << LOG2M, G = M / 16, THREADS = G / NG;
     if constexpr (!FftPlan<LOG2M>::ODD) {
@@ -112,19 +114,19 @@ __device__ __forceinline__ void fft_forward_global(float2* X, const float2* __re
         for (int i = 0; i < NG; ++i) {
             if (i) __builtin_amdgcn_sched_barrier(0);
             const int g = tid + i * THREADS;
-            float2 x[16];
+            c2 x[16];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) x[r] = (g + G * r < n_valid) ? src[g + G * r] : make_float2(0.f, 0.f);
+            for (int r = 0; r < 8; ++r) x[r] = (g + G * r < n_valid) ? src[g + G * r] : mk(0.f, 0.f);
 #pragma unroll
-            for (int r = 8; r < 16; ++r) x[r] = make_float2(0.f, 0.f);
-            fft16<false, true, true>(x, W.theta[0][i]);
+            for (int r = 8; r < 16; ++r) x[r] = mk(0.f, 0.f);
+            fft16<false, false, true>(x, mk(1.f, 0.f));   // no bit above the top pass: its twiddles are the constants W16^k
 #pragma unroll
             for (int r = 0; r < 16; ++r) X[pidx(g + G * r)] = x[r];
         }
         __syncthreads();
-        fft_forward_from<LOG2M, NG, 1>(X, W, tid);
+        fft_forward_from<LOG2M, NG, 1>(X, tw, W, tid);
     } else {
-        for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < n_valid) ? src[j] : make_float2(0.f, 0.f);
+        for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < n_valid) ? src[j] : mk(0.f, 0.f);
         __syncthreads();
         fft_forward<LOG2M, NG>(X, tw, W, tid);
     }
@@ -132,9 +134,9 @@ __device__ __forceinline__ void fft_forward_global(float2* X, const float2* __re
 
 // Pointwise stage in bit-reversed order (fft_core.h: pointwise_pair / pointwise_self), M/2 pairs over the workgroup.
 template <int LOG2M, int THREADS>
-__device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const float2* __restrict__ twp,
-                                                const float2* __restrict__ kfa, const float2* __restrict__ kfb,
-                                                const float2* __restrict__ kfs, int tid_in, float csign) {
+__device__ __forceinline__ void pointwise_pairs(c2* __restrict__ X, const c2* __restrict__ twp,
+                                                const c2* __restrict__ kfa, const c2* __restrict__ kfb,
+                                                const c2* __restrict__ kfs, int tid_in, float csign) {
     constexpr int M = 1 << LOG2M, NPW = M / 2 / THREADS;
     // opaque: the pair addresses are invariant over the rows a workgroup walks; hoisted out of that loop they would
     // occupy ~5 VGPRs per pair for the kernel's lifetime
@@ -142,7 +144,7 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
     // the spectrum / twiddle entries of ALL of this thread's pairs are requested first: one L2 round trip for the stage
     // instead of one per pair (every wave of the workgroup is in this stage at the same time, nothing else hides it);
     // same-box A/B: -1 % at M = 16384, -6 % at M = 4096
-    float2 wk[NPW], ka[NPW], kb[NPW];
+    c2 wk[NPW], ka[NPW], kb[NPW];
 #pragma unroll
     for (int it = 0; it < NPW; ++it) {
         const int q = tid + it * THREADS;
@@ -154,7 +156,7 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
     for (int it = 0; it < NPW; ++it) {
         const int q = tid + it * THREADS;
         if (q == 0) {
-            float2 z0 = X[pidx(0)], z1 = X[pidx(1)];
+            c2 z0 = X[pidx(0)], z1 = X[pidx(1)];
             pointwise_self(z0, z1, kfs[0], kfs[1], kfs[2], csign);
             X[pidx(0)] = z0;
             X[pidx(1)] = z1;
@@ -162,7 +164,7 @@ __device__ __forceinline__ void pointwise_pairs(float2* __restrict__ X, const fl
         }
         const int p = 2 * q;
         const int pm = brev(M - brev(p, LOG2M), LOG2M);
-        float2 zk = X[pidx(p)], zm = X[pidx(pm)];
+        c2 zk = X[pidx(p)], zm = X[pidx(pm)];
         pointwise_pair(zk, zm, wk[it], ka[it], kb[it], csign);
         X[pidx(p)] = zk;
         X[pidx(pm)] = zm;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     using P = FftPlan<LOG2M>;
     constexpr int M = 1 << LOG2M;
     constexpr bool DIRECT = !P::ODD;
-    extern __shared__ __attribute__((aligned(16))) float2 X[];  // M + M/16 complex
+    extern __shared__ __attribute__((aligned(16))) c2 X[];  // M + M/16 complex
     const int tid = threadIdx.x;
     const int L = a.L, Lc = L / 2;  // L even
     constexpr int NG = (1 << LOG2M) / 16 / THREADS;
@@ -207,18 +209,18 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
         // rows of one channel h are adjacent (the kernel spectrum is shared by the batch)
         const int h = row / a.B, b = row % a.B;
         const size_t off = ((size_t)b * a.H + h) * L;
-        const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + off);
+        const c2* __restrict__ u2 = reinterpret_cast<const c2*>(a.u + off);
         fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid);
         pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
                                         a.kfs + (size_t)h * 3, tid, csign);
         __syncthreads();
         const float Dh = a.D[h];
-        float2* __restrict__ g2 = reinterpret_cast<float2*>(a.g + off);
-        float2* __restrict__ p2 = a.pre ? reinterpret_cast<float2*>(a.pre + off) : nullptr;
-        auto finish = [&](int j, float2 y, float2 uu) {
-            const float2 v = make_float2(fmaf(y.x, scale, Dh * uu.x), fmaf(y.y, scale, Dh * uu.y));
+        c2* __restrict__ g2 = reinterpret_cast<c2*>(a.g + off);
+        c2* __restrict__ p2 = a.pre ? reinterpret_cast<c2*>(a.pre + off) : nullptr;
+        auto finish = [&](int j, c2 y, c2 uu) {
+            const c2 v = mk(fmaf(y.x, scale, Dh * uu.x), fmaf(y.y, scale, Dh * uu.y));
             if (p2) p2[j] = v;
-            g2[j] = a.no_act ? v : make_float2(gelu_f(v.x), gelu_f(v.y));
+            g2[j] = a.no_act ? v : mk(gelu_f(v.x), gelu_f(v.y));
         };
         if constexpr (DIRECT) {
             fft_inverse_to<LOG2M, NG, 1>(X, W, tid);
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
             for (int i = 0; i < NG; ++i) {
                 if (i) __builtin_amdgcn_sched_barrier(0);
                 const int g = tid + THREADS * i;
-                float2 x[16];
+                c2 x[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x[r] = X[pidx(g + (M / 16) * r)];
                 fft16<true, true, false, true>(x, W.theta[0][i]);
@@ -252,30 +254,30 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
 template <int LOG2M, int THREADS>
 __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
     constexpr int M = 1 << LOG2M, NP = M / 2 / THREADS;
-    extern __shared__ __attribute__((aligned(16))) float2 X[];
+    extern __shared__ __attribute__((aligned(16))) c2 X[];
     const int tid0 = threadIdx.x, h = blockIdx.x, bs = blockIdx.y;
     const int L = a.L, Lc = L / 2;
     constexpr int NG = (1 << LOG2M) / 16 / THREADS;
     FftTw<LOG2M, NG> W;
     W.load(a.tw, tid0);
     constexpr bool PARK = LOG2M >= 14;
-    float2 ua[PARK ? 1 : NP], ub[PARK ? 1 : NP], pa[NP], pb[NP];
-    float2* __restrict__ o = a.part + ((size_t)bs * a.H + h) * (M + 1);
+    c2 ua[PARK ? 1 : NP], ub[PARK ? 1 : NP], pa[NP], pb[NP];
+    c2* __restrict__ o = a.part + ((size_t)bs * a.H + h) * (M + 1);
     float u0 = 0.f, uM = 0.f, p0 = 0.f, pM = 0.f;
-    float2 uh = make_float2(0.f, 0.f), ph = make_float2(0.f, 0.f);
+    c2 uh = mk(0.f, 0.f), ph = mk(0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) pa[i] = pb[i] = make_float2(0.f, 0.f);
+    for (int i = 0; i < NP; ++i) pa[i] = pb[i] = mk(0.f, 0.f);
     const int b_end = min(a.B, (bs + 1) * a.bchunk);
     // real-FFT bins of pair q from the bit-reversed half-size spectrum (see pointwise_pairs)
-    auto bins = [&](int q, float2& ak, float2& am) {
+    auto bins = [&](int q, c2& ak, c2& am) {
         const int p = 2 * q;
         const int k = brev(p, LOG2M);
         const int pm = brev(M - k, LOG2M);
-        const float2 zk = X[pidx(p)], zm = X[pidx(pm)];
-        const float2 wk = a.twp[q];
-        const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);
-        const float2 t = cmul_(wk, make_float2(0.5f * d.y, -0.5f * d.x));
+        const c2 zk = X[pidx(p)], zm = X[pidx(pm)];
+        const c2 wk = a.twp[q];
+        const c2 xe = mk(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const c2 d = mk(zk.x - zm.x, zk.y + zm.y);
+        const c2 t = cmul_(wk, mk(0.5f * d.y, -0.5f * d.x));
         ak = cadd(xe, t);
         am = cconj(csub(xe, t));
     };
@@ -284,18 +286,18 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
         // opaque copies of the thread index per phase: addresses derived from it (pair positions, table offsets) are
         // loop invariant and would otherwise be hoisted and kept in ~100 VGPRs across the transforms
         int tid = opaque(tid0);
-        const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + ((size_t)b * a.H + h) * L);
-        const float2* __restrict__ d2 = reinterpret_cast<const float2*>(a.da + ((size_t)b * a.H + h) * L);
+        const c2* __restrict__ u2 = reinterpret_cast<const c2*>(a.u + ((size_t)b * a.H + h) * L);
+        const c2* __restrict__ d2 = reinterpret_cast<const c2*>(a.da + ((size_t)b * a.H + h) * L);
         fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid);
         tid = opaque(tid0);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int q = tid + i * THREADS;
             if (q == 0) {
-                const float2 z0 = X[pidx(0)];
+                const c2 z0 = X[pidx(0)];
                 u0 = z0.x + z0.y; uM = z0.x - z0.y; uh = cconj(X[pidx(1)]);   // A[0], A[M], A[M/2]
             } else if (PARK) {
-                float2 k1, k2;
+                c2 k1, k2;
                 bins(q, k1, k2);
                 o[q] = k1;
                 o[M / 2 + q] = k2;
@@ -312,14 +314,14 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
         for (int i = 0; i < NP; ++i) {
             const int q = tid + i * THREADS;
             if (q == 0) {
-                const float2 z0 = X[pidx(0)];
+                const c2 z0 = X[pidx(0)];
                 p0 = fmaf(u0, z0.x + z0.y, p0);
                 pM = fmaf(uM, z0.x - z0.y, pM);
                 ph = cadd(ph, cmulc(cconj(X[pidx(1)]), uh));
             } else {
-                float2 dk, dm;
+                c2 dk, dm;
                 bins(q, dk, dm);
-                const float2 uka = PARK ? o[q] : ua[i], ukb = PARK ? o[M / 2 + q] : ub[i];
+                const c2 uka = PARK ? o[q] : ua[i], ukb = PARK ? o[M / 2 + q] : ub[i];
                 pa[i] = cadd(pa[i], cmulc(dk, uka));   // dA * conj(U)
                 pb[i] = cadd(pb[i], cmulc(dm, ukb));
             }
@@ -331,8 +333,8 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
     for (int i = 0; i < NP; ++i) {
         const int q = tid0 + i * THREADS;
         if (q == 0) {
-            o[0] = make_float2(p0, 0.f);
-            o[M] = make_float2(pM, 0.f);
+            o[0] = mk(p0, 0.f);
+            o[M] = mk(pM, 0.f);
             o[M / 2] = ph;
         } else {
             const int k = brev(2 * q, LOG2M);
@@ -350,19 +352,19 @@ template <int LOG2M, int THREADS>
 __global__ __launch_bounds__(THREADS) void fftconv_seg_kernel(FftConvSegArgs a) {
     constexpr int M = 1 << LOG2M, S = M, NP = M / 2 / THREADS;
     constexpr int NG = M / 16 / THREADS;
-    extern __shared__ __attribute__((aligned(16))) float2 X[];
+    extern __shared__ __attribute__((aligned(16))) c2 X[];
     const int tid0 = threadIdx.x, row = blockIdx.x, j = blockIdx.y;
     const int h = row / a.B, b = row % a.B;
     const int L = a.L, nseg = (L + S - 1) / S;
     const size_t off = ((size_t)b * a.H + h) * L;
-    const float2* __restrict__ u2 = reinterpret_cast<const float2*>(a.u + off);   // L even: samples (2i, 2i+1)
+    const c2* __restrict__ u2 = reinterpret_cast<const c2*>(a.u + off);   // L even: samples (2i, 2i+1)
     FftTw<LOG2M, NG> W;
     W.load(a.tw, tid0);
-    float2 ya[NP], yb[NP];
+    c2 ya[NP], yb[NP];
     float y0 = 0.f, yM = 0.f;
-    float2 yh = make_float2(0.f, 0.f);
+    c2 yh = mk(0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) ya[i] = yb[i] = make_float2(0.f, 0.f);
+    for (int i = 0; i < NP; ++i) ya[i] = yb[i] = mk(0.f, 0.f);
 #pragma unroll 1
     for (int t = 0; t < 3; ++t) {
         const int sj = j + (t == 0 ? 0 : t == 1 ? -1 : 1);
@@ -371,20 +373,20 @@ __global__ __launch_bounds__(THREADS) void fftconv_seg_kernel(FftConvSegArgs a) 
         const int c0 = sj * (S / 2), cn = min(S / 2, L / 2 - c0);   // packed points of this segment that exist
         fft_forward_global<LOG2M, NG>(X, u2 + c0, cn, a.tw, W, tid);
         tid = opaque(tid0);
-        const float2* __restrict__ kfa = a.kfa[t] + (size_t)h * (M / 2);
-        const float2* __restrict__ kfb = a.kfb[t] + (size_t)h * (M / 2);
-        const float2* __restrict__ kfs = a.kfs[t] + (size_t)h * 3;
+        const c2* __restrict__ kfa = a.kfa[t] + (size_t)h * (M / 2);
+        const c2* __restrict__ kfb = a.kfb[t] + (size_t)h * (M / 2);
+        const c2* __restrict__ kfs = a.kfs[t] + (size_t)h * 3;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int q = tid + i * THREADS;
             if (q == 0) {
-                const float2 z0 = X[pidx(0)];
+                const c2 z0 = X[pidx(0)];
                 y0 = fmaf(z0.x + z0.y, kfs[0].x, y0);
                 yM = fmaf(z0.x - z0.y, kfs[1].x, yM);
                 yh = cadd(yh, cmul_(cconj(X[pidx(1)]), kfs[2]));
             } else {
                 const int p = 2 * q, pm = brev(M - brev(p, LOG2M), LOG2M);
-                float2 ak, am;
+                c2 ak, am;
                 pair_bins(X[pidx(p)], X[pidx(pm)], a.twp[q], ak, am);
                 ya[i] = cadd(ya[i], cmul_(ak, kfa[q]));
                 yb[i] = cadd(yb[i], cmul_(am, kfb[q]));
@@ -398,11 +400,11 @@ __global__ __launch_bounds__(THREADS) void fftconv_seg_kernel(FftConvSegArgs a) 
         for (int i = 0; i < NP; ++i) {
             const int q = tid + i * THREADS;
             if (q == 0) {
-                X[pidx(0)] = make_float2(0.5f * (y0 + yM), 0.5f * (y0 - yM));
+                X[pidx(0)] = mk(0.5f * (y0 + yM), 0.5f * (y0 - yM));
                 X[pidx(1)] = cconj(yh);
             } else {
                 const int p = 2 * q, pm = brev(M - brev(p, LOG2M), LOG2M);
-                float2 zk, zm;
+                c2 zk, zm;
                 pair_repack(ya[i], yb[i], a.twp[q], zk, zm);
                 X[pidx(p)] = zk;
                 X[pidx(pm)] = zm;
@@ -412,43 +414,48 @@ __global__ __launch_bounds__(THREADS) void fftconv_seg_kernel(FftConvSegArgs a) 
     __syncthreads();
     fft_inverse<LOG2M, NG>(X, a.tw, W, opaque(tid0));
     const float scale = 1.f / (float)M, Dh = a.D[h];
-    float2* __restrict__ g2 = reinterpret_cast<float2*>(a.g + off);
+    c2* __restrict__ g2 = reinterpret_cast<c2*>(a.g + off);
     const int c0 = j * (S / 2), cn = min(S / 2, L / 2 - c0);
     for (int i = tid0; i < cn; i += THREADS) {
-        const float2 y = X[pidx(i)], uu = u2[c0 + i];
-        g2[c0 + i] = make_float2(gelu_f(fmaf(y.x, scale, Dh * uu.x)), gelu_f(fmaf(y.y, scale, Dh * uu.y)));
+        const c2 y = X[pidx(i)], uu = u2[c0 + i];
+        g2[c0 + i] = mk(gelu_f(fmaf(y.x, scale, Dh * uu.x)), gelu_f(fmaf(y.y, scale, Dh * uu.y)));
     }
 }
 
 // Forward real FFT only (weight time): spectrum of the re-placed two-sided kernel, natural order
 // out[h][k], k = 0..M (Nf/2+1 bins).  Used to build K_f with the SAME transform the convolution uses.
 template <int LOG2M, int THREADS>
-__global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* __restrict__ in, float2* __restrict__ out,
-                                                            const float2* __restrict__ tw,
-                                                            const float2* __restrict__ twn) {
+// (kernel SIGNATURES keep HIP's float2: `c2` is a register-pair vector type in the device pass and float2 in the host pass,
+// and a kernel's mangled name must be the same in both)
+__global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* __restrict__ in, ::float2* __restrict__ out_,
+                                                            const ::float2* __restrict__ tw_,
+                                                            const ::float2* __restrict__ twn_) {
+    c2* __restrict__ out = reinterpret_cast<c2*>(out_);
+    const c2* __restrict__ tw = reinterpret_cast<const c2*>(tw_);
+    const c2* __restrict__ twn = reinterpret_cast<const c2*>(twn_);
     constexpr int M = 1 << LOG2M;
-    extern __shared__ __attribute__((aligned(16))) float2 X[];
+    extern __shared__ __attribute__((aligned(16))) c2 X[];
     const int tid = threadIdx.x, h = blockIdx.x;
-    const float2* __restrict__ r2 = reinterpret_cast<const float2*>(in + (size_t)h * 2 * M);
+    const c2* __restrict__ r2 = reinterpret_cast<const c2*>(in + (size_t)h * 2 * M);
     constexpr int NG = (1 << LOG2M) / 16 / THREADS;
     FftTw<LOG2M, NG> W;
     W.load(tw, tid);
     for (int j = tid; j < M; j += THREADS) X[pidx(j)] = r2[j];
     __syncthreads();
     fft_forward<LOG2M, NG>(X, tw, W, tid);
-    float2* __restrict__ o = out + (size_t)h * (M + 1);
+    c2* __restrict__ o = out + (size_t)h * (M + 1);
     for (int k = tid; k <= M / 2; k += THREADS) {
         if (k == 0) {
-            const float2 z0 = X[pidx(0)];
-            o[0] = make_float2(z0.x + z0.y, 0.f);
-            o[M] = make_float2(z0.x - z0.y, 0.f);
+            const c2 z0 = X[pidx(0)];
+            o[0] = mk(z0.x + z0.y, 0.f);
+            o[M] = mk(z0.x - z0.y, 0.f);
             continue;
         }
-        const float2 zk = X[pidx(brev(k, LOG2M))], zm = X[pidx(brev(M - k, LOG2M))];
-        const float2 wk = twn[k];  // exp(-2 pi i k / (2M))
-        const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);
-        const float2 t = cmul_(wk, make_float2(0.5f * d.y, -0.5f * d.x));
+        const c2 zk = X[pidx(brev(k, LOG2M))], zm = X[pidx(brev(M - k, LOG2M))];
+        const c2 wk = twn[k];  // exp(-2 pi i k / (2M))
+        const c2 xe = mk(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const c2 d = mk(zk.x - zm.x, zk.y + zm.y);
+        const c2 t = cmul_(wk, mk(0.5f * d.y, -0.5f * d.x));
         o[k] = cadd(xe, t);
         o[M - k] = cconj(csub(xe, t));
     }
@@ -474,15 +481,19 @@ __global__ void s4_twosided_pow2_kernel(const float* __restrict__ k, float* __re
 // Pair-ordered copies of the spectrum for the pointwise stage: q -> k = brev(2q):
 //   kfa[h][q] = Kf[h][k], kfb[h][q] = Kf[h][M-k];  kfs[h] = {Kf[0], Kf[M], Kf[M/2]}
 // sign_alt: bin k is multiplied by (-1)^k, i.e. the kernel is shifted by half the transform (segmented long rows).
-__global__ void kf_permute_kernel(const float2* __restrict__ kf, float2* __restrict__ kfa, float2* __restrict__ kfb,
-                                  float2* __restrict__ kfs, int log2m, int sign_alt) {
+__global__ void kf_permute_kernel(const ::float2* __restrict__ kf_, ::float2* __restrict__ kfa_, ::float2* __restrict__ kfb_,
+                                  ::float2* __restrict__ kfs_, int log2m, int sign_alt) {
+    const c2* __restrict__ kf = reinterpret_cast<const c2*>(kf_);
+    c2* __restrict__ kfa = reinterpret_cast<c2*>(kfa_);
+    c2* __restrict__ kfb = reinterpret_cast<c2*>(kfb_);
+    c2* __restrict__ kfs = reinterpret_cast<c2*>(kfs_);
     const int M = 1 << log2m;
     const int q = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y;
     if (q >= M / 2) return;
-    const float2* r = kf + (size_t)h * (M + 1);
+    const c2* r = kf + (size_t)h * (M + 1);
     auto bin = [&](int k) {
-        const float2 v = r[k];
-        return (sign_alt && (k & 1)) ? make_float2(-v.x, -v.y) : v;
+        const c2 v = r[k];
+        return (sign_alt && (k & 1)) ? mk(-v.x, -v.y) : v;
     };
     if (q == 0) {
         kfs[h * 3 + 0] = bin(0); kfs[h * 3 + 1] = bin(M); kfs[h * 3 + 2] = bin(M / 2);
@@ -564,8 +575,8 @@ static int launch_rf(const float* in, float* out, const float* tw, const float* 
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(H), dim3(C::THREADS), C::LDS, s, in, (float2*)out, (const float2*)tw,
-                       (const float2*)twn);
+    hipLaunchKernelGGL(kern, dim3(H), dim3(C::THREADS), C::LDS, s, in, (::float2*)out, (const ::float2*)tw,
+                       (const ::float2*)twn);
     return DWS_OK;
 }
 
@@ -606,8 +617,8 @@ int launch_s4_twosided_pow2(const float* k, float* K, int H, int Lt, int Nf, int
 int launch_kf_permute_signed(const float* kf, float* kfa, float* kfb, float* kfs, int H, int log2m, int sign_alt,
                              hipStream_t s) {
     const int M = 1 << log2m;
-    hipLaunchKernelGGL(kf_permute_kernel, dim3(ceil_div(M / 2, 256), H), dim3(256), 0, s, (const float2*)kf,
-                       (float2*)kfa, (float2*)kfb, (float2*)kfs, log2m, sign_alt);
+    hipLaunchKernelGGL(kf_permute_kernel, dim3(ceil_div(M / 2, 256), H), dim3(256), 0, s, (const ::float2*)kf,
+                       (::float2*)kfa, (::float2*)kfb, (::float2*)kfs, log2m, sign_alt);
     return DWS_OK;
 }
 

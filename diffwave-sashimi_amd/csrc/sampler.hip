@@ -57,13 +57,16 @@ __global__ void smp_fill_normal_kernel(float* __restrict__ x, size_t n, uint64_t
 }
 
 // x <- (x - c1[t]*eps) / c2[t]  (+ sigma[t]*z if t > 0); products and sums are
-// rounded separately (no fma contraction) to match the reference's op-by-op
-// fp32 evaluation (`generate.py:52,54`).
+// rounded separately to match the reference's op-by-op fp32 evaluation (`generate.py:52,54`): contraction is switched
+// off for this kernel and the arithmetic written with plain operators -- the __f*_rn intrinsics are inline functions
+// whose operations hipcc fused into FMAs after inlining (found by
+// tests/test_sampler_gpu.py::test_step_table_sampler_equals_the_per_step_loop: 1 ulp on most elements once t > 0).
 // The last block to finish moves the step index on (t <- t - 1): every block has read t by then, and the next kernel
 // that reads it is stream-ordered behind this one -- no separate one-thread launch per step.
 __global__ void smp_update_kernel(float* __restrict__ x, const float* __restrict__ eps,
                                   const float* __restrict__ tables, int* __restrict__ t_dev,
                                   const float* __restrict__ noise, uint64_t seed, size_t n, int T) {
+#pragma clang fp contract(off)
     const int t = __builtin_amdgcn_readfirstlane(*(volatile int*)t_dev);
     const float c1 = tables[t], c2 = tables[T + t], sg = tables[2 * T + t];
     const float* nz = noise ? noise + (size_t)t * n : nullptr;
@@ -74,8 +77,15 @@ __global__ void smp_update_kernel(float* __restrict__ x, const float* __restrict
         for (int j = 0; j < 4; ++j) {
             const size_t i = g * 4 + j;
             if (i >= n) break;
-            float v = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(c1, eps[i])), c2);
-            if (t > 0) v = __fadd_rn(v, __fmul_rn(sg, nz ? nz[i] : z[j]));
+            // plain operators under `fp contract(off)`: the products, the difference, the quotient and the sum are each
+            // rounded once (the __f*_rn intrinsics are inline functions compiled with contraction allowed; after inlining
+            // the backend fuses them)
+            const float p = c1 * eps[i];
+            float v = (x[i] - p) / c2;
+            if (t > 0) {
+                const float q = sg * (nz ? nz[i] : z[j]);
+                v = v + q;
+            }
             x[i] = v;
         }
     }

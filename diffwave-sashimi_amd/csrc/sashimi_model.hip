@@ -655,8 +655,8 @@ struct SashimiModel : dws_model {
             FftTables* t = tables[l->log2m];
             FftConvArgs fa{};
             fa.u = st->y.f(); fa.g = st->g.f(); fa.D = P(p + ".layer.D");
-            fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
-            fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
+            fa.tw = (const c2*)t->tw.p; fa.twp = (const c2*)t->twp.p;
+            fa.kfa = (const c2*)l->kfa.p; fa.kfb = (const c2*)l->kfb.p; fa.kfs = (const c2*)l->kfs.p;
             fa.B = nB; fa.H = H; fa.L = Ls;
             DWS_TRY(launch_fftconv(l->log2m, fa, s));
             return run_tail(l, st, x, addend, next, s);
@@ -668,10 +668,10 @@ struct SashimiModel : dws_model {
             FftTables* t = tables[FFTCONV_SEG_LOG2M];
             FftConvSegArgs fa{};
             fa.u = st->y.f(); fa.g = st->g.f(); fa.D = P(p + ".layer.D");
-            fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
-            fa.kfa[0] = (const float2*)l->kfa.p; fa.kfb[0] = (const float2*)l->kfb.p; fa.kfs[0] = (const float2*)l->kfs.p;
-            fa.kfa[1] = (const float2*)l->kfa_c.p; fa.kfb[1] = (const float2*)l->kfb_c.p; fa.kfs[1] = (const float2*)l->kfs_c.p;
-            fa.kfa[2] = (const float2*)l->kfa_a.p; fa.kfb[2] = (const float2*)l->kfb_a.p; fa.kfs[2] = (const float2*)l->kfs_a.p;
+            fa.tw = (const c2*)t->tw.p; fa.twp = (const c2*)t->twp.p;
+            fa.kfa[0] = (const c2*)l->kfa.p; fa.kfb[0] = (const c2*)l->kfb.p; fa.kfs[0] = (const c2*)l->kfs.p;
+            fa.kfa[1] = (const c2*)l->kfa_c.p; fa.kfb[1] = (const c2*)l->kfb_c.p; fa.kfs[1] = (const c2*)l->kfs_c.p;
+            fa.kfa[2] = (const c2*)l->kfa_a.p; fa.kfb[2] = (const c2*)l->kfb_a.p; fa.kfs[2] = (const c2*)l->kfs_a.p;
             fa.B = nB; fa.H = H; fa.L = Ls;
             DWS_TRY(launch_fftconv_seg(fa, s));
             return run_tail(l, st, x, addend, next, s);
@@ -1051,8 +1051,8 @@ struct SashimiModel : dws_model {
                 FftTables* t = tables[l->log2m];
                 FftConvArgs fa{};
                 fa.u = l->t_u.f(); fa.g = l->t_g.f(); fa.pre = l->t_a.f(); fa.D = P(p + ".layer.D");
-                fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
-                fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
+                fa.tw = (const c2*)t->tw.p; fa.twp = (const c2*)t->twp.p;
+                fa.kfa = (const c2*)l->kfa.p; fa.kfb = (const c2*)l->kfb.p; fa.kfs = (const c2*)l->kfs.p;
                 fa.B = nB; fa.H = H; fa.L = Ls;
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
                 if (tapconv_glu_supported(2 * H, H, Ls)) {   // o and x1 = x + GLU(o) (+ mel) from one kernel
@@ -1102,7 +1102,7 @@ struct SashimiModel : dws_model {
         DWS_TRY(dkt.ensure((size_t)2 * H * Ls * 4));
         DWS_TRY(dkf.ensure((size_t)2 * H * Lh * 8));
         FftCorrArgs c{};
-        c.u = l->t_u.f(); c.da = da; c.part = (float2*)fpart.p; c.tw = (const float2*)t->tw.p; c.twp = (const float2*)t->twp.p;
+        c.u = l->t_u.f(); c.da = da; c.part = (c2*)fpart.p; c.tw = (const c2*)t->tw.p; c.twp = (const c2*)t->twp.p;
         c.B = nB; c.H = H; c.L = Ls; c.bchunk = bchunk;
         DWS_TRY(launch_fftcorr(l->log2m, c, s));
         DWS_TRY(launch_sum_leading(fpart.f(), dKf.f(), (size_t)H * (M + 1) * 2, nchunks, 1.f, s));
@@ -1225,8 +1225,8 @@ struct SashimiModel : dws_model {
                 FftTables* t = tables[l->log2m];
                 FftConvArgs fa{};
                 fa.u = st->dh.f(); fa.g = st->du.f(); fa.D = P(p + ".layer.D"); fa.conj_k = 1; fa.no_act = 1;
-                fa.tw = (const float2*)t->tw.p; fa.twp = (const float2*)t->twp.p;
-                fa.kfa = (const float2*)l->kfa.p; fa.kfb = (const float2*)l->kfb.p; fa.kfs = (const float2*)l->kfs.p;
+                fa.tw = (const c2*)t->tw.p; fa.twp = (const c2*)t->twp.p;
+                fa.kfa = (const c2*)l->kfa.p; fa.kfb = (const c2*)l->kfb.p; fa.kfs = (const c2*)l->kfs.p;
                 fa.B = nB; fa.H = H; fa.L = Ls;
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
                 DWS_TRY(kernel_backward(l, st->dh.f(), s));

@@ -14,14 +14,11 @@ static void fwd_from(float2* X, const float2* tw) {
     using P = FftPlan<LOG2M>;
     constexpr int T = (1 << LOG2M) / 16;
     if constexpr (P0 < P::N16) {
-        for (int tid = 0; tid < T; ++tid) {
-            FftTw<LOG2M> W;
-            W.load(tw, tid);
-            pass16_lds<LOG2M, P::b0(P0), false>(X, W.theta[P0][0], tid);
-        }
+        for (int tid = 0; tid < T; ++tid)
+            pass16_lds<LOG2M, P::b0(P0), false>(X, FftTw<LOG2M>::template phi<P::b0(P0)>(tw, tid), tid);
         fwd_from<LOG2M, P0 + 1>(X, tw);
     } else if constexpr (P::TAIL4) {
-        for (int tid = 0; tid < T; ++tid) pass4_lds<false>(X, tid);
+        for (int tid = 0; tid < T; ++tid) pass4_lds<false>(X, FftTw<LOG2M>::tail_twiddle(tw, tid), tid);
     }
 }
 
@@ -43,7 +40,7 @@ static void inv_to(float2* X, const float2* tw) {
     using P = FftPlan<LOG2M>;
     constexpr int T = (1 << LOG2M) / 16;
     if constexpr (P::TAIL4)
-        for (int tid = 0; tid < T; ++tid) pass4_lds<true>(X, tid);
+        for (int tid = 0; tid < T; ++tid) pass4_lds<true>(X, make_float2(1.f, 0.f), tid);
     inv_passes<LOG2M, P0, P::N16>(X, tw);
 }
 
@@ -99,7 +96,7 @@ static void conv_row(const float* u, int L, const float* tw_, const float* twp_,
                 x[r] = (i < Lc) ? u2[i] : make_float2(0.f, 0.f);
             }
             for (int r = 8; r < 16; ++r) x[r] = make_float2(0.f, 0.f);
-            fft16<false, true, true>(x, W.theta[0][0]);
+            fft16<false, false, true>(x, make_float2(1.f, 0.f));
             for (int r = 0; r < 16; ++r) X[pidx(tid + T * r)] = x[r];
         }
         fwd_from<LOG2M, 1>(X.data(), tw);

@@ -110,3 +110,41 @@ def test_bench_executed_flops_formula_matches_the_counter():
     assert abs(formula - counted) < 5e-3 * counted, (formula, counted)
     algorithmic, _ = bench.layer_algorithmic_work(cfg)
     assert 0.74 < formula / algorithmic < 0.78          # (10 C^2 + 2 C S + padding) / (14 C^2 + 2 C S)
+
+
+def test_every_device_kernel_is_registered_under_its_own_name():
+    """A `__global__` function is registered by the host pass under its mangled name and looked up in the device code
+    object under the DEVICE pass's mangled name: a parameter type that differs between the passes (a typedef that is a
+    register-pair vector on the device and a struct on the host) builds fine and aborts at the first launch with "Cannot
+    find Symbol" -- on the GPU box only.  So: every kernel descriptor (`<name>.kd`) of every embedded gfx950 code object
+    must appear as a name string in the host half of libdws.so."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    import pytest
+    from diffwave_sashimi_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools) or not shutil.which("strings"):
+        pytest.skip("ROCm LLVM binutils not available")
+    lib = _lib.LIB_PATH
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib, os.path.join(d, "stripped")], check=True)
+        blob = open(fat, "rb").read()
+        offs = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]     # one bundle per translation unit
+        assert offs
+        dev = set()
+        for i, o in enumerate(offs):
+            part, co = os.path.join(d, "b%d.bin" % i), os.path.join(d, "b%d.co" % i)
+            open(part, "wb").write(blob[o:(offs[i + 1] if i + 1 < len(offs) else len(blob))])
+            subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            "--input=" + part, "--output=" + co], check=True)
+            syms = subprocess.run([tools[2], "-sW", co], capture_output=True, text=True, check=True).stdout
+            dev |= {l.split()[-1][:-3] for l in syms.splitlines() if l.split() and l.split()[-1].endswith(".kd")}
+        host = set(subprocess.run(["strings", "-n", "6", lib], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert len(dev) > 100
+    missing = sorted(dev - host)
+    assert not missing, "device kernels the host never registers under that name: %s" % missing[:5]

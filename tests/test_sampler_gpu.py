@@ -85,17 +85,19 @@ def test_step_table_sampler_equals_the_per_step_loop(gpu, backbone):
     al, ab, sg = (dh[k] for k in ("Alpha", "Alpha_bar", "Sigma"))
 
     def loop():
-        x = x_T.to(gpu)
+        # the update in numpy float32 on the host: every product / difference / quotient rounded once, as the engine's
+        # `smp_update_kernel` does them (torch's device kernels may turn a scalar divisor into a reciprocal multiply)
+        x = x_T.numpy().copy()
         with torch.no_grad():
             for t in range(T - 1, -1, -1):
-                eps = net((x, torch.full((B, 1), float(t), device=gpu)))
-                # fp32 scalars evaluated on the host in the reference's order (`generate.py:52`), as the engine's tables are
-                c1, c2 = float((1 - al[t]) / torch.sqrt(1 - ab[t])), torch.sqrt(al[t]).to(gpu)
-                x = (x - c1 * eps) / c2      # c2 as a device tensor: a true division (a host scalar divisor is turned
-                                             # into a multiplication by its reciprocal)
+                eps = net((torch.from_numpy(x).to(gpu), torch.full((B, 1), float(t), device=gpu))).cpu().numpy()
+                c1 = np.float32((1 - al[t]) / torch.sqrt(1 - ab[t]))      # fp32 scalars in the reference's order (`generate.py:52`)
+                c2 = np.float32(torch.sqrt(al[t]))
+                x = (x - c1 * eps) / c2
                 if t > 0:
-                    x = x + float(sg[t]) * noise[t].to(gpu)
-        return x
+                    x = x + np.float32(sg[t]) * noise[t].numpy()
+        assert x.dtype == np.float32
+        return torch.from_numpy(x).to(gpu)
 
     x = loop()
     assert torch.equal(got, x), float((got - x).abs().max())
