@@ -365,6 +365,36 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
         digest = float(sum(p.detach().double().abs().sum() for p in net.parameters()))
     per_rank_param_digest = ddist.gather_over_ranks(digest, red_dev)
     ms = elapsed / args.steps * 1e3
+    dp_overhead = None
+    if world == 1 and not ddist.dist.is_initialized() and os.environ.get("DWS_BENCH_NO_DP_OVERHEAD") is None:
+        # What data parallelism adds to ONE rank's step besides the wire time: the same steps inside a 1-rank RCCL group
+        # (apply_gradient_allreduce: gradients written into the flat buckets, hooks, bucketed asynchronous all-reduces,
+        # division) minus the plain steps above.  Measurable on a one-GPU box; the N-rank exchange itself is the driver's
+        # scaling run.
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ["MASTER_PORT"] = str(ddist._free_port())
+            ddist.dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            apply_gradient_allreduce(net)
+            for _ in range(max(args.warmup, 1)):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            ms_pg = (time.perf_counter() - t1) / args.steps * 1e3
+            red = net._dws_grad_reducer
+            dp_overhead = {"dp_overhead_ms": ms_pg - ms, "ms_per_step_in_1rank_rccl_group": ms_pg, "ms_per_step_plain": ms,
+                           "buckets": len(red.buckets), "bucket_mbytes": [b.flat.numel() * 4 / 2 ** 20 for b in red.buckets],
+                           "gradient_slots": red.last_stats}
+            red.remove()
+            del net._dws_grad_reducer
+        except Exception as e:      # noqa: BLE001 -- reported in the line
+            dp_overhead = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            if ddist.dist.is_initialized():
+                ddist.dist.destroy_process_group()
     roofline = None
     if world == 1 and not args.no_roofline:     # (an extra step on one rank only would hang the other ranks' all-reduce)
         # the MFMA GEMM kernels of one step (forward layer / 1x1 GEMMs, data gradients, weight gradients), timed with
@@ -411,7 +441,7 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
                        "parallelism": "dp%d, bucketed asynchronous RCCL all-reduce of the gradients" % world},
             "per_rank_ms_per_step": per_rank_ms, "process_group": ddist.group_info(),
             "per_rank_final_loss": per_rank_loss, "per_rank_param_digest": per_rank_param_digest,
-            "final_loss": float(loss)})
+            "final_loss": float(loss), **({"dp": dp_overhead} if dp_overhead else {})})
     del net, opt
     torch.cuda.empty_cache()
     if not emit:
@@ -571,7 +601,7 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
     try:
         r = train_bench(a, dict(CONFIGS[a.config]), world, rank, dev, ddist, red_dev, emit=False)
         out[key] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
-                                      "final_loss") if k in r}
+                                      "final_loss", "dp") if k in r}
         if not args.no_cpu_baseline:
             if args.cpu_train_baseline:
                 out[key]["cpu_baseline"] = cpu_train_baseline(dict(CONFIGS[a.config]))

@@ -265,6 +265,13 @@ static int multi_copy(dws_model* m, std::vector<dws::CopyJob>& jobs, hipStream_t
 
 int dws_model_read_tap(dws_model* m, const char* tap, float* dst, int64_t capacity, void* stream) {
     DWS_CHECK(m && tap && dst, DWS_ERR_INVALID, "dws_model_read_tap: null argument");
+    if (std::strcmp(tap, "sampler_eps") == 0) {     // the network output of the sampler's last reverse step
+        const int64_t n = m->B * m->d.out_channels * m->L;
+        DWS_CHECK(m->smp_eps.p && capacity >= n, DWS_ERR_INVALID, "tap sampler_eps: no sampler step has run, or capacity %lld < %lld",
+                  (long long)capacity, (long long)n);
+        DWS_HIP(hipMemcpyAsync(dst, m->smp_eps.p, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return DWS_OK;
+    }
     return m->read_tap(tap, dst, capacity, (hipStream_t)stream);
 }
 

@@ -34,6 +34,8 @@ struct S4TailArgs {
     const float* Ao_c;
     const float* A1_c;
     const float* A2_c;
+    unsigned long long* trace;   // nullable (tools only, DWS_TAIL_TRACE=1): s_memtime stamps [workgroup][wave][16] of the
+                                 // LDS-tile kernel's phases
 };
 
 struct PwMfmaArgs {

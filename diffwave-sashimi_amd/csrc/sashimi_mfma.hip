@@ -14,6 +14,8 @@
 // pw_mfma_kernel: the pooling 1x1 convs (`sashimi.py:23-58`) with the index
 // maps folded into the B-operand gather (DownPool) / the float4 scatter (UpPool).
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #include "sashimi.h"
 #include "sashimi_mfma.h"
@@ -151,6 +153,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
     const int b = __builtin_amdgcn_readfirstlane(tix / ntl), l0 = __builtin_amdgcn_readfirstlane((tix % ntl) * P);
     const int L4 = L * 4;
     constexpr int OOB = 0x7ffffff0;   // lane offset past every descriptor: loads give 0, stores are dropped
+    unsigned long long* __restrict__ trc = a.trace ? a.trace + ((size_t)blockIdx.x * (THREADS / 64) + wave) * 16 : nullptr;
+    auto stamp = [&](int i) {
+        if (trc) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) trc[i] = t;
+        }
+    };
+    stamp(0);
 
     // fp32 MFMA and VALU do not co-issue on a SIMD (tools/ubench/coexec.hip), so every VALU instruction in this
     // kernel is MFMA time lost: all global traffic goes through buffer instructions whose row part is a scalar
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
     __syncthreads();
+    stamp(1);    // staging (LDS-DMA round trip + barrier)
 
     const float4* Ao = reinterpret_cast<const float4*>(a.Ao);
     {
@@ -217,7 +228,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
                 for (int r = 0; r < 16; ++r) { acc_a[m][n][r] = 0.f; acc_b[m][n][r] = 0.f; }
         gemm_slab<MT, NT, P, KGU>(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane);
         gemm_slab<MT, NT, P, KGU>(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane);
+        stamp(2);    // GEMM-o
         __syncthreads();  // every wave is done reading g
+        stamp(3);    // barrier
         // x1 = x + GLU(o) (+ mel) -> tile.  (Requesting x together with the g tile, so that its HBM round trip overlaps the
         // staging barrier, was measured on the same box: 166.5 vs 165.1 us at H = 64 -- no gain, not kept.)
         __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
@@ -256,10 +269,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
             }
         }
     }
+    stamp(4);        // GLU + residual epilogue
     __syncthreads();
+    stamp(5);        // barrier
 
     // ---- LN2 statistics per column (population std, no eps; `sashimi.py:17-20`), centre in place
     column_stats<H, P, PARTS>(tile, red, colmean, colalpha, a.ln_s[0], tid);
+    stamp(6);        // LayerNorm statistics (three barriers)
 
     // ---- FF: per H-row chunk q of u: GEMM-1 chunk -> GELU -> LDS -> GEMM-2 partial
     const float4* A1 = reinterpret_cast<const float4*>(a.A1);
@@ -286,6 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
 #pragma unroll
         for (int m = 0; m < MT; ++m) mt_q[m] = q * (H / 32) + mt_h[m];
         gemm_slab<MT, NT, P, KGU>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
+        stamp(7 + 3 * (q & 1));     // GEMM-1 chunk q  (stamps 7..12 hold the first two chunks)
         if (q > 0) __syncthreads();  // previous chunk of u fully consumed by GEMM-2
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -309,7 +326,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
             }
         }
         __syncthreads();
+        stamp(8 + 3 * (q & 1));     // GELU epilogue + barrier(s)
         gemm_slab<MT, NT, P, KGU>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
+        stamp(9 + 3 * (q & 1));     // GEMM-2 partial
     }
 
     // ---- out = x1 + f (+ addend);  x1 = centred tile + mean
@@ -348,6 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
                 }
             }
         }
+        stamp(13);   // accumulators -> tile
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
@@ -359,6 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rO, voff4, i * ROWS_PASS * L4, 0);
         }
+        stamp(14);   // barrier + output stores issued
         if (a.ynext == nullptr) return;   // uniform
 
         // ---- the next block's S4 input: LN1_next down the columns of the output tile + its step-embedding projection
@@ -380,6 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
             for (int e = 0; e < 4; ++e) y[e] = fmaf(al[e], t[e] + n1m, ev[i]);     // (s/sd)(x - mu + m) + fc_t(e)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rY, voff4, i * ROWS_PASS * L4, 0);
         }
+        stamp(15);   // next block's LayerNorm + its stores issued
     } else {
         __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
         __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
@@ -450,6 +472,41 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
     }
 }
 
+// DWS_TAIL_TRACE=1 (tools only): stamp the phases of every wave of a launch (s_memtime, shader-clock ticks) and print the
+// mean ticks per phase on stderr -- the per-phase budget of a tile.  s_memtime is per XCD: only differences
+// inside one workgroup are formed.
+template <typename F>
+static void tail_trace_launch(int H, int nwg, int waves, S4TailArgs a, hipStream_t s, F launch) {
+    static const char* names[16] = {"", "staging", "GEMM-o", "barrier", "GLU+res", "barrier", "LN2 stats", "GEMM-1 q0", "GELU q0",
+                                    "GEMM-2 q0", "GEMM-1 q1", "GELU q1", "GEMM-2 q1", "acc->tile", "out stores", "next LN1"};
+    unsigned long long* d = nullptr;
+    const size_t n = (size_t)nwg * waves * 16;
+    if (hipMalloc(&d, n * 8) != hipSuccess) return;
+    hipMemsetAsync(d, 0, n * 8, s);
+    a.trace = d;
+    launch(a);
+    hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(n);
+    hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    double ph[16] = {0}, span = 0, wgspan = 0;
+    for (int g = 0; g < nwg; ++g) {
+        unsigned long long g0 = ~0ull, g1 = 0;
+        for (int w = 0; w < waves; ++w) {
+            const unsigned long long* t = &h[((size_t)g * waves + w) * 16];
+            for (int i = 1; i < 16; ++i) ph[i] += (double)(t[i] - t[i - 1]);
+            span += (double)(t[15] - t[0]);
+            if (t[0] < g0) g0 = t[0];
+            if (t[15] > g1) g1 = t[15];
+        }
+        wgspan += (double)(g1 - g0);
+    }
+    const double nw = (double)nwg * waves;
+    fprintf(stderr, "[tail trace] H=%d L=%d wgs=%d waves/wg=%d  mean ticks per wave:", H, a.L, nwg, waves);
+    for (int i = 1; i < 16; ++i) fprintf(stderr, " %s %.0f |", names[i], ph[i] / nw);
+    fprintf(stderr, " wave life %.0f, workgroup span %.0f\n", span / nw, wgspan / nwg);
+}
+
 template <int H, int WM, int WN, int NT, int OCC, bool KGU>
 static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     using T = TailCfg<H, WM, WN, NT, 2>;
@@ -464,6 +521,13 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, false, OCC, KGU>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
+    }
+    static const bool trace = getenv("DWS_TAIL_TRACE") != nullptr;
+    if (trace && (a.L & 3) == 0 && !no_vec && a.ynext) {
+        tail_trace_launch(H, a.B * ntl, T::THREADS / 64, a, s, [&](const S4TailArgs& at) {
+            hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, KGU>), dim3(at.B * ntl), dim3(T::THREADS), lds, s, at);
+        });
+        return DWS_OK;
     }
     if ((a.L & 3) == 0 && !no_vec)
         hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, KGU>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);

@@ -591,6 +591,17 @@ struct WaveNetModel : dws_model {
             DWS_TRY(scratch_out.ensure((size_t)B * Cout * L * 4));
             return final_stage(scratch_out.f(), dst, s);
         }
+        // step-only terms: the per-clip rows of the last forward and the sampler's step table (parity / debugging)
+        struct { const char* name; const DevBuf* buf; size_t n; } small[] = {
+            {"part_t", &part_t, (size_t)B * NL * C}, {"abt", &Abt, mfma_layer ? (size_t)NL * B * abt_row() : 0},
+            {"tab_part_t", &tab_pt, (size_t)tab_T * NL * C}, {"tab_abt", &tab_abt, mfma_layer ? (size_t)NL * tab_T * abt_row() : 0}};
+        for (auto& e : small)
+            if (t == e.name) {
+                DWS_CHECK(e.buf->p && e.n > 0 && capacity >= (int64_t)e.n, DWS_ERR_INVALID, "tap '%s': %zu floats, capacity %lld",
+                          tap, e.n, (long long)capacity);
+                DWS_HIP(hipMemcpyAsync(dst, e.buf->p, e.n * 4, hipMemcpyDeviceToDevice, s));
+                return DWS_OK;
+            }
         return set_error(DWS_ERR_INVALID, "unknown tap '%s'", tap);
     }
 };

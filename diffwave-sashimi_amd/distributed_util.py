@@ -14,8 +14,17 @@ the reference's pattern:
   backward, ``:112-142``).  xGMI is point-to-point (7 links x ~153 GB/s), so a
   ring all-reduce is per-link bound: several ~25 MB buckets in flight keep all
   links busy while backward still runs; a single 94 MB buffer cannot overlap at all.
-* the end-of-backward callback only waits for the outstanding buckets, divides
-  by the world size and hands the views back.
+* the end-of-backward callback only waits for the outstanding buckets and divides
+  by the world size.
+* ZERO-COPY with the engine modules: the flat bucket buffers are the gradient arena.
+  ``grad_views()`` hands out one view per parameter; the engine's backward has
+  ``dws_model_get_grads`` write every gradient straight into its view (one launch) and
+  returns those views, autograd adopts them as ``p.grad`` without a copy, the hooks find
+  the gradient already in place, and after the in-place all-reduce + division ``p.grad``
+  IS the averaged gradient: no per-parameter ``torch.empty``, no copy into the bucket,
+  no copy back (round 3: 656 of each per step for SaShiMi).  Gradients that arrive in
+  their own storage (torch-autograd backbones, accumulated gradients) still take the
+  copy-in / copy-back path.
 
 Backend "nccl" is RCCL on ROCm; the CPU tests use "gloo".
 """
@@ -82,6 +91,7 @@ class _Bucket:
             off += n
         self.pending = len(params)
         self.ready = set()
+        self.foreign = set()     # slots whose gradient lives in its own storage this backward: copied in, copied back
         self.work = None
 
 
@@ -109,6 +119,7 @@ class GradientAllReducer:
         if cur:
             self._close(cur, cur_key)
         self._callback_queued = False
+        self.last_stats = None      # {"in_place": slots found in the arena, "copied": slots copied in and back} of the last backward
         self._handles = []
         for p in params:
             self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -122,6 +133,16 @@ class GradientAllReducer:
     def _launch(self, b):
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
 
+    def grad_views(self):
+        """A fresh view of its bucket slot for every parameter (id(p) -> tensor shaped like p): the engine's backward
+        writes the gradients there and returns these very tensors, which autograd then adopts as ``p.grad``."""
+        out = {}
+        for b in self.buckets:
+            for (off, n), p in zip(b.offsets, b.params):
+                v = b.flat[off:off + n]
+                out[id(p)] = torch.view_as_complex(v.view(*p.shape, 2)) if p.is_complex() else v.view(p.shape)
+        return out
+
     def _on_grad(self, p):
         if not self._callback_queued:
             self._callback_queued = True
@@ -131,7 +152,12 @@ class GradientAllReducer:
         if pi in b.ready:       # gradient accumulated twice in one backward: re-copy, do not recount
             pass
         off, n = b.offsets[pi]
-        b.flat[off:off + n].copy_(_real_view(p.grad).reshape(-1))
+        g = _real_view(p.grad)
+        in_place = (g.data_ptr() == b.flat.data_ptr() + off * b.flat.element_size() and g.is_contiguous()
+                    and g.dtype == b.flat.dtype)
+        if not in_place:       # the gradient lives elsewhere (torch-autograd backbone, accumulation): copy in, copy back later
+            b.flat[off:off + n].copy_(g.reshape(-1))
+            b.foreign.add(pi)
         if pi not in b.ready:
             b.ready.add(pi)
             b.pending -= 1
@@ -139,6 +165,8 @@ class GradientAllReducer:
                 self._launch(b)
 
     def _finalize(self):
+        self.last_stats = {"in_place": sum(len(b.ready) - len(b.foreign) for b in self.buckets),
+                           "copied": sum(len(b.foreign) for b in self.buckets)}
         # Buckets with parameters that got no gradient this backward: every rank has the same graph,
         # so every rank reaches this point with the same set; missing slots contribute zeros.
         for b in self.buckets:
@@ -152,11 +180,12 @@ class GradientAllReducer:
             if b.work is not None:
                 b.work.wait()
                 b.flat /= self.world
-                for pi, p in enumerate(b.params):
-                    if pi in b.ready and p.grad is not None:
+                for pi in b.foreign:       # gradients in their own storage get the average copied back
+                    p = b.params[pi]
+                    if p.grad is not None:
                         off, n = b.offsets[pi]
                         _real_view(p.grad).copy_(b.flat[off:off + n].view_as(_real_view(p.grad)))
-            b.work, b.pending, b.ready = None, len(b.params), set()
+            b.work, b.pending, b.ready, b.foreign = None, len(b.params), set(), set()
         self._callback_queued = False
 
     def remove(self):

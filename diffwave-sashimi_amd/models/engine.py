@@ -41,7 +41,20 @@ class _EngineTrainFn(torch.autograd.Function):
         d = dout.detach().to(torch.float32).contiguous()
         _lib.check(lib.dws_model_backward(m._handle, d.data_ptr(), _lib.current_stream()))
         n = len(ctx.meta)
-        outs = [torch.empty(shape, device=d.device, dtype=torch.float32) for _, shape, _ in ctx.meta]
+        # Data-parallel runs (distributed_util.GradientAllReducer): the gradients are written straight into the flat
+        # all-reduce buckets -- views handed out per backward, adopted by autograd as p.grad without a copy.  A parameter
+        # that still holds a gradient (accumulation over several backwards) gets its own tensor instead: its p.grad may
+        # BE last step's view of the same slot.
+        reducer = getattr(m, "_dws_grad_reducer", None)
+        views = reducer.grad_views() if reducer is not None else {}
+        outs = []
+        for (_, shape, dtype), p in zip(ctx.meta, m.parameters()):
+            v = views.get(id(p)) if (p.grad is None and dtype == torch.float32) else None
+            if v is not None and v.device == d.device and v.dtype == torch.float32 and tuple(v.shape) == shape:
+                outs.append(v)
+            else:
+                outs.append(torch.empty(shape, device=d.device, dtype=torch.float32))
+        del views
         names = (ctypes.c_char_p * n)(*[name.encode() for name, _, _ in ctx.meta])
         dsts = (ctypes.c_void_p * n)(*[g.data_ptr() for g in outs])
         numels = (ctypes.c_int64 * n)(*[g.numel() for g in outs])

@@ -41,6 +41,8 @@ def run(dp):
         loss.backward()
         opt.step()
     torch.cuda.synchronize()
+    global slot_stats
+    slot_stats = net._dws_grad_reducer.last_stats if dp else None
     return losses, [p.detach().clone() for p in net.parameters()], nb
 
 plain_losses, plain_params, _ = run(False)
@@ -52,7 +54,7 @@ dev = torch.device("cuda", 0)
 mx = ddist.max_over_ranks(1.25, dev)
 ga = ddist.gather_over_ranks(2.5, dev)
 same = all(torch.equal(a, b) for a, b in zip(plain_params, dp_params))
-print(json.dumps({"backend": dist.get_backend(), "world": dist.get_world_size(), "buckets": nb, "same": same,
+print(json.dumps({"backend": dist.get_backend(), "world": dist.get_world_size(), "buckets": nb, "same": same, "slots": slot_stats,
                   "losses": [plain_losses, dp_losses], "max": mx, "gather": ga}))
 dist.destroy_process_group()
 '''
@@ -80,6 +82,8 @@ def test_one_rank_rccl_group_runs_the_dp_exchange(gpu):
     d = _last_json(r.stdout)
     assert d["backend"] == "nccl" and d["world"] == 1 and d["buckets"] >= 3
     assert d["same"], "averaging over one rank must leave the training trajectory bit-identical"
+    # zero-copy exchange: the engine wrote every gradient straight into the flat all-reduce buckets (no copy in / back)
+    assert d["slots"]["copied"] == 0 and d["slots"]["in_place"] > 100, d["slots"]
     assert d["losses"][0] == d["losses"][1] and d["max"] == 1.25 and d["gather"] == [2.5]
 
 

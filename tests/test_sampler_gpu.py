@@ -91,8 +91,11 @@ def test_step_table_sampler_equals_the_per_step_loop(gpu, backbone):
         with torch.no_grad():
             for t in range(T - 1, -1, -1):
                 eps = net((torch.from_numpy(x).to(gpu), torch.full((B, 1), float(t), device=gpu))).cpu().numpy()
-                c1 = np.float32((1 - al[t]) / torch.sqrt(1 - ab[t]))      # fp32 scalars in the reference's order (`generate.py:52`)
-                c2 = np.float32(torch.sqrt(al[t]))
+                # fp32 scalars in the reference's order (`generate.py:52`), in numpy: correctly rounded like the C float
+                # arithmetic of the engine's table (torch's CPU sqrt was seen 1 ulp off on an AVX-512 host)
+                a_t, ab_t = np.float32(al[t]), np.float32(ab[t])
+                c1 = (np.float32(1) - a_t) / np.sqrt(np.float32(1) - ab_t)
+                c2 = np.sqrt(a_t)
                 x = (x - c1 * eps) / c2
                 if t > 0:
                     x = x + np.float32(sg[t]) * noise[t].numpy()
