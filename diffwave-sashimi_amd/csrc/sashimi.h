@@ -11,6 +11,11 @@ int launch_s4_twosided(const float* k, float* K, int H, int L, int Lk, int Lt, h
 // step_idx != null (sampler's step-table mode): part_t is row 0 of a [T][pt_tstride] table, the kernel adds row *step_idx
 int launch_ln(const float* x, const float* m_p, const float* s_p, const float* part_t, int pt_bstride, float* out,
               int B, int H, int L, size_t ostride, hipStream_t s, const int* step_idx = nullptr, int pt_tstride = 0);
+// init_conv + the first block's LN1 + step embedding in one pass (x = relu(conv(audio)), y = LN1(x) + part_t)
+bool init_conv_ln_supported(int Cin);
+int launch_init_conv_ln(const float* audio, const float* W, const float* bias, const float* m_p, const float* s_p,
+                        const float* part_t, int pt_bstride, const int* step_idx, int pt_tstride, float* x, float* y, int B,
+                        int Cin, int D, int L, hipStream_t s);
 int launch_spec_mul(float* uf, const float* kf, int B, int H, int Lf, hipStream_t s);
 int launch_s4_post(const float* yc, const float* u, const float* D, float* g, int B, int H, int L, hipStream_t s);
 int launch_pw_conv(const float* in, const float* W, const float* bias, float* out, int B, int K, int O, int L, int act,

@@ -190,6 +190,68 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float* __restrict__ 
     }
 }
 
+// init_conv (`sashimi.py:281`: weight-normed 1x1 conv + ReLU from Cin channels) and the FIRST block's S4 input
+//   y = LN1(x) + fc_t(e)     (`sashimi.py:148-152`)
+// in one pass: a thread owns one position, the D channel values are recomputed from the Cin input samples for the mean,
+// the variance and the two outputs (Cin <= 4: cheaper than holding D values), so x_init is written once and never
+// re-read by a LayerNorm launch.  W / bias reads are wave-uniform (scalar loads).
+template <int CIN>
+__global__ __launch_bounds__(256) void init_conv_ln_kernel(const float* __restrict__ audio, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, const float* __restrict__ m_p,
+                                                           const float* __restrict__ s_p, const float* __restrict__ part_t,
+                                                           int pt_bstride, const int* __restrict__ step_idx, int pt_tstride,
+                                                           float* __restrict__ x, float* __restrict__ y, int D, int L) {
+    const int b = blockIdx.y, l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    part_t += (size_t)b * pt_bstride + step_row_off(step_idx, pt_tstride);
+    float a[CIN];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) a[ci] = audio[((size_t)b * CIN + ci) * L + l];
+    auto chan = [&](int c) {
+        float acc = bias[c];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc = fmaf(W[c * CIN + ci], a[ci], acc);
+        return fmaxf(acc, 0.f);
+    };
+    float sum = 0.f;
+    for (int c = 0; c < D; ++c) sum += chan(c);
+    const float mean = sum / (float)D;
+    float var = 0.f;
+    for (int c = 0; c < D; ++c) {
+        const float d = chan(c) - mean;
+        var = fmaf(d, d, var);
+    }
+    const float scale = s_p[0] / sqrtf(var / (float)D), shift = m_p[0] - mean;
+    float* __restrict__ xb = x + (size_t)b * D * L + l;
+    float* __restrict__ yb = y + (size_t)b * D * L + l;
+    for (int c = 0; c < D; ++c) {
+        const float v = chan(c);
+        xb[(size_t)c * L] = v;
+        yb[(size_t)c * L] = scale * (v + shift) + part_t[c];
+    }
+}
+
+bool init_conv_ln_supported(int Cin) { return Cin >= 1 && Cin <= 4; }
+
+int launch_init_conv_ln(const float* audio, const float* W, const float* bias, const float* m_p, const float* s_p,
+                        const float* part_t, int pt_bstride, const int* step_idx, int pt_tstride, float* x, float* y, int B,
+                        int Cin, int D, int L, hipStream_t s) {
+    ProfileScope ps("init_conv", s);
+    dim3 grid(ceil_div(L, 256), B);
+#define DWS_ICL(CI)                                                                                                     \
+    hipLaunchKernelGGL(init_conv_ln_kernel<CI>, grid, dim3(256), 0, s, audio, W, bias, m_p, s_p, part_t, pt_bstride, step_idx, \
+                       pt_tstride, x, y, D, L)
+    switch (Cin) {
+        case 1: DWS_ICL(1); break;
+        case 2: DWS_ICL(2); break;
+        case 3: DWS_ICL(3); break;
+        case 4: DWS_ICL(4); break;
+        default: return set_error(DWS_ERR_UNSUPPORTED, "init_conv_ln: Cin=%d", Cin);
+    }
+#undef DWS_ICL
+    return DWS_OK;
+}
+
 int launch_ln(const float* x, const float* m_p, const float* s_p, const float* part_t, int pt_bstride, float* out,
               int B, int H, int L, size_t ostride, hipStream_t s, const int* step_idx, int pt_tstride) {
     ProfileScope ps("ln_kernel", s);

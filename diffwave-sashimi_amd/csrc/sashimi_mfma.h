@@ -45,6 +45,14 @@ struct PwMfmaArgs {
     const float* addend;  // UpPool only, nullable
     float* out;
     int B, K, M, L, p;    // L = GEMM columns per batch element (DownPool: output length; UpPool: input length)
+    // optional (all M rows in one workgroup): also emit the S4 input of the block that runs next,
+    //   y = LN1_next(out) + fc_t_next(e)[b, channel]   (`sashimi.py:148-152`), from the output tile still in registers
+    float* ln_y;          // nullable, same layout as out
+    const float* ln_m;    // next block's norm1.m, norm1.s (device scalars)
+    const float* ln_s;
+    const float* ln_e;    // its step-embedding projection: ln_e[b * ln_e_stride + channel] (+ row *ln_step of a step table)
+    int ln_e_stride, ln_e_tstride;
+    const int* ln_step;
 };
 
 bool s4_tail_mfma_supported(int H, int ff);
@@ -54,6 +62,7 @@ int launch_s4_tail_chain(int H, const S4TailArgs& a, hipStream_t s);
 int launch_chain_permute_cols(const float* w, float* out, int M, int K, hipStream_t s);
 int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s);
 bool pw_mfma_supported(int mode, int K, int M, int p);
+bool pw_mfma_ln_supported(int M);
 int launch_pw_mfma(int mode, const PwMfmaArgs& a, hipStream_t s);
 
 }  // namespace dws

@@ -35,7 +35,8 @@ struct TailCfg {
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int MT = H / 32 / WM;            // 32-row tiles per wave for an H-row GEMM
     static constexpr int PARTS = THREADS / P;         // row partitions of the LN column reduction
-    static constexpr int LDS_FLOATS = 2 * H * P + 2 * P + 2 * PARTS * P;
+    static constexpr int NCONST = (3 + 2 * FFE) * H;  // per-row constants kept in LDS: bo [2H], rs1 [FFE H], b1 [FFE H], b2 [H]
+    static constexpr int LDS_FLOATS = 2 * H * P + 2 * P + 2 * PARTS * P + NCONST;
     static_assert(H % (32 * WM) == 0, "H split");
     static_assert(THREADS % P == 0 && H % PARTS == 0, "LN split");
 };
@@ -141,6 +142,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
     float* colmean = ut + H * P;       // [P]
     float* colalpha = colmean + P;     // [P]
     float* red = colalpha + P;         // [2][PARTS][P]
+    // per-row constants of the four epilogues (biases, row sums of W1): copied into LDS while the tiles are staged.  Fetched
+    // where they are used they cost one exposed L2 round trip per epilogue and tile (`profiles/r04_tail_phase_trace.txt`:
+    // the GLU / GELU / output phases carried ~2 k cycles of waiting each); a ds_read_b128 serves four consecutive rows.
+    float* cst_bo = red + 2 * PARTS * P;   // [2H]
+    float* cst_rs = cst_bo + 2 * H;        // [FFE H]
+    float* cst_b1 = cst_rs + FFE * H;      // [FFE H]
+    float* cst_b2 = cst_b1 + FFE * H;      // [H]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,6 +221,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         mt_a[m] = mt_h[m];
         mt_b[m] = H / 32 + mt_h[m];
     }
+    for (int i = tid; i < T::NCONST; i += THREADS) {
+        const float* src = i < 2 * H ? a.bo + i : i < (2 + FFE) * H ? a.rs1 + (i - 2 * H)
+                         : i < (2 + 2 * FFE) * H ? a.b1 + (i - (2 + FFE) * H) : a.b2 + (i - (2 + 2 * FFE) * H);
+        cst_bo[i] = *src;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
     __syncthreads();
     stamp(1);    // staging (LDS-DMA round trip + barrier)
@@ -236,16 +249,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
         __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.mel ? a.mel + (size_t)(a.mel_bstride ? b : 0) * H * L : a.x), 0, H * L4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rBo = __builtin_amdgcn_make_buffer_rsrc((void*)a.bo, 0, 2 * H * 4, 0x00020000);
         const bool has_mel = a.mel != nullptr;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float ba[16], bb[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2);
-                ba[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBo, 16 * lhi, row * 4, 0));
-                bb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBo, 16 * lhi, (H + row) * 4, 0));
+                const int row = mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                ba[r] = cst_bo[row];
+                bb[r] = cst_bo[H + row];
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -281,8 +293,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
     const float4* A1 = reinterpret_cast<const float4*>(a.A1);
     const float4* A2 = reinterpret_cast<const float4*>(a.A2);
     const float lnm = a.ln_m[0];
-    __amdgpu_buffer_rsrc_t rRs = __builtin_amdgcn_make_buffer_rsrc((void*)a.rs1, 0, FFE * H * 4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b1, 0, FFE * H * 4, 0x00020000);
     f32x16 acc2[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -309,9 +319,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
             float rsv[16], b1v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = q * H + mt_h[m] * 32 + (r & 3) + 8 * (r >> 2);
-                rsv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rRs, 16 * lhi, row * 4, 0)) * lnm;
-                b1v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB1, 16 * lhi, row * 4, 0));
+                const int row = q * H + mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                rsv[r] = cst_rs[row] * lnm;
+                b1v[r] = cst_b1[row];
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -336,7 +346,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
         __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.addend ? a.addend + (size_t)b * H * L : a.out), 0, H * L4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, H * 4, 0x00020000);
         const bool has_add = a.addend != nullptr;
         const int f4 = tid % F4_ROW, rsub = tid / F4_ROW;
         const int pos4 = l0 + 4 * f4;
@@ -354,8 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         for (int m = 0; m < MT; ++m) {
             float b2v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                b2v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+            for (int r = 0; r < 16; ++r) b2v[r] = cst_b2[mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int col = (wn * NT + n) * 32 + l31;
@@ -406,14 +414,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
         __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.addend ? a.addend + (size_t)b * H * L : a.out), 0, H * L4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, H * 4, 0x00020000);
         const bool has_add = a.addend != nullptr;
     #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float b2v[16];
     #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                b2v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB2, 16 * lhi, (mt_h[m] * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+            for (int r = 0; r < 16; ++r) b2v[r] = cst_b2[mt_h[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
     #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int col = (wn * NT + n) * 32 + l31;
@@ -666,6 +672,92 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
         __syncthreads();
     }
 
+    // ---- optional LayerNorm of the output columns (the next block's LN1 + step embedding), from the accumulators:
+    // a lane holds 16 MT rows of NT columns; MODE 1 interleaves four output positions (j = row & 3) per GEMM column, each
+    // with its own statistics over the M/4 channels
+    constexpr int NJ = MODE == 0 ? 1 : 4;
+    const bool ln = a.ln_y != nullptr;      // (uniform; the launcher only sets it when this workgroup owns all M rows)
+    float lnscale[NT][NJ], lnshift[NT][NJ];
+    if (ln) {
+        float* red = lds;                   // [4 waves][64 columns][NJ]: the staging buffers are free after the last barrier
+        const float inv_n = 1.f / (float)(a.M / NJ);
+        float part[NT][NJ];
+        auto reduce = [&](float (&out)[NT][NJ]) {      // sum `part` over the lane halves and the four waves
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    part[n][j] += __shfl_xor(part[n][j], 32);
+                    if (lhi == 0) red[(wave * 64 + n * 32 + l31) * NJ + j] = part[n][j];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) t += red[(w * 64 + n * 32 + l31) * NJ + j];
+                    out[n][j] = t;
+                }
+            __syncthreads();
+        };
+        // the values the LayerNorm sees: accumulator + bias (+ U-Net skip)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int pos = l0 + n * 32 + l31;
+                const int posc = pos < L ? pos : 0;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int o0 = mt[m] * 32 + 8 * qd + 4 * lhi;      // rows o0 .. o0+3
+                    float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (MODE == 1 && a.addend)      // the four rows are the four positions of one channel: one 16-byte load
+                        ad = *reinterpret_cast<const float4*>(a.addend + (size_t)b * (a.M / 4) * L * 4 + ((size_t)(o0 / 4) * L + posc) * 4);
+                    acc[m][n][qd * 4 + 0] += a.bias[o0 + 0] + ad.x;
+                    acc[m][n][qd * 4 + 1] += a.bias[o0 + 1] + ad.y;
+                    acc[m][n][qd * 4 + 2] += a.bias[o0 + 2] + ad.z;
+                    acc[m][n][qd * 4 + 3] += a.bias[o0 + 3] + ad.w;
+                }
+            }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) part[n][j] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[n][MODE == 0 ? 0 : (r & 3)] += acc[m][n][r];
+        float mean[NT][NJ], var[NT][NJ];
+        reduce(mean);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { mean[n][j] *= inv_n; part[n][j] = 0.f; }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[m][n][r] - mean[n][MODE == 0 ? 0 : (r & 3)];
+                    part[n][MODE == 0 ? 0 : (r & 3)] = fmaf(d, d, part[n][MODE == 0 ? 0 : (r & 3)]);
+                }
+        reduce(var);
+        const float s_p = a.ln_s[0], m_p = a.ln_m[0];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                lnscale[n][j] = s_p / sqrtf(var[n][j] * inv_n);      // population std, no eps (`sashimi.py:17-20`)
+                lnshift[n][j] = m_p - mean[n][j];
+            }
+    }
+    const float* __restrict__ lne = ln ? a.ln_e + (size_t)b * a.ln_e_stride + step_row_off(a.ln_step, a.ln_e_tstride) : nullptr;
+
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -674,31 +766,50 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
             const bool ok = pos < L;
             if (MODE == 0) {
                 float* __restrict__ ob = a.out + (size_t)b * a.M * L;
+                float* __restrict__ yb = ln ? a.ln_y + (size_t)b * a.M * L : nullptr;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = mt[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (ok) ob[(size_t)o * L + pos] = acc[m][n][r] + a.bias[o];
+                    const float v = ln ? acc[m][n][r] : acc[m][n][r] + a.bias[o];
+                    if (ok) ob[(size_t)o * L + pos] = v;
+                    if (ln && ok) yb[(size_t)o * L + pos] = fmaf(lnscale[n][0], v + lnshift[n][0], lne[o]);
                 }
             } else {
                 const int Ho = a.M / 4;
                 float* __restrict__ ob = a.out + (size_t)b * Ho * L * 4;
+                float* __restrict__ yb = ln ? a.ln_y + (size_t)b * Ho * L * 4 : nullptr;
                 const float* __restrict__ adb = a.addend ? a.addend + (size_t)b * Ho * L * 4 : nullptr;
                 const int posc = ok ? pos : 0;
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     const int o0 = mt[m] * 32 + 8 * qd + 4 * lhi;   // rows o0..o0+3 = channel o0/4, j = 0..3
                     const size_t idx = ((size_t)(o0 / 4) * L + posc) * 4;
-                    float4 v = make_float4(acc[m][n][qd * 4 + 0] + a.bias[o0], acc[m][n][qd * 4 + 1] + a.bias[o0 + 1],
-                                           acc[m][n][qd * 4 + 2] + a.bias[o0 + 2], acc[m][n][qd * 4 + 3] + a.bias[o0 + 3]);
-                    if (adb) {
-                        const float4 ad = *reinterpret_cast<const float4*>(adb + idx);
-                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    float4 v;
+                    if (ln) {     // bias and skip are in the accumulators already
+                        v = make_float4(acc[m][n][qd * 4 + 0], acc[m][n][qd * 4 + 1], acc[m][n][qd * 4 + 2], acc[m][n][qd * 4 + 3]);
+                    } else {
+                        v = make_float4(acc[m][n][qd * 4 + 0] + a.bias[o0], acc[m][n][qd * 4 + 1] + a.bias[o0 + 1],
+                                        acc[m][n][qd * 4 + 2] + a.bias[o0 + 2], acc[m][n][qd * 4 + 3] + a.bias[o0 + 3]);
+                        if (adb) {
+                            const float4 ad = *reinterpret_cast<const float4*>(adb + idx);
+                            v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                        }
                     }
                     if (ok) *reinterpret_cast<float4*>(ob + idx) = v;
+                    if (ln && ok) {
+                        const float e = lne[o0 / 4];
+                        *reinterpret_cast<float4*>(yb + idx) =
+                            make_float4(fmaf(lnscale[n][0], v.x + lnshift[n][0], e), fmaf(lnscale[n][NJ > 1 ? 1 : 0], v.y + lnshift[n][NJ > 1 ? 1 : 0], e),
+                                        fmaf(lnscale[n][NJ > 2 ? 2 : 0], v.z + lnshift[n][NJ > 2 ? 2 : 0], e),
+                                        fmaf(lnscale[n][NJ > 3 ? 3 : 0], v.w + lnshift[n][NJ > 3 ? 3 : 0], e));
+                    }
                 }
             }
         }
 }
+
+// the LayerNorm epilogue reduces over ALL output rows inside one workgroup (128 MT rows, MT <= 4)
+bool pw_mfma_ln_supported(int M) { return M == 128 || M == 256 || M == 512; }
 
 bool pw_mfma_supported(int mode, int K, int M, int p) {
     if (K % 64 != 0 || (M != 128 && M != 256 && M % 512 != 0)) return false;
@@ -708,6 +819,8 @@ bool pw_mfma_supported(int mode, int K, int M, int p) {
 
 template <int MODE>
 static int launch_pw_mode(const PwMfmaArgs& a, hipStream_t s) {
+    DWS_CHECK(a.ln_y == nullptr || pw_mfma_ln_supported(a.M), DWS_ERR_INVALID,
+              "pw_mfma: the LayerNorm epilogue needs all %d rows in one workgroup", a.M);
     const int grid = a.B * ceil_div(a.L, 64);
     if (a.M == 128) hipLaunchKernelGGL((pw_mfma_kernel<1, MODE>), dim3(grid), dim3(256), 0, s, a);
     else if (a.M == 256) hipLaunchKernelGGL((pw_mfma_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a);

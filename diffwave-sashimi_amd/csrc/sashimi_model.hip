@@ -601,6 +601,10 @@ struct SashimiModel : dws_model {
         DWS_TRY(h1.ensure((size_t)B * Emid * 4));
         DWS_TRY(h2.ensure((size_t)B * Eout * 4));
         DWS_TRY(part_t.ensure((size_t)B * pt_total * 4));
+        if (!zero_row.p) {     // (allocated here, never inside a stream capture)
+            DWS_TRY(zero_row.ensure((size_t)D * 4));
+            DWS_HIP(hipMemset(zero_row.p, 0, (size_t)D * 4));
+        }
         return DWS_OK;
     }
 
@@ -642,9 +646,36 @@ struct SashimiModel : dws_model {
                (next->log2m > 0 || next->seg) && !getenv("DWS_SASHIMI_NO_LN_FUSION");
     }
 
+    // A pooling layer on the fused MFMA kernel whose whole output column sits in one workgroup can emit the LN1 + step
+    // embedding of the block that follows it (the first block of the new stage), when that block reads the stage's y buffer.
+    bool pool_feeds(const SLayer* l, const SLayer* next) const {
+        if (!next || l->kind == L_BLOCK || next->kind != L_BLOCK || !l->mfma || getenv("DWS_SASHIMI_NO_LN_FUSION")) return false;
+        const int M = (l->kind == L_DOWN) ? l->Hout : l->Hout * l->p;
+        return pw_mfma_ln_supported(M) && (next->log2m > 0 || next->seg);
+    }
+
     // DiffWaveBlock.forward (sashimi.py:143-184).  y_ready: the previous block's tail already wrote this block's S4 input
     // into the stage's y buffer; next: the block whose S4 input this block's tail should write (or null).
-    int run_block(SLayer* l, const float* x, const float* addend, bool y_ready, SLayer* next, hipStream_t s) {
+    // LayerNorm a tail kernel applies to ITS OUTPUT on the way out (the tile is still in LDS / registers): the next block's
+    // LN1 + step-embedding projection into the stage's y buffer, or -- after the last block -- the network's final norm
+    // (`sashimi.py:309`) into nfin
+    struct OutLN {
+        const float *m = nullptr, *s = nullptr, *e = nullptr;
+        int e_stride = 0, e_tstride = 0;
+        const int* e_step = nullptr;
+        float* y = nullptr;
+    };
+    OutLN next_ln(Stage* st, const SLayer* next) {
+        OutLN o;
+        o.m = P(next->prefix + ".norm1.m"); o.s = P(next->prefix + ".norm1.s");
+        o.e = pt_base() + next->pt_off; o.e_stride = pt_bstride(); o.e_step = step_idx; o.e_tstride = pt_total;
+        o.y = st->y.f();
+        return o;
+    }
+    DevBuf zero_row;     // [max H] zeros: the "step embedding" of the final norm
+    bool final_ln_fused = false;   // set by forward(): the last block's tail wrote norm(x) into nfin
+
+    int run_block(SLayer* l, const float* x, const float* addend, bool y_ready, const OutLN* next, hipStream_t s) {
         Stage* st = stages[l->stage];
         const int H = l->H, Ls = l->L, nB = (int)B;
         const std::string& p = l->prefix;
@@ -692,7 +723,7 @@ struct SashimiModel : dws_model {
     }
 
     // everything of the block after the S4 convolution (sashimi.py:177-184, s4.py:1435)
-    int run_tail(SLayer* l, Stage* st, const float* x, const float* addend, SLayer* next, hipStream_t s) {
+    int run_tail(SLayer* l, Stage* st, const float* x, const float* addend, const OutLN* next, hipStream_t s) {
         const int H = l->H, Ls = l->L, nB = (int)B;
         const std::string& p = l->prefix;
         if (l->mfma) {
@@ -704,11 +735,11 @@ struct SashimiModel : dws_model {
             t.A2 = l->A2.f(); t.b2 = P(p + ".ff.ff.2.conv.bias");
             t.addend = addend; t.out = l->out.f(); t.B = nB; t.L = Ls;
             t.Ao_c = l->Ao_c.f(); t.A1_c = l->A1_c.f(); t.A2_c = l->A2_c.f();
-            if (next) {     // feeds_next(l, next) holds: the stage's y buffer is free once this block's convolution ran
-                t.ynext = st->y.f();
-                t.n1_m = P(next->prefix + ".norm1.m"); t.n1_s = P(next->prefix + ".norm1.s");
-                t.e_next = pt_base() + next->pt_off; t.e_stride = pt_bstride();
-                t.e_step = step_idx; t.e_tstride = pt_total;
+            if (next) {     // next block: feeds_next(l, next) holds, the stage's y buffer is free once this block's convolution ran
+                t.ynext = next->y;
+                t.n1_m = next->m; t.n1_s = next->s;
+                t.e_next = next->e; t.e_stride = next->e_stride;
+                t.e_step = next->e_step; t.e_tstride = next->e_tstride;
             }
             return launch_s4_tail_mfma(H, t, s);
         }
@@ -721,7 +752,7 @@ struct SashimiModel : dws_model {
         return DWS_OK;
     }
 
-    int run_layer(SLayer* l, const float* x, const float* addend, hipStream_t s, bool y_ready = false, SLayer* next = nullptr) {
+    int run_layer(SLayer* l, const float* x, const float* addend, hipStream_t s, bool y_ready = false, const OutLN* next = nullptr) {
         if (l->kind == L_BLOCK) return run_block(l, x, addend, y_ready, next, s);
         if (l->mfma) {
             PwMfmaArgs a{};
@@ -729,6 +760,10 @@ struct SashimiModel : dws_model {
             a.B = (int)B; a.p = l->p;
             if (l->kind == L_DOWN) { a.K = l->H * l->p; a.M = l->Hout; a.L = l->Lout; a.addend = nullptr; }
             else { a.K = l->H; a.M = l->Hout * l->p; a.L = l->L; a.addend = addend; }
+            if (next) {     // pool_feeds(l, next block) holds: the first block of the new stage gets its S4 input from here
+                a.ln_y = next->y; a.ln_m = next->m; a.ln_s = next->s;
+                a.ln_e = next->e; a.ln_e_stride = next->e_stride; a.ln_step = next->e_step; a.ln_e_tstride = next->e_tstride;
+            }
             return launch_pw_mfma(l->kind == L_DOWN ? 0 : 1, a, s);
         }
         if (l->mfma2) {
@@ -748,8 +783,8 @@ struct SashimiModel : dws_model {
                                 l->Hout, l->L, s);
     }
 
-    int final_stage(const float* xin, float* out, float* tap, hipStream_t s) {
-        DWS_TRY(launch_ln(xin, P("norm.m"), P("norm.s"), nullptr, 0, nfin.f(), (int)B, D, (int)L, (size_t)L, s));
+    int final_stage(const float* xin, float* out, float* tap, hipStream_t s, bool ln_done = false) {
+        if (!ln_done) DWS_TRY(launch_ln(xin, P("norm.m"), P("norm.s"), nullptr, 0, nfin.f(), (int)B, D, (int)L, (size_t)L, s));
         WnFinalArgs f{};
         f.skip = nfin.f(); f.Af = Af.f(); f.Wf = Wf.f(); f.bf = P("final_conv.0.conv.bias");
         f.Wz = P("final_conv.2.conv.weight"); f.bz = P("final_conv.2.conv.bias");
@@ -800,7 +835,6 @@ struct SashimiModel : dws_model {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
         trained_fwd = false;   // this forward (eval call, or a step of the sampler) overwrites the activations a pending backward needs
         if (dirty) DWS_TRY(commit(s));
-        DWS_TRY(launch_init_conv(audio, Wi.f(), P("init_conv.0.conv.bias"), x_init.f(), (int)B, Cin, D, (int)L, s));
         DWS_CHECK(!step_idx || (tab_T > 0 && tab_version == commit_version), DWS_ERR_STATE, "step-table forward without a current table");
         DWS_CHECK(step_idx || steps, DWS_ERR_INVALID, "forward: steps == null");
         if (!step_idx) DWS_TRY(embed_rows(steps, (int)B, emb.f(), h1.f(), h2.f(), part_t.f(), s));
@@ -810,11 +844,34 @@ struct SashimiModel : dws_model {
         std::vector<SLayer*> order(d_layers);
         order.insert(order.end(), c_layers.begin(), c_layers.end());
         order.insert(order.end(), u_layers.begin(), u_layers.end());
-        size_t oi = 0;
+        static const bool ln_fusion = getenv("DWS_SASHIMI_NO_LN_FUSION") == nullptr;
+        // the first block's LN1 + step embedding comes out of the init-conv pass when that block runs a fused convolution
+        // (which reads the stage's y buffer); otherwise the block's own LayerNorm launch does it
+        SLayer* first = order.empty() ? nullptr : order[0];
         bool y_ready = false;
+        if (ln_fusion && first && first->kind == L_BLOCK && (first->log2m > 0 || first->seg) && init_conv_ln_supported(Cin)) {
+            DWS_TRY(launch_init_conv_ln(audio, Wi.f(), P("init_conv.0.conv.bias"), P(first->prefix + ".norm1.m"),
+                                        P(first->prefix + ".norm1.s"), pt_base() + first->pt_off, pt_bstride(), step_idx, pt_total,
+                                        x_init.f(), stages[first->stage]->y.f(), (int)B, Cin, D, (int)L, s));
+            y_ready = true;
+        } else {
+            DWS_TRY(launch_init_conv(audio, Wi.f(), P("init_conv.0.conv.bias"), x_init.f(), (int)B, Cin, D, (int)L, s));
+        }
+        // the network's final norm (`sashimi.py:309`) comes out of the LAST block's tail the same way (a zero "embedding")
+        SLayer* last = order.empty() ? nullptr : order.back();
+        final_ln_fused = ln_fusion && last && last->kind == L_BLOCK && last->mfma && last->H == D && zero_row.p;
+        size_t oi = 0;
         auto run = [&](SLayer* l, const float* add) -> int {
-            SLayer* nx = (oi + 1 < order.size() && feeds_next(l, order[oi + 1])) ? order[oi + 1] : nullptr;
-            const int st_ = run_layer(l, x, add, s, y_ready, nx);
+            SLayer* nxt = oi + 1 < order.size() ? order[oi + 1] : nullptr;
+            SLayer* nx = (nxt && (feeds_next(l, nxt) || pool_feeds(l, nxt))) ? nxt : nullptr;
+            OutLN o;
+            const OutLN* po = nullptr;
+            if (nx) { o = next_ln(stages[nx->stage], nx); po = &o; }
+            else if (final_ln_fused && l == last) {
+                o.m = P("norm.m"); o.s = P("norm.s"); o.e = zero_row.f(); o.y = nfin.f();
+                po = &o;
+            }
+            const int st_ = run_layer(l, x, add, s, y_ready, po);
             y_ready = nx != nullptr;
             ++oi;
             return st_;
@@ -838,7 +895,7 @@ struct SashimiModel : dws_model {
             x = l->out.f();
         }
         last_x = x;
-        DWS_TRY(final_stage(x, out, nullptr, s));
+        DWS_TRY(final_stage(x, out, nullptr, s, final_ln_fused));
         DWS_HIP(hipGetLastError());
         return DWS_OK;
     }
