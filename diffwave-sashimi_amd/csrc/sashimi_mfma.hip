@@ -715,10 +715,10 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
                     float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (MODE == 1 && a.addend)      // the four rows are the four positions of one channel: one 16-byte load
                         ad = *reinterpret_cast<const float4*>(a.addend + (size_t)b * (a.M / 4) * L * 4 + ((size_t)(o0 / 4) * L + posc) * 4);
-                    acc[m][n][qd * 4 + 0] += a.bias[o0 + 0] + ad.x;
-                    acc[m][n][qd * 4 + 1] += a.bias[o0 + 1] + ad.y;
-                    acc[m][n][qd * 4 + 2] += a.bias[o0 + 2] + ad.z;
-                    acc[m][n][qd * 4 + 3] += a.bias[o0 + 3] + ad.w;
+                    acc[m][n][qd * 4 + 0] = (acc[m][n][qd * 4 + 0] + a.bias[o0 + 0]) + ad.x;   // (the plain epilogue's order)
+                    acc[m][n][qd * 4 + 1] = (acc[m][n][qd * 4 + 1] + a.bias[o0 + 1]) + ad.y;
+                    acc[m][n][qd * 4 + 2] = (acc[m][n][qd * 4 + 2] + a.bias[o0 + 2]) + ad.z;
+                    acc[m][n][qd * 4 + 3] = (acc[m][n][qd * 4 + 3] + a.bias[o0 + 3]) + ad.w;
                 }
             }
 #pragma unroll
