@@ -229,6 +229,18 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     const int pbase = (q0 >> log2d) << (log2d + 1);          // first position of the tile's block (d < 32: a multiple of 64)
     const int ob = contig ? 32 + (p - pbase) - dil : l31;
     const int os = contig ? dil : 32;
+    // Output columns of the [res; skip] GEMM.  Its two 32-column tiles are the first halves p(q) and the partners p(q) + d
+    // of the tile's 32 pairs -- for d >= 32 two runs of 32 consecutive positions.  For d < 32 (contiguous staging: the tile
+    // is one block of 64 positions with the pairs interleaved) that would scatter every store / atomic instruction over
+    // twice the cache lines (d = 1: even positions in one instruction, odd ones in the other; the d <= 8 layers ran 1.68-1.70
+    // ms against 1.60, `profiles/r03_wino_layer_times.txt`), so there the tiles are positions [base, base + 32) and
+    // [base + 32, base + 64): the gate tile is WRITTEN in that column order (two dword writes per element instead of one
+    // 8-byte write), the B-fragment reads of the GEMM and everything after it stay as they are.
+    //   xo0 / xo1: where this lane's residual x values sit in a staged raw row;  go0 / go1: float offsets of this lane's
+    //   (first half, partner) gate values inside a channel's 64 floats [column][tile].
+    const int x0l = p - pbase, x1l = x0l + dil;                 // local positions of the pair (contig only)
+    const int xo0 = contig ? 32 + l31 : ob + os, xo1 = contig ? 32 : os;
+    const int go0 = contig ? (x0l & 31) * 2 + (x0l >> 5) : l31 * 2, go1 = contig ? (x1l & 31) * 2 + (x1l >> 5) : l31 * 2 + 1;
     int voffA, voffB;
     if (contig) {   // lane = (row parity, 4-float piece of [pbase - 32, pbase + 96))
         const int pp = pbase - 32 + 4 * (lane & 31);
@@ -289,12 +301,12 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
         }
         if (KC >= 32) {
             if ((wave * 32) / KC == c1) {         // the chunk holds all 32 res rows of this wave
-                const float* xw = xs + ((wave * 32) % KC) * 128 + ob;
+                const float* xw = xs + ((wave * 32) % KC) * 128 + xo0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float* xr = xw + ((r & 3) + 8 * (r >> 2) + 4 * lhi) * 128;
-                    acc2[0][0][r] = xr[os];
-                    acc2[0][1][r] = xr[2 * os];
+                    acc2[0][0][r] = xr[0];
+                    acc2[0][1][r] = xr[xo1];
                 }
             }
         } else if ((c1 * KC) / 32 == wave) {      // KC < 32: the wave's rows span 32 / KC chunks
@@ -302,9 +314,9 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
             for (int r = 0; r < 16; ++r) {
                 const int ch = (r & 3) + 8 * (r >> 2);            // + 4*lhi: never crosses a multiple of 8
                 if ((ch % 32) / KC == c1 % ((32 / KC) > 0 ? (32 / KC) : 1)) {   // compile-time per r once c1's parity is known
-                    const float* xr = xs + ((ch % KC) + 4 * lhi) * 128 + ob;
-                    acc2[0][0][r] = xr[os];
-                    acc2[0][1][r] = xr[2 * os];
+                    const float* xr = xs + ((ch % KC) + 4 * lhi) * 128 + xo0;
+                    acc2[0][0][r] = xr[0];
+                    acc2[0][1][r] = xr[xo1];
                 }
             }
         }
@@ -425,7 +437,12 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
             }
             g2[n] = wino_gate(ht, hs);
         }
-        *reinterpret_cast<float2*>(gt + (ch * 32 + l31) * 2) = make_float2(g2[0], g2[1]);
+        if (contig) {
+            gt[ch * 64 + go0] = g2[0];
+            gt[ch * 64 + go1] = g2[1];
+        } else {
+            *reinterpret_cast<float2*>(gt + (ch * 32 + l31) * 2) = make_float2(g2[0], g2[1]);
+        }
     }
     stamp(3);
     __syncthreads();
@@ -442,7 +459,10 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     const char* gb = reinterpret_cast<const char*>(gt) + lane * 8;
     int voffn[2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) voffn[n] = (p + n * dil < L) ? (4 * lhi * L + p + n * dil) * 4 : 0x7ffffff0;
+    for (int n = 0; n < 2; ++n) {
+        const int pos = contig ? pbase + 32 * n + l31 : p + n * dil;
+        voffn[n] = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
+    }
     // (Measured and dropped, same box: one row tile of [res; skip] at a time, so that the x' stores go out under the skip
     // tile's MFMAs: 58.1 against 58.8 / 59.5 ms per step in back-to-back runs -- inside the run-to-run spread.)
     f32x4 c_cur[1 + MS], c_nxt[1 + MS];
