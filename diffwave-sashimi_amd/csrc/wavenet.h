@@ -45,6 +45,7 @@ struct WnFinalArgs {
     float* tap;         // nullable: relu(final_conv[0]) [B, S, L]
     float scale;        // sqrt(1 / num_res_layers)
     int B, L, Cout;
+    int af_scaled;      // Af already holds Wf * scale (the MFMA kernel then stages the skip tile by LDS-DMA, unscaled)
 };
 
 int launch_fold_weight_norm(const float* v, const float* g, float* out, int O, int inner, hipStream_t s);

@@ -681,10 +681,30 @@ __global__ __launch_bounds__(256, 2) void wn_final_mfma_kernel(WnFinalArgs a) {
     const int b = tile / ntl, l0 = (tile % ntl) * P;
 
     const float* sk = a.skip + (size_t)b * S * L;
-    for (int i = tid; i < S * P; i += 256) {
-        const int row = i / P, col = i % P;
-        const int pos = l0 + col;
-        lds[i] = (pos < L) ? sk[(size_t)row * L + pos] * a.scale : 0.f;
+    // the skip tile [S][P]: 16-byte LDS-DMA when the rows allow it (one instruction = 256 consecutive floats of the tile =
+    // 256 / P whole rows; columns past L get an out-of-range offset and read 0) -- no VALU, no VGPRs, a quarter of the
+    // instructions; the 1/sqrt(n_layers) factor then sits in the packed weights (af_scaled).  Otherwise a dword loop.
+    if ((L & 3) == 0 && (((size_t)sk & 15) == 0) && (a.af_scaled || a.scale == 1.f)) {
+        constexpr int F4_ROW = P / 4, RPI = 256 / P, NI = S / RPI / WAVES;
+        static_assert(S % (RPI * WAVES) == 0, "DMA split");
+        __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)sk, 0, S * L * 4, 0x00020000);
+        float* const tile = lds;   // (the builtin takes a pointer variable, not the array expression: with `lds + ...` hipcc's
+                                   // host pass silently drops the kernel's stub)
+        const int pos = l0 + 4 * (lane % F4_ROW);
+        const int voff = pos < L ? ((lane / F4_ROW) * L + pos) * 4 : 0x7ffffff0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row0 = (wave + WAVES * i) * RPI;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, tile + row0 * P, 16, voff, row0 * L * 4, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a barrier does not wait for this wave's LDS-DMA by itself
+    } else {
+        const float sc = a.af_scaled ? 1.f : a.scale;
+        for (int i = tid; i < S * P; i += 256) {
+            const int row = i / P, col = i % P;
+            const int pos = l0 + col;
+            lds[i] = (pos < L) ? sk[(size_t)row * L + pos] * sc : 0.f;
+        }
     }
     __syncthreads();
 
@@ -697,11 +717,17 @@ __global__ __launch_bounds__(256, 2) void wn_final_mfma_kernel(WnFinalArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     constexpr int NKG = S / 8;
     const float4* A = reinterpret_cast<const float4*>(a.Af);
+    // A fragments one k-group ahead of their MFMAs (a k-group feeds only 4 MT NT of them, less than an L2 round trip);
+    // the sched_barrier pins the prefetch where it is written
+    float4 av4[MT], avn[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) av4[m] = A[((size_t)(wm * MT + m) * NKG) * 64 + lane];
 #pragma unroll 2
     for (int kg = 0; kg < NKG; ++kg) {
-        float4 av4[MT];
+        const int kn = (kg + 1 < NKG) ? kg + 1 : kg;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) av4[m] = A[((size_t)(wm * MT + m) * NKG + kg) * 64 + lane];
+        for (int m = 0; m < MT; ++m) avn[m] = A[((size_t)(wm * MT + m) * NKG + kn) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int krow = kg * 8 + j * 2 + lhi;
@@ -716,6 +742,8 @@ __global__ __launch_bounds__(256, 2) void wn_final_mfma_kernel(WnFinalArgs a) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc[m][n], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av4[m] = avn[m];
     }
     // y = relu(acc + bf[row]); optional tap; out[oc] = bz[oc] + sum_row Wz[oc,row] * y
     for (int oc = 0; oc < a.Cout; ++oc) {

@@ -181,9 +181,12 @@ struct WaveNetModel : dws_model {
         }
         DWS_TRY(Wf.ensure((size_t)S * S * 4));
         DWS_TRY(fold("final_conv.0.conv", Wf.f(), S, S, s));
-        if (mfma_final) {
+        if (mfma_final) {   // the packed copy carries the 1/sqrt(n_layers) of `wavenet.py:165` (the kernel's skip tile arrives by
+                            // LDS-DMA, which cannot scale); Wf itself stays unscaled for the generic kernel and the adjoints
             DWS_TRY(Af.ensure((size_t)S * S * 4));
-            DWS_TRY(launch_pack_a_frag(Wf.f(), Af.f(), S, S, s));
+            DWS_TRY(tmp_pack.ensure((size_t)std::max(2 * C * 4 * C, S * S) * 4));
+            DWS_TRY(launch_scale(Wf.f(), tmp_pack.f(), (float)std::sqrt(1.0 / NL), (size_t)S * S, s));
+            DWS_TRY(launch_pack_a_frag(tmp_pack.f(), Af.f(), S, S, s));
         }
         // embedding frequencies: exp(float(i) * float(-ln(1e4)/(half-1)))  (`models/utils.py:22-23`)
         DWS_TRY(stack_params.run(s));
@@ -312,7 +315,7 @@ struct WaveNetModel : dws_model {
         WnFinalArgs f{};
         f.skip = skip.f(); f.Af = Af.f(); f.Wf = Wf.f(); f.bf = P("final_conv.0.conv.bias");
         f.Wz = P("final_conv.2.conv.weight"); f.bz = P("final_conv.2.conv.bias");
-        f.out = out; f.tap = tap; f.scale = (float)std::sqrt(1.0 / NL);
+        f.out = out; f.tap = tap; f.scale = (float)std::sqrt(1.0 / NL); f.af_scaled = mfma_final ? 1 : 0;
         f.B = (int)B; f.L = (int)L; f.Cout = Cout;
         return launch_wn_final(S, f, s);
     }
