@@ -643,24 +643,38 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma4_kernel(WgradArgs a) {
         if (ch + 1 < ch_end) stage(ch + 1, buf ^ 1);
         const float* sdy = wlds + buf * 2 * TILE;
         const float* sx = sdy + TILE;
-        if (do_bias && tid < 128) {           // the row sum does not care about the rotation
+        if (do_bias) {     // row sums of dY: ALL 512 threads take a quarter row each (the row sum does not care about the rotation).
+                           // Done by the first 128 threads alone (a whole row each) the two waves that own them reached every
+                           // chunk barrier ~600 cycles after the other six.
+            const int brow = tid >> 2, bq = (tid & 3) * 4;
 #pragma unroll
-            for (int q = 0; q < PC / 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sdy + tid * PC + 4 * ((q + tid) & 15));
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sdy + brow * PC + 4 * ((bq + q + brow) & 15));
                 bsum += (v[0] + v[1]) + (v[2] + v[3]);
             }
         }
+        // operands of block j + 1 are read while block j's eight MFMAs run (the sched_barriers pin that order): left to
+        // itself hipcc reads one operand, waits for it (lgkmcnt(0)) and issues four MFMAs on ONE accumulator, eight registers
+        // of operands in all -- every group of four MFMAs then starts with an exposed LDS round trip
+        f32x4 a0, a1, bv, a0n, a1n, bvn;
+        auto rd = [&](int j, f32x4& x0, f32x4& x1, f32x4& y) {
+            const int qa = (2 * j + lhi + rowA) & 15, qb = (2 * j + lhi + rowB) & 15;
+            x0 = *reinterpret_cast<const f32x4*>(sdy + rowA * PC + 4 * qa);
+            x1 = *reinterpret_cast<const f32x4*>(sdy + (rowA + 32) * PC + 4 * qa);
+            y = *reinterpret_cast<const f32x4*>(sx + rowB * PC + 4 * qb);
+        };
+        rd(0, a0, a1, bv);
 #pragma unroll
         for (int j = 0; j < PC / 8; ++j) {
-            const int qa = (2 * j + lhi + rowA) & 15, qb = (2 * j + lhi + rowB) & 15;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sdy + rowA * PC + 4 * qa);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sdy + (rowA + 32) * PC + 4 * qa);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(sx + rowB * PC + 4 * qb);
+            if (j + 1 < PC / 8) rd(j + 1, a0n, a1n, bvn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bv[e], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bv[e], acc[1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a0n; a1 = a1n; bv = bvn;
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk ch+1 has landed (hipcc does not make a barrier wait for LDS-DMA)
         __syncthreads();                      // ... for every wave, and buffer `buf` is free again
@@ -674,7 +688,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma4_kernel(WgradArgs a) {
             const int c = c0 + wc * 32 + l31;
             if (o < a.O && c < a.C) part[(size_t)o * a.C + c] = acc[i][r];
         }
-    if (do_bias && tid < 128 && o0 + tid < a.O) a.bias_part[(size_t)split * a.O + o0 + tid] = bsum;
+    if (do_bias) {     // the four quarter-row partials of a row sit in four adjacent lanes
+        bsum += __shfl_xor(bsum, 1);
+        bsum += __shfl_xor(bsum, 2);
+        if ((tid & 3) == 0 && o0 + (tid >> 2) < a.O) a.bias_part[(size_t)split * a.O + o0 + (tid >> 2)] = bsum;
+    }
 }
 
 
