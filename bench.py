@@ -515,6 +515,8 @@ def main():
                     help="also time one training step of the CPU oracle at B=1 beside the training leg / --mode train (~100 s)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs of the default headline run")
+    ap.add_argument("--no-full-loop", action="store_true",
+                    help="skip the complete T-step dws_sampler_run beside the timed steps (profiler passes: counters serialise kernels)")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -717,7 +719,7 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
     free_b, total_b = torch.cuda.mem_get_info()
     result["hbm_bytes_in_use"] = int(total_b - free_b)     # device-wide (engine workspaces are hipMalloc'ed, not torch's)
 
-    if rank == 0 and full:
+    if rank == 0 and full and not getattr(args, "no_full_loop", False):
         # the metric as `generate.py:49-54` defines it: ONE complete T-step loop -- Philox draw of x_T, then T replays of the
         # captured step -- wall-clocked end to end on this rank (launch to synchronize), beside the per-step rate above
         torch.cuda.synchronize()
@@ -741,14 +743,23 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
         # launch stream inside the engine (eager launches, outside any capture).
         flops, bytes_ = layer_algorithmic_work(cfg)
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
-        _lib.check(lib.dws_profile_enable(b"wn_layer"))
-        nprof = 3
-        _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, nprof, seed, 0, stream))
-        torch.cuda.synchronize()
-        n_launch, tot_ms = ctypes.c_int64(), ctypes.c_double()
-        _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
-        lib.dws_profile_disable()
-        avg_ms = tot_ms.value / max(n_launch.value, 1)
+        # every launch position of a step takes its MEDIAN over five eager steps (the first eager step after graph replays
+        # runs with cold caches and lazily created events: averaged in, it put this leg 1.5 % above the launch durations
+        # rocprof sees inside the timed replays)
+        NLAY = cfg["model"]["num_res_layers"]
+        nprof = 5
+        eager = lambda k: _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, k, seed, 0, stream))
+        step_ms = profiled_step_ms(lib, eager, b"wn_layer", nprof, NLAY)
+        n_launch = ctypes.c_int64(nprof * NLAY)
+        if step_ms is None:          # launch count differs from n_layers per step: fall back to the plain average
+            _lib.check(lib.dws_profile_enable(b"wn_layer"))
+            eager(nprof)
+            torch.cuda.synchronize()
+            tot_ms = ctypes.c_double()
+            _lib.check(lib.dws_profile_query(ctypes.byref(n_launch), ctypes.byref(tot_ms)))
+            lib.dws_profile_disable()
+            step_ms = tot_ms.value / max(n_launch.value, 1) * NLAY
+        avg_ms = step_ms / NLAY
         wino = args.precision == "f32" and os.environ.get("DWS_WN_DIRECT") is None
         # `achieved` / `frac` are priced on the flops the kernel EXECUTES (frac <= 1 by construction): the Winograd
         # F(2,3) form does 8 C^2 instead of 12 C^2 flop per position for the convolution.  The direct-convolution

@@ -96,14 +96,16 @@ def test_cauchy_mult_module_is_importable_by_its_reference_name():
 
 def test_bench_executed_flops_formula_matches_the_counter():
     """`bench.py: wino_executed_work` (tile counts x MFMAs per wave x 4096) against what the hardware counted for the same
-    launch (`SQ_INSTS_MFMA` per dispatch, profiles/r03_wavenet_traffic.json): the figure `roofline.frac` is priced on."""
+    launch (`SQ_INSTS_MFMA` per dispatch, the newest profiles/r*_wavenet_traffic.json): the figure `roofline.frac` is priced on."""
     import json
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    rec = json.load(open(os.path.join(root, "profiles", "r03_wavenet_traffic.json")))
+    import glob
+    rec = json.load(open(sorted(glob.glob(os.path.join(root, "profiles", "r*_wavenet_traffic.json")))[-1]))
+    assert rec["kernel"].startswith("wn_layer_wino_kernel")
     cfg = bench.CONFIGS["wnet_h256_d36_T200"]
     formula = bench.wino_executed_work(cfg)
     counted = rec["sq_insts_mfma_per_launch"] * 4096

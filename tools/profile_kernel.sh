@@ -9,8 +9,8 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 W=/tmp/prof_$TAG; rm -rf $W; mkdir -p $W
-CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra $*"
-CMD2="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra $*"
+CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-full-loop $*"
+CMD2="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra --no-full-loop $*"
 rocprofv3 --kernel-trace --stats -d $W/stats -o stats -- $CMD > $W/stats.log 2>&1
 python $R/tools/rocpd_summary.py stats $W/stats/stats_results.db > $OUT/${TAG}_kernel_stats.txt
 {

@@ -16,7 +16,7 @@ for what in "$@"; do
   esac
   python $R/bench.py $ARGS > /tmp/b_$what.log 2>&1; grep '^{' /tmp/b_$what.log | tail -1 > $OUT/${TAG}_bench_$what.json
   W=/tmp/prof_$what; rm -rf $W; mkdir -p $W
-  rocprofv3 --kernel-trace --stats -d $W/stats -o stats -- python $R/bench.py $ARGS --no-cpu-baseline > $W/stats.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $W/stats -o stats -- python $R/bench.py $ARGS --no-cpu-baseline --no-full-loop > $W/stats.log 2>&1
   python $R/tools/rocpd_summary.py stats $W/stats/stats_results.db | head -45 > $OUT/${TAG}_${what}_kernel_stats.txt
   rm -rf $W
 done

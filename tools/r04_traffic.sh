@@ -9,7 +9,7 @@ TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 W=/tmp/traffic_$TAG; rm -rf $W; mkdir -p $W
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra"
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra --no-full-loop"
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_MFMA; do
   rocprofv3 --pmc $C -d $W/$C -o p -- $CMD > $W/$C.log 2>&1
 done
@@ -22,7 +22,7 @@ def avg(counter):
                           "kernel_name like '%wn_layer_%' group by kernel_name order by count(*) desc", (counter,)))
     return rows[0]
 (kn, n, fetch), (_, _, write), (_, _, mfma) = avg("FETCH_SIZE"), avg("WRITE_SIZE"), avg("SQ_INSTS_MFMA")
-short = kn.split("dws::")[-1].split("(")[0].replace(" ", "")
+short = kn.split("dws::", 1)[1].split("(")[0].replace(" ", "")      # void dws::NAME<...>(dws::Args, ...) -> NAME<...>
 json.dump({"kernel": short, "dispatches": n,
            "source": "tools/r04_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_MFMA, separate passes, bench.py --steps 3",
            "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
