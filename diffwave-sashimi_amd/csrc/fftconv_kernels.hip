@@ -16,6 +16,8 @@
 // brings natural order back -- no reordering pass at all.
 // LDS rows are padded by one complex per 16 so both the strided and the 16-contiguous access
 // patterns are bank-conflict free for ds_read_b64 / ds_write_b64.
+#include <cstdlib>
+
 #include "fftconv.h"
 
 #include "fft_core.h"
@@ -555,7 +557,22 @@ static int launch_fc(const FftConvArgs& a, hipStream_t s) {
 template <int LOG2M>
 static int launch_fcorr(const FftCorrArgs& a, hipStream_t s) {
     using C = FcCfg<LOG2M>;
-    constexpr int TH = C::THREADS > 512 ? 512 : C::THREADS;
+    // M = 16384: one 16-point group per thread (1024 threads, 111 VGPRs with the packed FFT core and the bins of U parked
+    // in the output slab) -- rounds 2-3 ran two groups per thread on 512 threads there (the scalar core needed 256 VGPRs).
+    // DWS_FFTCORR_512=1 keeps that shape (A/B runs).
+    static const bool half = std::getenv("DWS_FFTCORR_512") != nullptr;
+    if (LOG2M >= 14 && half) {
+        constexpr int TH = C::THREADS > 512 ? 512 : C::THREADS;
+        auto kern = fftcorr_kernel<LOG2M, TH>;
+        static bool attr = false;
+        if (!attr) {
+            DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(a.H, ceil_div(a.B, a.bchunk)), dim3(TH), C::LDS, s, a);
+        return DWS_OK;
+    }
+    constexpr int TH = C::THREADS;
     auto kern = fftcorr_kernel<LOG2M, TH>;
     static bool attr = false;
     if (!attr) {

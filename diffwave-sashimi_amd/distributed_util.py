@@ -22,8 +22,10 @@ the reference's pattern:
   returns those views, autograd adopts them as ``p.grad`` without a copy, the hooks find
   the gradient already in place, and after the in-place all-reduce + division ``p.grad``
   IS the averaged gradient: no per-parameter ``torch.empty``, no copy into the bucket,
-  no copy back (round 3: 656 of each per step for SaShiMi).  Gradients that arrive in
-  their own storage (torch-autograd backbones, accumulated gradients) still take the
+  no copy back (round 3: 656 of each per step for SaShiMi).  Accumulating a further
+  backward into a gradient that already lives in the arena stays in place as well (the
+  engine hands the new gradient over in a fresh tensor, autograd adds it into the view);
+  gradients that live in their own storage (torch-autograd backbones) still take the
   copy-in / copy-back path.
 
 Backend "nccl" is RCCL on ROCm; the CPU tests use "gloo".
