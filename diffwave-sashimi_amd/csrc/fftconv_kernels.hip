@@ -213,6 +213,10 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
         const size_t off = ((size_t)b * a.H + h) * L;
         const c2* __restrict__ u2 = reinterpret_cast<const c2*>(a.u + off);
         fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid);
+        // (Round 4, measured and dropped: touching the NEXT row's input here -- one LDS-DMA dword per lane, 64 bytes apart, into a
+        // scratch slot, so that its top pass would find the points in L2 instead of paying the HBM round trip with all 16 waves
+        // waiting -- made the kernel SLOWER, 87.8 -> 94.5 us same box: vector-memory loads return in order, so the pointwise
+        // stage's K_f loads queue behind the prefetch and expose the very latency it was meant to hide.)
         pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
                                         a.kfs + (size_t)h * 3, tid, csign);
         __syncthreads();
@@ -538,7 +542,7 @@ static int cu_count() {
 }
 
 template <int LOG2M>
-static int launch_fc(const FftConvArgs& a, hipStream_t s) {
+static int launch_fc(const FftConvArgs& a_in, hipStream_t s) {
     using C = FcCfg<LOG2M>;
     auto kern = fftconv_kernel<LOG2M, C::THREADS>;
     static bool attr = false;
@@ -546,6 +550,7 @@ static int launch_fc(const FftConvArgs& a, hipStream_t s) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;
     }
+    const FftConvArgs& a = a_in;
     // one resident workgroup per LDS slot of every CU walks several rows (RowSchedule); small rows: one row per block
     const int rows = a.B * a.H;
     const int slots = cu_count() * std::max(1, std::min((int)(160 * 1024 / C::LDS), 2048 / C::THREADS));
