@@ -172,14 +172,22 @@ int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, f
 
 /* Debug/parity tap: copy an internal activation into `dst` (device pointer,
  * `capacity` floats).  WaveNet: "pre_final" = ReLU(final_conv[0](skip)) [B,S,L],
- * "skip" [B,S,L], "x" (last residual output) [B,C,L]. */
+ * "skip" [B,S,L], "x" (last residual output) [B,C,L]; the step-only terms: "part_t"
+ * [B, n_layers*C] / "abt" (per-clip rows of the last forward) and "tab_part_t"
+ * [T, n_layers*C] / "tab_abt" (the sampler's step table).  Both models:
+ * "sampler_eps" = the network output of the sampler's last reverse step [B,Cout,L]. */
 int dws_model_read_tap(dws_model* m, const char* tap, float* dst, int64_t capacity, void* stream);
 
 /* ------------------------------------------------------------------------
  * Reverse-diffusion sampler -- replaces `generate.sampling`
  * (`generate.py:23-55`).  One reverse step is captured as a hipGraph on first
  * use and replayed T times; step index, schedule coefficients and the RNG
- * counter live in device memory.
+ * counter live in device memory.  Everything of the network that depends on the
+ * diffusion step only (embedding, its MLP, every layer's fc_t projection) is
+ * evaluated once per (weights, T) for t = 0..T-1 and indexed by the device step
+ * counter inside the replays; the update x <- (x - c1 eps) / c2 (+ sigma z) rounds
+ * every product, difference, quotient and sum once, as the reference's op-by-op
+ * float32 evaluation does.
  *
  *   x          [B, C, L]  in: x_T (or anything when seed-driven, see below); out: x_0
  *   alpha, alpha_bar, sigma  HOST float[T] tables from calc_diffusion_hyperparams
