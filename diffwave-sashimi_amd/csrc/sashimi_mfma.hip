@@ -45,6 +45,9 @@ struct TailCfg {
 // A packed as pack[mt][kg][lane][4]; Bt in LDS row-major [K][P].
 // KGU: leave the k-group loop to hipcc's unroller (nkg is a constant at every call site: it unrolls fully and hoists
 // ring loads, +40..100 VGPRs but a little faster where the registers are there); !KGU pins it rolled (`unroll 1`).
+// (Round 4, measured and dropped: requesting the first ring entries of the NEXT slab before the epilogue that separates two
+// slabs -- a slab that fills its own ring starts with an L2 round trip in front of its first MFMA, six times per tile.  Same box:
+// H = 128 126.05 -> 126.1 us, H = 256 116.3 -> 117.2 us.  The partner workgroup's MFMAs already cover those waits.)
 template <int MT, int NT, int P, bool KGU>
 __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* __restrict__ A, int nkg_total,
                                           int kg0, int nkg, const int (&mt)[MT], const float* __restrict__ bt, int wn,
@@ -601,7 +604,9 @@ int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s) {
 //   MODE 1 (UpPool):   B operand row k is x[b, k, l]; out[b, o/p, l*p + o%p] (+ addend), p == 4:
 //                      a lane's 4 consecutive accumulator rows are the 4 j of one channel -> one float4 store
 // ---------------------------------------------------------------------------
-template <int MT, int MODE>
+// LN: the instance with the LayerNorm epilogue.  (At MT = 4 the accumulators alone are 128 registers and the epilogue's
+// statistics spill ~330 bytes; still 9 us cheaper than the plain instance + a LayerNorm launch: 76.8 vs 69.3 + 16.5 us.)
+template <int MT, int MODE, bool LN>
 __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
     constexpr int P = 64, NT = 2, KC = 64;
     __shared__ __attribute__((aligned(16))) float lds[2 * KC * P];
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
     // a lane holds 16 MT rows of NT columns; MODE 1 interleaves four output positions (j = row & 3) per GEMM column, each
     // with its own statistics over the M/4 channels
     constexpr int NJ = MODE == 0 ? 1 : 4;
-    const bool ln = a.ln_y != nullptr;      // (uniform; the launcher only sets it when this workgroup owns all M rows)
+    const bool ln = LN && a.ln_y != nullptr;      // (uniform; the launcher only sets it when this workgroup owns all M rows)
     float lnscale[NT][NJ], lnshift[NT][NJ];
     if (ln) {
         float* red = lds;                   // [4 waves][64 columns][NJ]: the staging buffers are free after the last barrier
@@ -822,9 +827,16 @@ static int launch_pw_mode(const PwMfmaArgs& a, hipStream_t s) {
     DWS_CHECK(a.ln_y == nullptr || pw_mfma_ln_supported(a.M), DWS_ERR_INVALID,
               "pw_mfma: the LayerNorm epilogue needs all %d rows in one workgroup", a.M);
     const int grid = a.B * ceil_div(a.L, 64);
-    if (a.M == 128) hipLaunchKernelGGL((pw_mfma_kernel<1, MODE>), dim3(grid), dim3(256), 0, s, a);
-    else if (a.M == 256) hipLaunchKernelGGL((pw_mfma_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((pw_mfma_kernel<4, MODE>), dim3(grid, a.M / 512), dim3(256), 0, s, a);
+#define DWS_PW(MTV)                                                                                                 \
+    do {                                                                                                            \
+        const dim3 g(grid, (MTV) == 4 ? a.M / 512 : 1);                                                              \
+        if (a.ln_y) hipLaunchKernelGGL((pw_mfma_kernel<MTV, MODE, true>), g, dim3(256), 0, s, a);                    \
+        else hipLaunchKernelGGL((pw_mfma_kernel<MTV, MODE, false>), g, dim3(256), 0, s, a);                          \
+    } while (0)
+    if (a.M == 128) DWS_PW(1);
+    else if (a.M == 256) DWS_PW(2);
+    else DWS_PW(4);
+#undef DWS_PW
     return DWS_OK;
 }
 
