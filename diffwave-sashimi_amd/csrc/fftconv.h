@@ -21,8 +21,6 @@ struct FftConvArgs {
     float* pre;         // also store the pre-activation conv + D u
     int conj_k;         // multiply by conj(K_f): the adjoint (correlation) of the convolution
     int no_act;         // g = conv + D u without the GELU
-    int skew;           // experiment (DWS_FFT_SKEW=n): wave-local passes without workgroup barriers, waves 8..15 start them
-                        // n x 64 cycles late
 };
 
 // dK_f partials of the convolution's kernel gradient: part[bs][h][k] = sum_{b in chunk bs} conj(U_b[k]) * dA_b[k],

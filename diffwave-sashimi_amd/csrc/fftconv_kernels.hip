@@ -34,20 +34,7 @@ __device__ __forceinline__ int brev(int k, int bits) { return brev_bits(k, bits)
 // cycles at 2.7 cycles each) plus the LDS write path (~35 %), not by waves waiting for each other.)
 // Forward passes P0 .. of the plan on an LDS-resident row (a barrier after each).  A thread owns the NG groups
 // g = tid + i*THREADS, THREADS = M/16/NG.
-// Between two passes: a workgroup barrier, or -- LOCAL, when the pass just done AND the next one stay inside a wave's own
-// 1024-point block (bits [b, b+4) with b + 4 <= 10: 64 threads x 16 points) -- nothing but a compiler fence: a wave's LDS
-// instructions execute in order.
-template <bool LOCAL>
-__device__ __forceinline__ void pass_sync() {
-    if constexpr (LOCAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    else __syncthreads();
-}
-__device__ __forceinline__ void skew_delay(int n, int tid) {
-    if (tid >= 512)
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-}
-
-template <int LOG2M, int NG, int P0, bool SK = false>
+template <int LOG2M, int NG, int P0>
 __device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ tw, const FftTw<LOG2M, NG>& W, int tid) {
     using P = FftPlan<LOG2M>;
     constexpr int THREADS = (P::M / 16) / NG;
@@ -58,10 +45,8 @@ __device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ t
             pass16_lds<LOG2M, P::b0(P0), false>(X, FftTw<LOG2M, NG>::template phi<P::b0(P0)>(tw, opaque(tid) + i * THREADS),
                                                 tid + i * THREADS);
         }
-        // this pass and the next one wave-local (and a next one exists): no workgroup barrier between them
-        constexpr bool more = (P0 + 1 < P::N16) || P::TAIL4;
-        pass_sync<SK && NG == 1 && more && (P::b0(P0) + 4 <= 10)>();
-        fft_forward_from<LOG2M, NG, P0 + 1, SK>(X, tw, W, tid);
+        __syncthreads();
+        fft_forward_from<LOG2M, NG, P0 + 1>(X, tw, W, tid);
     } else if constexpr (P::TAIL4) {
 #pragma unroll
         for (int i = 0; i < NG; ++i)
@@ -71,7 +56,7 @@ __device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ t
 }
 
 // Inverse passes in mirrored order down to (and including) radix-16 pass P0.
-template <int LOG2M, int NG, int P0, int PCUR, bool SK = false>
+template <int LOG2M, int NG, int P0, int PCUR>
 __device__ __forceinline__ void fft_inverse_passes(c2* X, const FftTw<LOG2M, NG>& W, int tid) {
     constexpr int THREADS = (FftPlan<LOG2M>::M / 16) / NG;
     if constexpr (PCUR > P0) {
@@ -80,23 +65,21 @@ __device__ __forceinline__ void fft_inverse_passes(c2* X, const FftTw<LOG2M, NG>
             if (i) __builtin_amdgcn_sched_barrier(0);
             pass16_lds<LOG2M, FftPlan<LOG2M>::b0(PCUR - 1), true>(X, W.theta[PCUR - 1][i], tid + i * THREADS);
         }
-        // the NEXT inverse pass (bits b0(PCUR - 2) .. +4) still wave-local, and it runs inside this call chain: no barrier
-        constexpr bool next_local = (PCUR - 1 > P0) && (FftPlan<LOG2M>::b0(PCUR - 2 >= 0 ? PCUR - 2 : 0) + 4 <= 10);
-        pass_sync<SK && NG == 1 && next_local>();
-        fft_inverse_passes<LOG2M, NG, P0, PCUR - 1, SK>(X, W, tid);
+        __syncthreads();
+        fft_inverse_passes<LOG2M, NG, P0, PCUR - 1>(X, W, tid);
     }
 }
 
-template <int LOG2M, int NG, int P0, bool SK = false>
+template <int LOG2M, int NG, int P0>
 __device__ __forceinline__ void fft_inverse_to(c2* X, const FftTw<LOG2M, NG>& W, int tid) {
     using P = FftPlan<LOG2M>;
     constexpr int THREADS = (P::M / 16) / NG;
     if constexpr (P::TAIL4) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) pass4_lds<true>(X, mk(1.f, 0.f), tid + i * THREADS);
-        pass_sync<SK && NG == 1 && (P::N16 > P0) && (P::b0(P::N16 - 1) + 4 <= 10)>();
+        __syncthreads();
     }
-    fft_inverse_passes<LOG2M, NG, P0, P::N16, SK>(X, W, tid);
+    fft_inverse_passes<LOG2M, NG, P0, P::N16>(X, W, tid);
 }
 
 // Whole transforms of an LDS-resident row; the caller has synchronised after filling X.
@@ -124,9 +107,9 @@ __device__ __forceinline__ void fft_inverse(c2* X, const c2* tw, const FftTw<LOG
 // the rest of the M-point row is zero.  Even sizes: the top radix-16 pass runs on registers (a thread's 16 points are
 // g + (M/16) r, of which r >= 8 are padding and never loaded) and only its result goes to LDS; odd sizes stage the row
 // in LDS first.  The caller must have passed a barrier since the last read of X.
-template <int LOG2M, int NG, bool SK = false>
+template <int LOG2M, int NG>
 __device__ __forceinline__ void fft_forward_global(c2* X, const c2* __restrict__ src, int n_valid, const c2* tw,
-                                                   const FftTw<LOG2M, NG>& W, int tid, int skew = 0) {
+                                                   const FftTw<LOG2M, NG>& W, int tid) {
     constexpr int M = 1 << LOG2M, G = M / 16, THREADS = G / NG;
     if constexpr (!FftPlan<LOG2M>::ODD) {
 #pragma unroll
@@ -143,8 +126,7 @@ __device__ __forceinline__ void fft_forward_global(c2* X, const c2* __restrict__
             for (int r = 0; r < 16; ++r) X[pidx(g + G * r)] = x[r];
         }
         __syncthreads();
-        if (SK) skew_delay(skew, tid);
-        fft_forward_from<LOG2M, NG, 1, SK>(X, tw, W, tid);
+        fft_forward_from<LOG2M, NG, 1>(X, tw, W, tid);
     } else {
         for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < n_valid) ? src[j] : mk(0.f, 0.f);
         __syncthreads();
@@ -212,7 +194,6 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     using P = FftPlan<LOG2M>;
     constexpr int M = 1 << LOG2M;
     constexpr bool DIRECT = !P::ODD;
-    constexpr bool SK = LOG2M == 14 && THREADS == 1024;     // wave-local passes without workgroup barriers (+ optional skew)
     extern __shared__ __attribute__((aligned(16))) c2 X[];  // M + M/16 complex
     const int tid = threadIdx.x;
     const int L = a.L, Lc = L / 2;  // L even
@@ -231,7 +212,7 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
         const int h = row / a.B, b = row % a.B;
         const size_t off = ((size_t)b * a.H + h) * L;
         const c2* __restrict__ u2 = reinterpret_cast<const c2*>(a.u + off);
-        fft_forward_global<LOG2M, NG, SK>(X, u2, Lc, a.tw, W, tid, a.skew);
+        fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid);
         // (Round 4, measured and dropped: touching the NEXT row's input here -- one LDS-DMA dword per lane, 64 bytes apart, into a
         // scratch slot, so that its top pass would find the points in L2 instead of paying the HBM round trip with all 16 waves
         // waiting -- made the kernel SLOWER, 87.8 -> 94.5 us same box: vector-memory loads return in order, so the pointwise
@@ -248,8 +229,7 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
             g2[j] = a.no_act ? v : mk(gelu_f(v.x), gelu_f(v.y));
         };
         if constexpr (DIRECT) {
-            if (SK) skew_delay(a.skew, tid);
-            fft_inverse_to<LOG2M, NG, 1, SK>(X, W, tid);
+            fft_inverse_to<LOG2M, NG, 1>(X, W, tid);
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 if (i) __builtin_amdgcn_sched_barrier(0);
@@ -570,9 +550,7 @@ static int launch_fc(const FftConvArgs& a_in, hipStream_t s) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;
     }
-    static const int skew = std::getenv("DWS_FFT_SKEW") ? atoi(std::getenv("DWS_FFT_SKEW")) : 0;
-    FftConvArgs a = a_in;
-    a.skew = skew;
+    const FftConvArgs& a = a_in;
     // one resident workgroup per LDS slot of every CU walks several rows (RowSchedule); small rows: one row per block
     const int rows = a.B * a.H;
     const int slots = cu_count() * std::max(1, std::min((int)(160 * 1024 / C::LDS), 2048 / C::THREADS));
