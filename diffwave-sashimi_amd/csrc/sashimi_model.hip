@@ -844,7 +844,7 @@ struct SashimiModel : dws_model {
         std::vector<SLayer*> order(d_layers);
         order.insert(order.end(), c_layers.begin(), c_layers.end());
         order.insert(order.end(), u_layers.begin(), u_layers.end());
-        static const bool ln_fusion = getenv("DWS_SASHIMI_NO_LN_FUSION") == nullptr;
+        const bool ln_fusion = getenv("DWS_SASHIMI_NO_LN_FUSION") == nullptr;   // (read per call: tests switch it inside one process)
         // the first block's LN1 + step embedding comes out of the init-conv pass when that block runs a fused convolution
         // (which reads the stage's y buffer); otherwise the block's own LayerNorm launch does it
         SLayer* first = order.empty() ? nullptr : order[0];

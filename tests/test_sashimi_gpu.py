@@ -213,8 +213,10 @@ def test_segmented_long_rows_agree_with_the_rocfft_path(gpu):
 
 @pytest.mark.parametrize("name", ["ss_d64_short", "ss_d128_short"])
 def test_fused_next_block_layernorm_agrees_with_the_separate_pass(gpu, name):
-    """A block's tail kernel also writes the next block's S4 input (LN1 + step embedding, `sashimi.py:148-152`) when
-    both sit on one stage; DWS_SASHIMI_NO_LN_FUSION=1 runs the separate LayerNorm pass instead.  Same weights, both ways."""
+    """Every LayerNorm of a forward comes out of its producer's epilogue: a block's tail kernel writes the next block's S4
+    input (LN1 + step embedding, `sashimi.py:148-152`) when both sit on one stage, the init conv and the pooling GEMMs
+    write the first block's of their stage, the last tail the network's final norm; DWS_SASHIMI_NO_LN_FUSION=1 runs the
+    separate LayerNorm passes instead.  Same weights, both ways."""
     import os
     cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES[name]
     net = cases.build_ours(cfg, wseed).to(gpu)
