@@ -129,6 +129,15 @@ DWS_HD c2 cmulk(c2 a, c2 k) {
 }
 // s * a for a real scalar s held in the LOW half of `s2`
 DWS_HD c2 cscale(c2 a, c2 s2) { c2 r; DWS_PK2("v_pk_mul_f32", "op_sel_hi:[0,1]", r, s2, a); return r; }
+// a + conj(b), a - conj(b)
+DWS_HD c2 cadd_conj(c2 a, c2 b) { c2 r; DWS_PK2("v_pk_add_f32", "neg_hi:[0,1]", r, a, b); return r; }
+DWS_HD c2 csub_conj(c2 a, c2 b) { c2 r; DWS_PK2("v_pk_add_f32", "neg_lo:[0,1]", r, a, b); return r; }
+// conj(2 a - x0)
+DWS_HD c2 cmirror_conj(c2 a, c2 x0) {
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(x0));
+    return r;
+}
 #undef DWS_PK3
 #undef DWS_PK2
 #undef DWS_PK3S
@@ -151,6 +160,9 @@ DWS_HD c2 cmul_(c2 a, c2 w) { return mk(fmaf(w.y, -a.y, w.x * a.x), fmaf(w.y, a.
 DWS_HD c2 cmulc(c2 a, c2 w) { return mk(fmaf(w.y, a.y, w.x * a.x), fmaf(w.y, -a.x, w.x * a.y)); }
 DWS_HD c2 cmulk(c2 a, c2 k) { return cmul_(a, k); }
 DWS_HD c2 cscale(c2 a, c2 s2) { return mk(s2.x * a.x, s2.x * a.y); }
+DWS_HD c2 cadd_conj(c2 a, c2 b) { return mk(a.x + b.x, a.y - b.y); }
+DWS_HD c2 csub_conj(c2 a, c2 b) { return mk(a.x - b.x, a.y + b.y); }
+DWS_HD c2 cmirror_conj(c2 a, c2 x0) { return mk(fmaf(a.x, 2.f, -x0.x), fmaf(-a.y, 2.f, x0.y)); }
 #endif
 
 DWS_HD c2 csqr(c2 a) { return cmul_(a, a); }
@@ -184,6 +196,13 @@ DWS_HD c2 opaque(c2 v) {
     asm volatile("" : "+v"(v));
 #endif
     return v;
+}
+
+// nothing moves across this point in the instruction schedule (device code)
+DWS_HD void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 DWS_HD int opaque(int v) {
@@ -323,6 +342,12 @@ struct FftTw {
             }
         }
     }
+    // theta[p] of group g fetched at its use instead of held (a kernel at its register limit)
+    template <int PASS>
+    static DWS_HD c2 theta_at(const c2* __restrict__ tw, int g) {
+        constexpr int b = P::b0(PASS);
+        return (b == 0) ? mk(1.f, 0.f) : tw[(g & ((1 << b) - 1)) * (P::M >> (b + 4))];
+    }
     template <int B0>
     static DWS_HD c2 phi(const c2* __restrict__ tw, int g) {
         return !P::tw_fwd(B0) ? mk(1.f, 0.f) : tw[brev_bits(g >> B0, LOG2M - 4 - B0) << B0];
@@ -341,13 +366,15 @@ template <int LOG2M, int B0, bool INV>
 DWS_HD void pass16_lds(c2* __restrict__ X, c2 tau, int g) {
     constexpr int S = 1 << B0;
     constexpr bool TW = INV ? FftPlan<LOG2M>::tw_inv(B0) : FftPlan<LOG2M>::tw_fwd(B0);
-    const int base = group_base<B0>(g);
+    // pidx(base + r S) = pidx(base) + r S + (r S >> 4): the group's bits [B0, B0+4) of `base` are clear, so adding r S never
+    // carries into or out of the low four bits -- ONE address register per pass, the points at immediate offsets
+    const int pb = pidx(group_base<B0>(g));
     c2 x[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = X[pidx(base + r * S)];
+    for (int r = 0; r < 16; ++r) x[r] = X[pb + r * S + ((r * S) >> 4)];
     fft16<INV, TW>(x, tau);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) X[pidx(base + r * S)] = x[r];
+    for (int r = 0; r < 16; ++r) X[pb + r * S + ((r * S) >> 4)] = x[r];
 }
 
 // Final (forward; tau = psi) / first (inverse; unit twiddles) radix-4 pass over bits [0, 2): thread g owns points
@@ -395,6 +422,28 @@ DWS_HD void pointwise_pair(c2& zk_io, c2& zm_io, c2 wk, c2 ka, c2 kb, float csig
     zm_io = cconj(csub(ye, iyo));
 }
 
+// The same pair on packed arithmetic, result scaled by FOUR (the two halvings of pointwise_pair are exact and commute with
+// every rounding: they move into the caller's 1/M): 14 packed instructions + 2 multiplies against ~45 scalar ones.
+//   s = Zk + conj Zm, d = Zk - conj Zm;  2 A[k] = s + Wk (-i d),  2 conj A[M-k] = u = 2 s - 2 A[k]
+//   Yk = 2 A[k] K1,  v = u conj(K2) = 2 conj(Y[M-k]);  ye = Yk + v, e = Yk - v
+//   4 Zy[k] = ye + conj(Wk) (i e),  4 Zy[M-k] = conj(2 ye - 4 Zy[k])
+DWS_HD void pointwise_pair4(c2& zk_io, c2& zm_io, c2 wk, c2 ka, c2 kb, float csign) {
+    const c2 s = cadd_conj(zk_io, zm_io), d = csub_conj(zk_io, zm_io);
+    const c2 ak = cfma<false, 1>(s, wk, d);
+    const c2 u = cmirror(s, ak);
+    const c2 yk = cmul_(ak, mk(ka.x, csign * ka.y)), v = cmulc(u, mk(kb.x, csign * kb.y));
+    const c2 ye = cadd(yk, v), e = csub(yk, v);
+    const c2 zk = cfma<true, 1>(ye, wk, e);
+    zk_io = zk;
+    zm_io = cmirror_conj(ye, zk);
+}
+DWS_HD void pointwise_self4(c2& z0, c2& z1, c2 kf0, c2 kfM, c2 kfh, float csign) {
+    const float y0 = (z0.x + z0.y) * kf0.x, ym = (z0.x - z0.y) * kfM.x;
+    z0 = mk(2.f * (y0 + ym), 2.f * (y0 - ym));
+    const c2 t = cmulc(z1, mk(kfh.x, csign * kfh.y));
+    z1 = mk(4.f * t.x, 4.f * t.y);
+}
+
 // The two halves of pointwise_pair on their own (kernels that accumulate several spectra between them):
 // bins A[k], A[M-k] of the real row from the packed spectrum, and the packed form of a real-row spectrum Y[k], Y[M-k].
 DWS_HD void pair_bins(c2 zk, c2 zm, c2 wk, c2& ak, c2& am) {
@@ -418,6 +467,128 @@ DWS_HD void pointwise_self(c2& z0, c2& z1, c2 kf0, c2 kfM, c2 kfh, float csign) 
     const float ym = (z0.x - z0.y) * kfM.x;   // A[M] = Re - Im
     z0 = mk(0.5f * (y0 + ym), 0.5f * (y0 - ym));
     z1 = cmulc(z1, mk(kfh.x, csign * kfh.y));  // Zy[M/2] = Z[M/2] * conj(Kf[M/2])
+}
+
+
+// ---- fused tail: forward radix-4 tail + pointwise stage + inverse radix-4 tail in ONE LDS round trip ---------------
+// (plans with TAIL4: the separate sequence reads and writes every point three times -- tail pass, pair stage, tail pass --
+// with two barriers between them.)
+// The pair stage couples frequency k with M - k.  In the bit-reversed layout a block of 16 contiguous positions 16 t ..
+// 16 t + 15 holds the frequencies kb + (r0 M/2 + r1 M/4 + r2 M/8 + r3 M/16), kb = rev(t) < M/16, and their partners are
+//   M - k = (M/16 - kb) + ((1 - r0) M/2 + (1 - r1) M/4 + (1 - r2) M/8 + (1 - r3) M/16)          (kb != 0)
+// i.e. position 15 - r of the block whose base frequency is M/16 - kb.  Negating a frequency complements, in the
+// reversed index, every bit below the highest set one: that block is t' = 3 msb(t) - 1 - t (t and t' mirror each other
+// inside the octave [msb, 2 msb); t = 1 is its own mirror).  So thread t takes the r3 = 0 half of block t and the r3 = 1
+// half of block t' -- 16 points, x[0..7] and x[8..15], the same index bits as a whole block -- and holds all eight pairs
+// (x[e], x[15 - e]), e even, with the tables' pair index q = position / 2 = 8 t + e/2 (e < 8), 8 t' + e/2 (e >= 8); thread t'
+// takes the other two halves.  Block 0 (kb = 0) pairs inside itself in a different pattern (k = 0 and M/2 are their own
+// partners, group M/8 mirrors itself, groups M/16 and 3M/16 each other): thread 0 takes the whole block and routes its
+// odd positions into the generic slots for the pair stage.
+// The radix-4 butterflies only couple positions inside a group of four, so the two halves transform independently, each
+// with its block's tail twiddle; the arithmetic per point is exactly that of pass4_lds / pointwise_pair / pass4_lds.
+DWS_HD int mirror_block(int t) {
+    if (t == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int msb = 1 << (31 - __clz(t));
+#else
+    int msb = 1;
+    while (2 * msb <= t) msb *= 2;
+#endif
+    return 3 * msb - 1 - t;
+}
+
+// forward tail stage BIT (1, then 0) on x[0..7] (twiddles of tl) and x[8..15] (twiddles of th): stage16<false, true, BIT>
+// with the table chosen by the half
+template <int BIT>
+DWS_HD void stage16_fwd_halves(c2 (&x)[16], const Tw16<true>& tl, const Tw16<true>& th) {
+    static_assert(BIT == 0 || BIT == 1, "tail stages");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i & (1 << BIT)) continue;
+        const int j = i + (1 << BIT);
+        const int hi = i >> (BIT + 1), nb = 3 - BIT;
+        int rv = 0;
+        for (int q = 0; q < nb; ++q) rv |= ((hi >> q) & 1) << (nb - 1 - q);
+        const int e = rv << BIT, rot = e >> 2, sel = e & 3;
+        const Tw16<true>& t = (i & 8) ? th : tl;
+        const c2 w = BIT == 1 ? t.T2[sel >> 1] : t.T1[sel];
+        if (rot) bfly<false, 1, false, false>(x[i], x[j], w);
+        else bfly<false, 0, false, false>(x[i], x[j], w);
+    }
+}
+
+// X4: the packed pair arithmetic, the row comes out scaled by four (pointwise_pair4).
+template <int LOG2M, bool X4 = false>
+DWS_HD void pass_tail_pointwise(c2* __restrict__ X, const c2* __restrict__ tw, const c2* __restrict__ twp,
+                                const c2* __restrict__ kfa, const c2* __restrict__ kfb, const c2* __restrict__ kfs, int t,
+                                float csign) {
+    static_assert(FftPlan<LOG2M>::TAIL4, "plans that end in a radix-4 pass");
+    const int tm = mirror_block(t);
+    // the tables of the four pairs whose even position lies in block t first: their L2 round trip runs under the LDS reads
+    // and the tail butterflies; the other four (block t') are requested once the butterflies are done and arrive under
+    // the first four pairs' arithmetic (all eight at once cost 24 more live registers: spills at 1024 threads)
+    c2 wk[4], ka[4], kb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wk[i] = twp[8 * t + i];
+        ka[i] = kfa[8 * t + i];
+        kb[i] = kfb[8 * t + i];
+    }
+    const c2 taul = tw[brev_bits(t, LOG2M - 4)], tauh = tw[brev_bits(tm, LOG2M - 4)];
+    c2 x[16];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) x[d] = X[17 * t + d];            // pidx(16 t + d) = 17 t + d
+#pragma unroll
+    for (int d = 8; d < 16; ++d) x[d] = X[17 * tm + d];
+    {
+        const Tw16<true> tl(opaque(taul)), th(opaque(tauh));
+        stage16_fwd_halves<1>(x, tl, th);
+        stage16_fwd_halves<0>(x, tl, th);
+    }
+    sched_fence();
+    c2 wk2[4], ka2[4], kb2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wk2[i] = twp[8 * tm + 4 + i];
+        ka2[i] = kfa[8 * tm + 4 + i];
+        kb2[i] = kfb[8 * tm + 4 + i];
+    }
+    if (t == 0) {   // block 0: partners of 2, 4, 6, 8, 10, 12, 14 are 3, 7, 5, 15, 13, 11, 9; generic slot of e is 15 - e
+        const c2 x1 = x[1], x3 = x[3], x5 = x[5], x7 = x[7], x9 = x[9], x11 = x[11], x13 = x[13], x15 = x[15];
+        x[15] = x1; x[13] = x3; x[11] = x7; x[9] = x5; x[7] = x15; x[5] = x13; x[3] = x11; x[1] = x9;
+    }
+#pragma unroll
+    for (int e = 2; e < 8; e += 2) {
+        if (X4) pointwise_pair4(x[e], x[15 - e], wk[e / 2], ka[e / 2], kb[e / 2], csign);
+        else pointwise_pair(x[e], x[15 - e], wk[e / 2], ka[e / 2], kb[e / 2], csign);
+    }
+    {
+        c2 a = x[0], b = x[15];
+        if (X4) pointwise_pair4(a, b, wk[0], ka[0], kb[0], csign);
+        else pointwise_pair(a, b, wk[0], ka[0], kb[0], csign);
+        if (t == 0) {   // k = 0 and k = M/2 are their own partners
+            if (X4) pointwise_self4(x[0], x[15], kfs[0], kfs[1], kfs[2], csign);
+            else pointwise_self(x[0], x[15], kfs[0], kfs[1], kfs[2], csign);
+        } else {
+            x[0] = a;
+            x[15] = b;
+        }
+    }
+    sched_fence();
+#pragma unroll
+    for (int e = 8; e < 16; e += 2) {
+        if (X4) pointwise_pair4(x[e], x[15 - e], wk2[e / 2 - 4], ka2[e / 2 - 4], kb2[e / 2 - 4], csign);
+        else pointwise_pair(x[e], x[15 - e], wk2[e / 2 - 4], ka2[e / 2 - 4], kb2[e / 2 - 4], csign);
+    }
+    if (t == 0) {
+        const c2 n1 = x[1], n3 = x[3], n5 = x[5], n7 = x[7], n9 = x[9], n11 = x[11], n13 = x[13], n15 = x[15];
+        x[1] = n15; x[3] = n13; x[7] = n11; x[5] = n9; x[15] = n7; x[13] = n5; x[11] = n3; x[9] = n1;
+    }
+    fft16<true, false, false, false, true>(x, mk(1.f, 0.f));     // inverse tail: unit base twiddle in every block
+#pragma unroll
+    for (int d = 0; d < 8; ++d) X[17 * t + d] = x[d];
+#pragma unroll
+    for (int d = 8; d < 16; ++d) X[17 * tm + d] = x[d];
 }
 
 }  // namespace dws

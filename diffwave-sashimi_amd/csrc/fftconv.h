@@ -21,6 +21,7 @@ struct FftConvArgs {
     float* pre;         // also store the pre-activation conv + D u
     int conj_k;         // multiply by conj(K_f): the adjoint (correlation) of the convolution
     int no_act;         // g = conv + D u without the GELU
+    unsigned long long* trace;   // DWS_FFT_TRACE=1 only: s_memtime stamps [workgroup][wave][row][slot] (fftconv_kernels.hip)
 };
 
 // dK_f partials of the convolution's kernel gradient: part[bs][h][k] = sum_{b in chunk bs} conj(U_b[k]) * dA_b[k],

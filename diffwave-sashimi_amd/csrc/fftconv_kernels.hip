@@ -16,7 +16,10 @@
 // brings natural order back -- no reordering pass at all.
 // LDS rows are padded by one complex per 16 so both the strided and the 16-contiguous access
 // patterns are bank-conflict free for ds_read_b64 / ds_write_b64.
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <vector>
 
 #include "fftconv.h"
 
@@ -32,10 +35,34 @@ __device__ __forceinline__ int brev(int k, int bits) { return brev_bits(k, bits)
 // replaced by a wavefront-scope fence (4 of the 9 barriers per row at M = 16384).  All parity tests stay green and the time
 // does not move: 86.4 vs 86.7 us.  The row is bound by its 2660 VALU instructions per wave (43.6 M per launch, ~56 % of the
 // cycles at 2.7 cycles each) plus the LDS write path (~35 %), not by waves waiting for each other.)
+// Phase stamps (DWS_FFT_TRACE=1: `fftconv_kernel<.., TRACE = true>`): the pass drivers below call st() after each
+// barrier-closed phase; the product instances get NoStamp, which compiles to nothing.
+struct NoStamp {
+    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void loads_landed() const {}
+};
+constexpr int FFT_TRACE_SLOTS = 16, FFT_TRACE_ROWS = 4;
+struct WaveStamp {
+    unsigned long long* slot;   // this wave's [FFT_TRACE_ROWS][FFT_TRACE_SLOTS]; null beyond the traced rows
+    int k;
+    bool lane0;
+    __device__ __forceinline__ void operator()() {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (slot && lane0 && k < FFT_TRACE_SLOTS) slot[k] = t;
+        ++k;
+    }
+    __device__ __forceinline__ void loads_landed() {   // the top pass's global loads: wait for them, then stamp
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (*this)();
+    }
+};
+
 // Forward passes P0 .. of the plan on an LDS-resident row (a barrier after each).  A thread owns the NG groups
 // g = tid + i*THREADS, THREADS = M/16/NG.
-template <int LOG2M, int NG, int P0>
-__device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ tw, const FftTw<LOG2M, NG>& W, int tid) {
+// TAIL = false: stop before the radix-4 tail (the caller runs it fused with the pair stage: pass_tail_pointwise).
+template <int LOG2M, int NG, int P0, bool TAIL = true, class ST = NoStamp>
+__device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ tw, const FftTw<LOG2M, NG>& W, int tid,
+                                                 ST&& st = ST()) {
     using P = FftPlan<LOG2M>;
     constexpr int THREADS = (P::M / 16) / NG;
     if constexpr (P0 < P::N16) {
@@ -46,40 +73,50 @@ __device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ t
                                                 tid + i * THREADS);
         }
         __syncthreads();
-        fft_forward_from<LOG2M, NG, P0 + 1>(X, tw, W, tid);
-    } else if constexpr (P::TAIL4) {
+        st();
+        fft_forward_from<LOG2M, NG, P0 + 1, TAIL>(X, tw, W, tid, st);
+    } else if constexpr (P::TAIL4 && TAIL) {
 #pragma unroll
         for (int i = 0; i < NG; ++i)
             pass4_lds<false>(X, FftTw<LOG2M, NG>::tail_twiddle(tw, opaque(tid) + i * THREADS), tid + i * THREADS);
         __syncthreads();
+        st();
     }
 }
 
-// Inverse passes in mirrored order down to (and including) radix-16 pass P0.
-template <int LOG2M, int NG, int P0, int PCUR>
-__device__ __forceinline__ void fft_inverse_passes(c2* X, const FftTw<LOG2M, NG>& W, int tid) {
+// Inverse passes in mirrored order down to (and including) radix-16 pass P0.  FETCH: the base twiddles are fetched from
+// `tw` where they are used (an L2 hit per pass) instead of read from W -- a kernel at its register limit does not hold W.
+template <int LOG2M, int NG, int P0, int PCUR, bool FETCH = false, class ST = NoStamp>
+__device__ __forceinline__ void fft_inverse_passes(c2* X, const FftTw<LOG2M, NG>& W, int tid, ST&& st = ST(),
+                                                   const c2* __restrict__ tw = nullptr) {
     constexpr int THREADS = (FftPlan<LOG2M>::M / 16) / NG;
     if constexpr (PCUR > P0) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             if (i) __builtin_amdgcn_sched_barrier(0);
-            pass16_lds<LOG2M, FftPlan<LOG2M>::b0(PCUR - 1), true>(X, W.theta[PCUR - 1][i], tid + i * THREADS);
+            c2 th;
+            if constexpr (FETCH) th = FftTw<LOG2M, NG>::template theta_at<PCUR - 1>(tw, opaque(tid) + i * THREADS);
+            else th = W.theta[PCUR - 1][i];
+            pass16_lds<LOG2M, FftPlan<LOG2M>::b0(PCUR - 1), true>(X, th, tid + i * THREADS);
         }
         __syncthreads();
-        fft_inverse_passes<LOG2M, NG, P0, PCUR - 1>(X, W, tid);
+        st();
+        fft_inverse_passes<LOG2M, NG, P0, PCUR - 1, FETCH>(X, W, tid, st, tw);
     }
 }
 
-template <int LOG2M, int NG, int P0>
-__device__ __forceinline__ void fft_inverse_to(c2* X, const FftTw<LOG2M, NG>& W, int tid) {
+template <int LOG2M, int NG, int P0, bool TAIL = true, bool FETCH = false, class ST = NoStamp>
+__device__ __forceinline__ void fft_inverse_to(c2* X, const FftTw<LOG2M, NG>& W, int tid, ST&& st = ST(),
+                                               const c2* __restrict__ tw = nullptr) {
     using P = FftPlan<LOG2M>;
     constexpr int THREADS = (P::M / 16) / NG;
-    if constexpr (P::TAIL4) {
+    if constexpr (P::TAIL4 && TAIL) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) pass4_lds<true>(X, mk(1.f, 0.f), tid + i * THREADS);
         __syncthreads();
+        st();
     }
-    fft_inverse_passes<LOG2M, NG, P0, P::N16>(X, W, tid);
+    fft_inverse_passes<LOG2M, NG, P0, P::N16, FETCH>(X, W, tid, st, tw);
 }
 
 // Whole transforms of an LDS-resident row; the caller has synchronised after filling X.
@@ -107,9 +144,9 @@ __device__ __forceinline__ void fft_inverse(c2* X, const c2* tw, const FftTw<LOG
 // the rest of the M-point row is zero.  Even sizes: the top radix-16 pass runs on registers (a thread's 16 points are
 // g + (M/16) r, of which r >= 8 are padding and never loaded) and only its result goes to LDS; odd sizes stage the row
 // in LDS first.  The caller must have passed a barrier since the last read of X.
-template <int LOG2M, int NG>
+template <int LOG2M, int NG, bool TAIL = true, class ST = NoStamp>
 __device__ __forceinline__ void fft_forward_global(c2* X, const c2* __restrict__ src, int n_valid, const c2* tw,
-                                                   const FftTw<LOG2M, NG>& W, int tid) {
+                                                   const FftTw<LOG2M, NG>& W, int tid, ST&& st = ST()) {
     constexpr int M = 1 << LOG2M, G = M / 16, THREADS = G / NG;
     if constexpr (!FftPlan<LOG2M>::ODD) {
 #pragma unroll
@@ -121,20 +158,24 @@ __device__ __forceinline__ void fft_forward_global(c2* X, const c2* __restrict__
             for (int r = 0; r < 8; ++r) x[r] = (g + G * r < n_valid) ? src[g + G * r] : mk(0.f, 0.f);
 #pragma unroll
             for (int r = 8; r < 16; ++r) x[r] = mk(0.f, 0.f);
+            if (i == 0) st.loads_landed();
             fft16<false, false, true>(x, mk(1.f, 0.f));   // no bit above the top pass: its twiddles are the constants W16^k
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X[pidx(g + G * r)] = x[r];
+            for (int r = 0; r < 16; ++r) X[pidx(g) + (G + G / 16) * r] = x[r];   // = pidx(g + G r): G is a multiple of 16
         }
         __syncthreads();
-        fft_forward_from<LOG2M, NG, 1>(X, tw, W, tid);
+        st();
+        fft_forward_from<LOG2M, NG, 1, TAIL>(X, tw, W, tid, st);
     } else {
+        static_assert(TAIL, "odd sizes run the plain sequence");
         for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < n_valid) ? src[j] : mk(0.f, 0.f);
         __syncthreads();
         fft_forward<LOG2M, NG>(X, tw, W, tid);
     }
 }
 
-// Pointwise stage in bit-reversed order (fft_core.h: pointwise_pair / pointwise_self), M/2 pairs over the workgroup.
+// Pointwise stage in bit-reversed order (fft_core.h: pointwise_pair4 / pointwise_self4: the packed form, which leaves the
+// row scaled by FOUR), M/2 pairs over the workgroup.
 template <int LOG2M, int THREADS>
 __device__ __forceinline__ void pointwise_pairs(c2* __restrict__ X, const c2* __restrict__ twp,
                                                 const c2* __restrict__ kfa, const c2* __restrict__ kfb,
@@ -159,7 +200,7 @@ __device__ __forceinline__ void pointwise_pairs(c2* __restrict__ X, const c2* __
         const int q = tid + it * THREADS;
         if (q == 0) {
             c2 z0 = X[pidx(0)], z1 = X[pidx(1)];
-            pointwise_self(z0, z1, kfs[0], kfs[1], kfs[2], csign);
+            pointwise_self4(z0, z1, kfs[0], kfs[1], kfs[2], csign);
             X[pidx(0)] = z0;
             X[pidx(1)] = z1;
             continue;
@@ -167,7 +208,7 @@ __device__ __forceinline__ void pointwise_pairs(c2* __restrict__ X, const c2* __
         const int p = 2 * q;
         const int pm = brev(M - brev(p, LOG2M), LOG2M);
         c2 zk = X[pidx(p)], zm = X[pidx(pm)];
-        pointwise_pair(zk, zm, wk[it], ka[it], kb[it], csign);
+        pointwise_pair4(zk, zm, wk[it], ka[it], kb[it], csign);
         X[pidx(p)] = zk;
         X[pidx(pm)] = zm;
     }
@@ -189,9 +230,14 @@ struct RowSchedule {
 //
 // Even sizes: the top radix-16 pass works straight from / to global memory -- a thread's 16 points are tid + THREADS*r,
 // of which r >= 8 are the zero padding (never loaded) on the way in and never needed on the way out.
-template <int LOG2M, int THREADS>
+// FUSED (plans that end in a radix-4 tail, one 16-point group per thread): forward tail + pair stage + inverse tail are ONE
+// pass (fft_core.h: pass_tail_pointwise) -- a row of M = 16384 goes through LDS in six round trips and six barriers
+// instead of eight and nine.
+template <int LOG2M, int THREADS, bool TRACE = false, bool FUSED = false>
 __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     using P = FftPlan<LOG2M>;
+    static_assert(!TRACE || !P::ODD, "phase stamps: even sizes only");
+    static_assert(!FUSED || (P::TAIL4 && !P::ODD && THREADS == (1 << LOG2M) / 16), "fused tail: shape");
     constexpr int M = 1 << LOG2M;
     constexpr bool DIRECT = !P::ODD;
     extern __shared__ __attribute__((aligned(16))) c2 X[];  // M + M/16 complex
@@ -201,25 +247,65 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     // (Distinct s_setprio per wave of a SIMD, so that one wave is writing its pass back while the others still compute:
     // 86.6 vs 86.4 us, no effect.)
     FftTw<LOG2M, NG> W;
-    W.load(a.tw, tid);
-    const float scale = 1.f / (float)M, csign = a.conj_k ? -1.f : 1.f;
+    if constexpr (!FUSED) W.load(a.tw, tid);   // (FUSED fetches every base twiddle at its use: no register held over a row)
+    // (the packed pair arithmetic leaves the row scaled by four, see pointwise_pair4)
+    const float scale = 0.25f / (float)M, csign = a.conj_k ? -1.f : 1.f;
     const RowSchedule sch(a.B * a.H);
-    // (fetching the next row's points before the last pass of the current one was measured SLOWER: 99 vs 88 us at
-    // M = 16384 -- 16 more live registers at the 128-VGPR limit of a 1024-thread workgroup)
+    // (Fetching the next row's points before the last pass of the current one was measured SLOWER: 99 vs 88 us at
+    // M = 16384 -- 16 more live registers at the 128-VGPR limit of a 1024-thread workgroup.  Round 4: requested AFTER the
+    // bottom pass, when its registers are free, and BEFORE the closing barrier, so that the waves that reach the barrier early
+    // -- the trace shows 2-3 k cycles of mean wait -- have the round trip covered: the trace's "loads landed" phase drops
+    // from 3.5 k to 0.6 k cycles, but __syncthreads() waits for vmcnt(0), i.e. for the requests, and the row gets no
+    // shorter (75.7 vs 74.4 us); with `s_waitcnt lgkmcnt(0); s_barrier` in its place the 16 registers live across the
+    // barrier spill.  Dropped: a row's points are requested at its own top pass.)
+    // TRACE: stamps of the first FFT_TRACE_ROWS rows this workgroup walks: row start | top pass: loads landed, done | forward
+    // passes | pointwise | inverse passes | bottom pass + stores | closing barrier
+    typename std::conditional<TRACE, WaveStamp, NoStamp>::type st;
+    int ri = 0;
 #pragma unroll 1
     for (int row = sch.first; row < sch.end; row += sch.step) {
         // rows of one channel h are adjacent (the kernel spectrum is shared by the batch)
         const int h = row / a.B, b = row % a.B;
         const size_t off = ((size_t)b * a.H + h) * L;
         const c2* __restrict__ u2 = reinterpret_cast<const c2*>(a.u + off);
-        fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid);
-        // (Round 4, measured and dropped: touching the NEXT row's input here -- one LDS-DMA dword per lane, 64 bytes apart, into a
-        // scratch slot, so that its top pass would find the points in L2 instead of paying the HBM round trip with all 16 waves
-        // waiting -- made the kernel SLOWER, 87.8 -> 94.5 us same box: vector-memory loads return in order, so the pointwise
-        // stage's K_f loads queue behind the prefetch and expose the very latency it was meant to hide.)
-        pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
-                                        a.kfs + (size_t)h * 3, tid, csign);
+        if constexpr (TRACE) {
+            st.slot = ri < FFT_TRACE_ROWS ? a.trace + (((size_t)blockIdx.x * (THREADS / 64) + __builtin_amdgcn_readfirstlane(tid >> 6)) * FFT_TRACE_ROWS + ri) *
+                                                          FFT_TRACE_SLOTS
+                                          : nullptr;
+            st.k = 0;
+            st.lane0 = (tid & 63) == 0;
+            ++ri;
+            st();
+        }
+        if constexpr (FUSED) {
+            // top pass on registers (fft_forward_global's); buffer loads: a point beyond the row's L/2 comes back as zero
+            __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)(a.u + off), 0, L * 4, 0x00020000);
+            c2 x[16];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                x[r] = __builtin_bit_cast(c2, __builtin_amdgcn_raw_buffer_load_b64(rU, (tid + (M / 16) * r) * 8, 0, 0));
+#pragma unroll
+            for (int r = 8; r < 16; ++r) x[r] = mk(0.f, 0.f);
+            st.loads_landed();
+            fft16<false, false, true>(x, mk(1.f, 0.f));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[pidx(tid) + (M / 16 + M / 256) * r] = x[r];
+            __syncthreads();
+            st();
+            fft_forward_from<LOG2M, NG, 1, false>(X, a.tw, W, tid, st);
+            pass_tail_pointwise<LOG2M, true>(X, a.tw, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
+                                             a.kfs + (size_t)h * 3, opaque(tid), csign);
+        } else {
+            fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid, st);
+            pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
+                                            a.kfs + (size_t)h * 3, tid, csign);
+        }
+        // (Round 4, measured and dropped, twice: touching the NEXT row's input -- one LDS-DMA dword per lane, 64 bytes apart,
+        // into a scratch slot -- so that its top pass would find the points in L2.  Before the pair stage: 87.8 -> 94.5 us
+        // (vector-memory loads return in order: the stage's K_f loads queue behind the requests); after it, with no
+        // vector-memory instruction for three passes: 77.4 -> 80.4 us (`profiles/r04_ab_fftconv_fused_tail.txt`).)
         __syncthreads();
+        st();
         const float Dh = a.D[h];
         c2* __restrict__ g2 = reinterpret_cast<c2*>(a.g + off);
         c2* __restrict__ p2 = a.pre ? reinterpret_cast<c2*>(a.pre + off) : nullptr;
@@ -229,26 +315,33 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
             g2[j] = a.no_act ? v : mk(gelu_f(v.x), gelu_f(v.y));
         };
         if constexpr (DIRECT) {
-            fft_inverse_to<LOG2M, NG, 1>(X, W, tid);
+            fft_inverse_to<LOG2M, NG, 1, !FUSED, FUSED>(X, W, tid, st, a.tw);
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 if (i) __builtin_amdgcn_sched_barrier(0);
                 const int g = tid + THREADS * i;
                 c2 x[16];
+                // (FUSED: the bottom pass's base twiddle is fetched here -- held over the row it is the one value too many
+                // for the 128 registers of a 1024-thread workgroup)
+                const c2 th0 = FUSED ? FftTw<LOG2M, NG>::template theta_at<0>(a.tw, opaque(g)) : W.theta[0][i];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = X[pidx(g + (M / 16) * r)];
-                fft16<true, true, false, true>(x, W.theta[0][i]);
+                for (int r = 0; r < 16; ++r) x[r] = X[pidx(g) + (M / 16 + M / 256) * r];   // = pidx(g + (M/16) r)
+                fft16<true, true, false, true>(x, th0);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int j = g + (M / 16) * r;
                     if (j < Lc) finish(j, x[r], u2[j]);   // this row's input once more for the D u term (an L2 hit)
                 }
             }
+            st();
         } else {
             fft_inverse<LOG2M, NG>(X, a.tw, W, tid);
             for (int j = tid; j < Lc; j += THREADS) finish(j, X[pidx(j)], u2[j]);
         }
         __syncthreads();   // the next row overwrites X
+        // (lgkmcnt(0) + s_barrier instead -- nobody needs this row's global stores to have landed, and __syncthreads()
+        // waits for them -- measured no different: 80.5 vs 80.6 us)
+        st();
     }
 }
 
@@ -518,6 +611,7 @@ struct FcCfg {
     // 256 VGPRs, room to overlap one group's LDS traffic with the other's butterflies -- measured 121 us against 87 us.)
     static constexpr int THREADS = M / 16;
     static constexpr size_t LDS = (size_t)(M + M / 16) * 8;
+    static constexpr bool FUSED = FftPlan<LOG2M>::TAIL4 && !FftPlan<LOG2M>::ODD;
 };
 
 bool fftconv_supported(int L, int* log2m) {
@@ -541,13 +635,80 @@ static int cu_count() {
     return n;
 }
 
+// DWS_FFT_TRACE=1: the launch runs the stamped instance, waits, and prints the mean ticks per phase (one line per traced row
+// index: a workgroup's first row starts cold, the later ones show the steady state) on stderr -- the per-phase budget of a
+// row.  s_memtime is per XCD: only differences inside one wave / workgroup are formed.
 template <int LOG2M>
-static int launch_fc(const FftConvArgs& a_in, hipStream_t s) {
+static int fft_trace_launch(FftConvArgs a, int nwg, hipStream_t s) {
     using C = FcCfg<LOG2M>;
-    auto kern = fftconv_kernel<LOG2M, C::THREADS>;
+    static const char* names[12] = {"", "loads landed", "top pass", "fwd P1", "fwd P2", "fwd tail", "pointwise", "inv tail",
+                                    "inv P2", "inv P1", "bottom + stores", "closing barrier"};
+    static const bool fused = C::FUSED && getenv("DWS_FFT_NO_FUSED_TAIL") == nullptr;
+    auto kern = fused ? fftconv_kernel<LOG2M, C::THREADS, true, C::FUSED> : fftconv_kernel<LOG2M, C::THREADS, true>;
+    constexpr int NP = FftPlan<LOG2M>::N16 - 1;
+    const int T4 = (FftPlan<LOG2M>::TAIL4 && !fused) ? 1 : 0, NST = 3 + NP + T4 + 1 + T4 + NP + 2;   // fused: the pair stage carries both tails
     static bool attr = false;
     if (!attr) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        attr = true;
+    }
+    constexpr int WAVES = C::THREADS / 64, PER = FFT_TRACE_ROWS * FFT_TRACE_SLOTS;
+    // stamps per row: start, loads, top, the plan's further radix-16 passes, (tail), pointwise, (tail), inverse passes, bottom, barrier
+    const size_t n = (size_t)nwg * WAVES * PER;
+    unsigned long long* d = nullptr;
+    DWS_HIP(hipMalloc(&d, n * 8));
+    DWS_HIP(hipMemsetAsync(d, 0, n * 8, s));
+    a.trace = d;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(C::THREADS), C::LDS, s, a);
+    DWS_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h(n);
+    DWS_HIP(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
+    DWS_HIP(hipFree(d));
+    for (int ri = 0; ri < FFT_TRACE_ROWS; ++ri) {
+        double ph[FFT_TRACE_SLOTS] = {0}, life = 0, span = 0;
+        long waves = 0, wgs = 0;
+        for (int g = 0; g < nwg; ++g) {
+            unsigned long long g0 = ~0ull, g1 = 0;
+            for (int w = 0; w < WAVES; ++w) {
+                const unsigned long long* t = &h[((size_t)g * WAVES + w) * PER + (size_t)ri * FFT_TRACE_SLOTS];
+                if (t[0] == 0 || t[NST - 1] == 0) continue;    // this workgroup walked fewer rows
+                for (int i = 1; i < NST; ++i) ph[i] += (double)(t[i] - t[i - 1]);
+                life += (double)(t[NST - 1] - t[0]);
+                g0 = std::min(g0, t[0]);
+                g1 = std::max(g1, t[NST - 1]);
+                ++waves;
+            }
+            if (g1 > g0 && g0 != ~0ull) { span += (double)(g1 - g0); ++wgs; }
+        }
+        if (!waves) continue;
+        fprintf(stderr, "[fft trace] M=%d L=%d rows=%d wgs=%d row#%d (%ld waves) mean ticks:", 1 << LOG2M, a.L, a.B * a.H, nwg, ri, waves);
+        int name = 1;
+        for (int i = 1; i < NST; ++i) {
+            // names[] lists the M = 16384 plan (two further passes, a tail); shorter plans skip the entries they do not have
+            const char* nm = names[std::min(name, 11)];
+            fprintf(stderr, " %s %.0f |", nm, ph[i] / waves);
+            ++name;
+            if (NP < 2 && name == 4) name = 5;
+            if (!T4 && (name == 5 || name == 7)) ++name;
+            if (NP < 2 && name == 8) name = 9;
+        }
+        fprintf(stderr, " row %.0f, workgroup span %.0f\n", life / waves, span / std::max(1l, wgs));
+    }
+    return DWS_OK;
+}
+
+template <int LOG2M>
+static int launch_fc(const FftConvArgs& a_in, hipStream_t s) {
+    using C = FcCfg<LOG2M>;
+    // A/B switch, read once: DWS_FFT_NO_FUSED_TAIL=1 (separate tail / pair / tail passes, scalar pair arithmetic)
+    static const bool fused = C::FUSED && getenv("DWS_FFT_NO_FUSED_TAIL") == nullptr;
+    auto kern = fused ? fftconv_kernel<LOG2M, C::THREADS, false, C::FUSED> : fftconv_kernel<LOG2M, C::THREADS>;
+    static bool attr = false;
+    if (!attr) {
+        DWS_HIP(hipFuncSetAttribute((const void*)fftconv_kernel<LOG2M, C::THREADS, false, C::FUSED>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        DWS_HIP(hipFuncSetAttribute((const void*)fftconv_kernel<LOG2M, C::THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)C::LDS));
         attr = true;
     }
     const FftConvArgs& a = a_in;
@@ -555,6 +716,10 @@ static int launch_fc(const FftConvArgs& a_in, hipStream_t s) {
     const int rows = a.B * a.H;
     const int slots = cu_count() * std::max(1, std::min((int)(160 * 1024 / C::LDS), 2048 / C::THREADS));
     const int nwg = (std::min(rows, LOG2M >= 13 ? slots : rows) + 7) / 8 * 8;
+    if constexpr (!FftPlan<LOG2M>::ODD) {
+        static const bool trace = getenv("DWS_FFT_TRACE") != nullptr;
+        if (trace) return fft_trace_launch<LOG2M>(a, nwg, s);
+    }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(C::THREADS), C::LDS, s, a);
     return DWS_OK;
 }

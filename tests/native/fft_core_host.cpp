@@ -9,15 +9,15 @@
 
 using namespace dws;
 
-template <int LOG2M, int P0>
+template <int LOG2M, int P0, bool TAIL = true>
 static void fwd_from(float2* X, const float2* tw) {
     using P = FftPlan<LOG2M>;
     constexpr int T = (1 << LOG2M) / 16;
     if constexpr (P0 < P::N16) {
         for (int tid = 0; tid < T; ++tid)
             pass16_lds<LOG2M, P::b0(P0), false>(X, FftTw<LOG2M>::template phi<P::b0(P0)>(tw, tid), tid);
-        fwd_from<LOG2M, P0 + 1>(X, tw);
-    } else if constexpr (P::TAIL4) {
+        fwd_from<LOG2M, P0 + 1, TAIL>(X, tw);
+    } else if constexpr (P::TAIL4 && TAIL) {
         for (int tid = 0; tid < T; ++tid) pass4_lds<false>(X, FftTw<LOG2M>::tail_twiddle(tw, tid), tid);
     }
 }
@@ -35,11 +35,11 @@ static void inv_passes(float2* X, const float2* tw) {
     }
 }
 
-template <int LOG2M, int P0>
+template <int LOG2M, int P0, bool TAIL = true>
 static void inv_to(float2* X, const float2* tw) {
     using P = FftPlan<LOG2M>;
     constexpr int T = (1 << LOG2M) / 16;
-    if constexpr (P::TAIL4)
+    if constexpr (P::TAIL4 && TAIL)
         for (int tid = 0; tid < T; ++tid) pass4_lds<true>(X, make_float2(1.f, 0.f), tid);
     inv_passes<LOG2M, P0, P::N16>(X, tw);
 }
@@ -74,9 +74,12 @@ static void transform(float* data, const float* tw, int inverse) {
 
 // One row of fftconv_kernel: out[0..L) = conv part only (scaled by 1/M), as the kernel sequences it -- for even sizes the
 // top radix-16 pass runs on registers straight from the (zero padded) input and straight to the output.
-template <int LOG2M>
+// FUSED (even plans that end in a radix-4 tail): forward tail + pair stage + inverse tail as the one pass
+// `pass_tail_pointwise` (a thread per block of 16 positions and its mirror block).
+template <int LOG2M, bool FUSED = false, bool X4 = false>
 static void conv_row(const float* u, int L, const float* tw_, const float* twp_, const float* kfa_, const float* kfb_,
                      const float* kfs_, float csign, float* out) {
+    static_assert(!FUSED || (FftPlan<LOG2M>::TAIL4 && !FftPlan<LOG2M>::ODD), "fused tail");
     using P = FftPlan<LOG2M>;
     constexpr int M = 1 << LOG2M, T = M / 16;
     const int Lc = L / 2;
@@ -99,23 +102,30 @@ static void conv_row(const float* u, int L, const float* tw_, const float* twp_,
             fft16<false, false, true>(x, make_float2(1.f, 0.f));
             for (int r = 0; r < 16; ++r) X[pidx(tid + T * r)] = x[r];
         }
-        fwd_from<LOG2M, 1>(X.data(), tw);
+        fwd_from<LOG2M, 1, !FUSED>(X.data(), tw);
     } else {
         for (int j = 0; j < M; ++j) X[pidx(j)] = (j < Lc) ? u2[j] : make_float2(0.f, 0.f);
         forward_lds<LOG2M>(X.data(), tw);
     }
-    for (int q = 0; q < M / 2; ++q) {
-        if (q == 0) {
-            pointwise_self(X[pidx(0)], X[pidx(1)], kfs[0], kfs[1], kfs[2], csign);
-            continue;
+    if constexpr (FUSED) {
+        // every thread reads and writes its own 16 points only: any order of the threads gives the same row
+        for (int tid = T - 1; tid >= 0; --tid) pass_tail_pointwise<LOG2M, X4>(X.data(), tw, twp, kfa, kfb, kfs, tid, csign);
+    } else {
+        for (int q = 0; q < M / 2; ++q) {
+            if (q == 0) {
+                if (X4) pointwise_self4(X[pidx(0)], X[pidx(1)], kfs[0], kfs[1], kfs[2], csign);
+                else pointwise_self(X[pidx(0)], X[pidx(1)], kfs[0], kfs[1], kfs[2], csign);
+                continue;
+            }
+            const int p = 2 * q;
+            const int pm = brev_bits(M - brev_bits(p, LOG2M), LOG2M);
+            if (X4) pointwise_pair4(X[pidx(p)], X[pidx(pm)], twp[q], kfa[q], kfb[q], csign);
+            else pointwise_pair(X[pidx(p)], X[pidx(pm)], twp[q], kfa[q], kfb[q], csign);
         }
-        const int p = 2 * q;
-        const int pm = brev_bits(M - brev_bits(p, LOG2M), LOG2M);
-        pointwise_pair(X[pidx(p)], X[pidx(pm)], twp[q], kfa[q], kfb[q], csign);
     }
-    const float scale = 1.f / (float)M;
+    const float scale = (X4 ? 0.25f : 1.f) / (float)M;
     if constexpr (!P::ODD) {
-        inv_to<LOG2M, 1>(X.data(), tw);
+        inv_to<LOG2M, 1, !FUSED>(X.data(), tw);
         for (int tid = 0; tid < T; ++tid) {
             FftTw<LOG2M> W;
             W.load(tw, tid);
@@ -208,6 +218,39 @@ extern "C" int dws_host_fft(int log2m, float* data, const float* tw, int inverse
 extern "C" int dws_host_conv_row(int log2m, const float* u, int L, const float* tw, const float* twp, const float* kfa,
                                  const float* kfb, const float* kfs, float csign, float* out) {
     DISPATCH(conv_row, u, L, tw, twp, kfa, kfb, kfs, csign, out);
+}
+
+// the same row with the fused tail pass (sizes whose plan is even and ends in a radix-4 tail: 2^6, 2^10, 2^14)
+extern "C" int dws_host_conv_row_fused(int log2m, const float* u, int L, const float* tw, const float* twp, const float* kfa,
+                                       const float* kfb, const float* kfs, float csign, float* out) {
+    switch (log2m) {
+        case 6: conv_row<6, true>(u, L, tw, twp, kfa, kfb, kfs, csign, out); return 0;
+        case 10: conv_row<10, true>(u, L, tw, twp, kfa, kfb, kfs, csign, out); return 0;
+        case 14: conv_row<14, true>(u, L, tw, twp, kfa, kfb, kfs, csign, out); return 0;
+    }
+    return 1;
+}
+
+// the separate pair stage with the packed pair arithmetic (`pointwise_pair4`; the kernel's form at every size)
+template <int LOG2M>
+static void conv_row_x4(const float* u, int L, const float* tw, const float* twp, const float* kfa, const float* kfb,
+                        const float* kfs, float csign, float* out) {
+    conv_row<LOG2M, false, true>(u, L, tw, twp, kfa, kfb, kfs, csign, out);
+}
+extern "C" int dws_host_conv_row_x4(int log2m, const float* u, int L, const float* tw, const float* twp, const float* kfa,
+                                    const float* kfb, const float* kfs, float csign, float* out) {
+    DISPATCH(conv_row_x4, u, L, tw, twp, kfa, kfb, kfs, csign, out);
+}
+
+// ... and the fused tail pass with it (sizes 2^6, 2^10, 2^14 in the kernel)
+extern "C" int dws_host_conv_row_fused4(int log2m, const float* u, int L, const float* tw, const float* twp, const float* kfa,
+                                        const float* kfb, const float* kfs, float csign, float* out) {
+    switch (log2m) {
+        case 6: conv_row<6, true, true>(u, L, tw, twp, kfa, kfb, kfs, csign, out); return 0;
+        case 10: conv_row<10, true, true>(u, L, tw, twp, kfa, kfb, kfs, csign, out); return 0;
+        case 14: conv_row<14, true, true>(u, L, tw, twp, kfa, kfb, kfs, csign, out); return 0;
+    }
+    return 1;
 }
 
 extern "C" int dws_host_conv_long_row(int log2m, const float* u, int L, const float* tw, const float* twp,

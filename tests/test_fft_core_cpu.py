@@ -24,6 +24,9 @@ def host():
     fp = ctypes.POINTER(ctypes.c_float)
     lib.dws_host_fft.argtypes = [ctypes.c_int, fp, fp, ctypes.c_int]
     lib.dws_host_conv_row.argtypes = [ctypes.c_int, fp, ctypes.c_int, fp, fp, fp, fp, fp, ctypes.c_float, fp]
+    lib.dws_host_conv_row_fused.argtypes = lib.dws_host_conv_row.argtypes
+    lib.dws_host_conv_row_fused4.argtypes = lib.dws_host_conv_row.argtypes
+    lib.dws_host_conv_row_x4.argtypes = lib.dws_host_conv_row.argtypes
     fpp = ctypes.POINTER(fp)
     lib.dws_host_conv_long_row.argtypes = [ctypes.c_int, fp, ctypes.c_int, fp, fp, fpp, fpp, fpp, fp]
     return lib
@@ -69,7 +72,7 @@ def test_forward_is_the_bit_reversed_dft_and_inverse_undoes_it(host, lg):
     assert np.abs(back - x).max() / np.abs(x).max() < 2e-6
 
 
-@pytest.mark.parametrize("lg,L", [(10, 1000), (10, 64), (12, 4000), (14, 16000), (14, 16384), (11, 1500), (13, 8000)])
+@pytest.mark.parametrize("lg,L", [(6, 60), (10, 1000), (10, 64), (12, 4000), (14, 16000), (14, 16384), (11, 1500), (13, 8000)])
 @pytest.mark.parametrize("csign", [1.0, -1.0])
 def test_convolution_row_matches_the_definition(host, lg, L, csign):
     """y[i] = sum_j k0[j] u[i-j] + sum_{m>=1} k1[m-1] u[i+m] (csign = -1: the adjoint, i.e. correlation with the same
@@ -101,6 +104,26 @@ def test_convolution_row_matches_the_definition(host, lg, L, csign):
         assert np.abs(direct - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
     err = np.abs(out - ref).max() / np.abs(ref).max()
     assert err < 5e-6, err
+    # the kernel's pair arithmetic (`pointwise_pair4`: packed, fused multiply-adds, the two exact halvings moved into the
+    # final 1/M): other roundings, same accuracy against the float64 definition
+    x4 = np.zeros(L, dtype=np.float32)
+    assert host.dws_host_conv_row_x4(lg, _p(u), L, _p(_c2f(tw)), _p(_c2f(twp)), _p(_c2f(kfa)), _p(_c2f(kfb)), _p(_c2f(kfs)),
+                                     csign, _p(x4)) == 0
+    errx = np.abs(x4 - ref).max() / np.abs(ref).max()
+    assert errx < 5e-6 and errx < 1.5 * err + 1e-7, (errx, err)
+    if lg in (6, 10, 14):
+        # plans that end in a radix-4 tail run forward tail + pair stage + inverse tail as ONE pass in the kernel
+        # (`pass_tail_pointwise`: a thread holds half of a block of 16 positions and half of its mirror block): the same
+        # butterflies and pair arithmetic on the same operands, so the row must come out bit for bit the same
+        fused = np.zeros(L, dtype=np.float32)
+        assert host.dws_host_conv_row_fused(lg, _p(u), L, _p(_c2f(tw)), _p(_c2f(twp)), _p(_c2f(kfa)), _p(_c2f(kfb)),
+                                            _p(_c2f(kfs)), csign, _p(fused)) == 0
+        assert np.array_equal(fused, out), np.abs(fused - out).max()
+        # ... and the fused pass with the packed pair arithmetic (what the kernel runs) equals the separate sequence with it
+        f4 = np.zeros(L, dtype=np.float32)
+        assert host.dws_host_conv_row_fused4(lg, _p(u), L, _p(_c2f(tw)), _p(_c2f(twp)), _p(_c2f(kfa)), _p(_c2f(kfb)),
+                                             _p(_c2f(kfs)), csign, _p(f4)) == 0
+        assert np.array_equal(f4, x4), np.abs(f4 - x4).max()
 
 
 @pytest.mark.parametrize("lg,L,Lt", [(8, 1000, 256), (8, 1000, 100), (8, 513, 256), (10, 2500, 1000), (14, 40000, 16000)])
