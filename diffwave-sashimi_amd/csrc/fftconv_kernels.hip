@@ -256,8 +256,10 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     // bottom pass, when its registers are free, and BEFORE the closing barrier, so that the waves that reach the barrier early
     // -- the trace shows 2-3 k cycles of mean wait -- have the round trip covered: the trace's "loads landed" phase drops
     // from 3.5 k to 0.6 k cycles, but __syncthreads() waits for vmcnt(0), i.e. for the requests, and the row gets no
-    // shorter (75.7 vs 74.4 us); with `s_waitcnt lgkmcnt(0); s_barrier` in its place the 16 registers live across the
-    // barrier spill.  Dropped: a row's points are requested at its own top pass.)
+    // shorter (75.7 vs 74.4 us); with `s_waitcnt lgkmcnt(0); s_barrier` in its place (no spill when the choice is made at
+    // compile time) the loads do land under the barrier, and the bottom pass and the barrier grow by more than the top pass
+    // saves: 74.9 vs 73.6 us (`profiles/r04_fft_trace_c3_early_loads_dropped.txt`).  Dropped: a row's points are requested
+    // at its own top pass.)
     // TRACE: stamps of the first FFT_TRACE_ROWS rows this workgroup walks: row start | top pass: loads landed, done | forward
     // passes | pointwise | inverse passes | bottom pass + stores | closing barrier
     typename std::conditional<TRACE, WaveStamp, NoStamp>::type st;
