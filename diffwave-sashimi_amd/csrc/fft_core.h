@@ -518,11 +518,13 @@ DWS_HD void stage16_fwd_halves(c2 (&x)[16], const Tw16<true>& tl, const Tw16<tru
 }
 
 // X4: the packed pair arithmetic, the row comes out scaled by four (pointwise_pair4).
-template <int LOG2M, bool X4 = false>
+// TAILS = false: the pair stage alone in the same block / mirror-block order (plans without a radix-4 tail): contiguous
+// conflict-free LDS runs and adjacent table entries instead of eight scattered pairs per thread.
+template <int LOG2M, bool X4 = false, bool TAILS = true>
 DWS_HD void pass_tail_pointwise(c2* __restrict__ X, const c2* __restrict__ tw, const c2* __restrict__ twp,
                                 const c2* __restrict__ kfa, const c2* __restrict__ kfb, const c2* __restrict__ kfs, int t,
                                 float csign) {
-    static_assert(FftPlan<LOG2M>::TAIL4, "plans that end in a radix-4 pass");
+    static_assert(FftPlan<LOG2M>::TAIL4 || !TAILS, "plans that end in a radix-4 pass");
     const int tm = mirror_block(t);
     // the tables of the four pairs whose even position lies in block t first: their L2 round trip runs under the LDS reads
     // and the tail butterflies; the other four (block t') are requested once the butterflies are done and arrive under
@@ -534,18 +536,22 @@ DWS_HD void pass_tail_pointwise(c2* __restrict__ X, const c2* __restrict__ tw, c
         ka[i] = kfa[8 * t + i];
         kb[i] = kfb[8 * t + i];
     }
-    const c2 taul = tw[brev_bits(t, LOG2M - 4)], tauh = tw[brev_bits(tm, LOG2M - 4)];
+    c2 taul = mk(1.f, 0.f), tauh = mk(1.f, 0.f);
+    if (TAILS) {
+        taul = tw[brev_bits(t, LOG2M - 4)];
+        tauh = tw[brev_bits(tm, LOG2M - 4)];
+    }
     c2 x[16];
 #pragma unroll
     for (int d = 0; d < 8; ++d) x[d] = X[17 * t + d];            // pidx(16 t + d) = 17 t + d
 #pragma unroll
     for (int d = 8; d < 16; ++d) x[d] = X[17 * tm + d];
-    {
+    if (TAILS) {
         const Tw16<true> tl(opaque(taul)), th(opaque(tauh));
         stage16_fwd_halves<1>(x, tl, th);
         stage16_fwd_halves<0>(x, tl, th);
+        sched_fence();
     }
-    sched_fence();
     c2 wk2[4], ka2[4], kb2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -584,7 +590,7 @@ DWS_HD void pass_tail_pointwise(c2* __restrict__ X, const c2* __restrict__ tw, c
         const c2 n1 = x[1], n3 = x[3], n5 = x[5], n7 = x[7], n9 = x[9], n11 = x[11], n13 = x[13], n15 = x[15];
         x[1] = n15; x[3] = n13; x[7] = n11; x[5] = n9; x[15] = n7; x[13] = n5; x[11] = n3; x[9] = n1;
     }
-    fft16<true, false, false, false, true>(x, mk(1.f, 0.f));     // inverse tail: unit base twiddle in every block
+    if (TAILS) fft16<true, false, false, false, true>(x, mk(1.f, 0.f));     // inverse tail: unit base twiddle in every block
 #pragma unroll
     for (int d = 0; d < 8; ++d) X[17 * t + d] = x[d];
 #pragma unroll

@@ -174,46 +174,6 @@ __device__ __forceinline__ void fft_forward_global(c2* X, const c2* __restrict__
     }
 }
 
-// Pointwise stage in bit-reversed order (fft_core.h: pointwise_pair4 / pointwise_self4: the packed form, which leaves the
-// row scaled by FOUR), M/2 pairs over the workgroup.
-template <int LOG2M, int THREADS>
-__device__ __forceinline__ void pointwise_pairs(c2* __restrict__ X, const c2* __restrict__ twp,
-                                                const c2* __restrict__ kfa, const c2* __restrict__ kfb,
-                                                const c2* __restrict__ kfs, int tid_in, float csign) {
-    constexpr int M = 1 << LOG2M, NPW = M / 2 / THREADS;
-    // opaque: the pair addresses are invariant over the rows a workgroup walks; hoisted out of that loop they would
-    // occupy ~5 VGPRs per pair for the kernel's lifetime
-    const int tid = opaque(tid_in);
-    // the spectrum / twiddle entries of ALL of this thread's pairs are requested first: one L2 round trip for the stage
-    // instead of one per pair (every wave of the workgroup is in this stage at the same time, nothing else hides it);
-    // same-box A/B: -1 % at M = 16384, -6 % at M = 4096
-    c2 wk[NPW], ka[NPW], kb[NPW];
-#pragma unroll
-    for (int it = 0; it < NPW; ++it) {
-        const int q = tid + it * THREADS;
-        wk[it] = twp[q];
-        ka[it] = kfa[q];
-        kb[it] = kfb[q];
-    }
-#pragma unroll
-    for (int it = 0; it < NPW; ++it) {
-        const int q = tid + it * THREADS;
-        if (q == 0) {
-            c2 z0 = X[pidx(0)], z1 = X[pidx(1)];
-            pointwise_self4(z0, z1, kfs[0], kfs[1], kfs[2], csign);
-            X[pidx(0)] = z0;
-            X[pidx(1)] = z1;
-            continue;
-        }
-        const int p = 2 * q;
-        const int pm = brev(M - brev(p, LOG2M), LOG2M);
-        c2 zk = X[pidx(p)], zm = X[pidx(pm)];
-        pointwise_pair4(zk, zm, wk[it], ka[it], kb[it], csign);
-        X[pidx(p)] = zk;
-        X[pidx(pm)] = zm;
-    }
-}
-
 // Row schedule: a persistent grid whose block b sits on XCD b % 8 (observed dispatch order); every XCD gets a contiguous
 // range of rows, i.e. whole channels -- the rows of one channel share K_f, which then lives in ONE L2.
 struct RowSchedule {
@@ -299,8 +259,10 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
                                              a.kfs + (size_t)h * 3, opaque(tid), csign);
         } else {
             fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid, st);
-            pointwise_pairs<LOG2M, THREADS>(X, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
-                                            a.kfs + (size_t)h * 3, tid, csign);
+            // the pair stage alone, in the same block / mirror-block order (contiguous LDS runs, adjacent table entries)
+            static_assert(NG == 1, "one block of 16 positions per thread");
+            pass_tail_pointwise<LOG2M, true, false>(X, a.tw, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
+                                                    a.kfs + (size_t)h * 3, opaque(tid), csign);
         }
         // (Round 4, measured and dropped, twice: touching the NEXT row's input -- one LDS-DMA dword per lane, 64 bytes apart,
         // into a scratch slot -- so that its top pass would find the points in L2.  Before the pair stage: 87.8 -> 94.5 us

@@ -110,6 +110,10 @@ static void conv_row(const float* u, int L, const float* tw_, const float* twp_,
     if constexpr (FUSED) {
         // every thread reads and writes its own 16 points only: any order of the threads gives the same row
         for (int tid = T - 1; tid >= 0; --tid) pass_tail_pointwise<LOG2M, X4>(X.data(), tw, twp, kfa, kfb, kfs, tid, csign);
+    } else if constexpr (X4) {
+        // the kernel's pair stage at sizes without a fused tail: the same block / mirror-block order, no butterflies
+        for (int tid = T - 1; tid >= 0; --tid)
+            pass_tail_pointwise<LOG2M, true, false>(X.data(), tw, twp, kfa, kfb, kfs, tid, csign);
     } else {
         for (int q = 0; q < M / 2; ++q) {
             if (q == 0) {
