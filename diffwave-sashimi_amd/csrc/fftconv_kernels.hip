@@ -291,10 +291,24 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x[r] = X[pidx(g) + (M / 16 + M / 256) * r];   // = pidx(g + (M/16) r)
                 fft16<true, true, false, true>(x, th0);
+                // buffer instructions clip at the row's end (loads return zero, stores are dropped): no predicate, no
+                // branch per output; the row's input once more for the D u term (an L2 hit), requested together
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __amdgpu_buffer_rsrc_t rUu = __builtin_amdgcn_make_buffer_rsrc((void*)(a.u + off), 0, L * 4, 0x00020000);
+                __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + off), 0, L * 4, 0x00020000);
+                __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)((a.pre ? a.pre : a.g) + off), 0,
+                                                                               a.pre ? L * 4 : 0, 0x00020000);
+                c2 uu[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    uu[r] = __builtin_bit_cast(c2, __builtin_amdgcn_raw_buffer_load_b64(rUu, (g + (M / 16) * r) * 8, 0, 0));
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const int j = g + (M / 16) * r;
-                    if (j < Lc) finish(j, x[r], u2[j]);   // this row's input once more for the D u term (an L2 hit)
+                    const int vo = (g + (M / 16) * r) * 8;
+                    const c2 v = mk(fmaf(x[r].x, scale, Dh * uu[r].x), fmaf(x[r].y, scale, Dh * uu[r].y));
+                    if (a.pre) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rP, vo, 0, 0);
+                    const c2 o = a.no_act ? v : mk(gelu_f(v.x), gelu_f(v.y));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rG, vo, 0, 0);
                 }
             }
             st();
