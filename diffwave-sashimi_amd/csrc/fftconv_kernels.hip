@@ -691,6 +691,7 @@ static int launch_fc(const FftConvArgs& a_in, hipStream_t s) {
     }
     const FftConvArgs& a = a_in;
     // one resident workgroup per LDS slot of every CU walks several rows (RowSchedule); small rows: one row per block
+    // (the persistent schedule from M = 4096 / 1024 up: 32.0-32.2 vs 31.7-31.9 us and 16.4 vs 16.3 us, no gain)
     const int rows = a.B * a.H;
     const int slots = cu_count() * std::max(1, std::min((int)(160 * 1024 / C::LDS), 2048 / C::THREADS));
     const int nwg = (std::min(rows, LOG2M >= 13 ? slots : rows) + 7) / 8 * 8;

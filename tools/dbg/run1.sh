@@ -1,3 +1,10 @@
-cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_sashimi_gpu.py tests/test_full_size_gpu.py -x -q --timeout 600 2>&1 | tail -2
-timeout 900 tools/ab_lib.sh "fftconv_kernel<1" --config unet_d64_n6_T200 --steps 60 --warmup 5 --no-roofline 2>&1 | tail -16
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+export DWS_BENCH_NO_DP_OVERHEAD=1
+for pf in 13 12 10 13 12 10; do
+  export DWS_FFT_PERSIST_FROM=$pf
+  W=/tmp/ab_p; rm -rf $W; mkdir -p $W
+  rocprofv3 --kernel-trace --stats -d $W -o s -- python $R/bench.py --config unet_d64_n6_T200 --steps 60 --warmup 5 --no-cpu-baseline --no-extra --no-full-loop --no-roofline > $W/log 2>&1
+  echo "== persist_from=$pf: $(grep '^{' $W/log | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"])')"
+  python $R/tools/rocpd_summary.py stats $W/s_results.db | grep -i "fftconv_kernel<1" | cut -c1-160
+done
