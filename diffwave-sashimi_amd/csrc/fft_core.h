@@ -517,30 +517,51 @@ DWS_HD void stage16_fwd_halves(c2 (&x)[16], const Tw16<true>& tl, const Tw16<tru
     }
 }
 
+// What the pass reads from global memory before it can start: the first half's tables and the two tail twiddles.  A kernel
+// may request them ahead of the barrier in front of the pass (TailPre::load) and hand them in.
+struct TailPre {
+    c2 wk[4], ka[4], kb[4], taul, tauh;
+    template <int LOG2M, bool TAILS>
+    DWS_HD void load(const c2* __restrict__ tw, const c2* __restrict__ twp, const c2* __restrict__ kfa,
+                     const c2* __restrict__ kfb, int t) {
+        const int tm = mirror_block(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wk[i] = twp[8 * t + i];
+            ka[i] = kfa[8 * t + i];
+            kb[i] = kfb[8 * t + i];
+        }
+        taul = tauh = mk(1.f, 0.f);
+        if (TAILS) {
+            taul = tw[brev_bits(t, LOG2M - 4)];
+            tauh = tw[brev_bits(tm, LOG2M - 4)];
+        }
+    }
+};
+
 // X4: the packed pair arithmetic, the row comes out scaled by four (pointwise_pair4).
 // TAILS = false: the pair stage alone in the same block / mirror-block order (plans without a radix-4 tail): contiguous
 // conflict-free LDS runs and adjacent table entries instead of eight scattered pairs per thread.
 template <int LOG2M, bool X4 = false, bool TAILS = true>
 DWS_HD void pass_tail_pointwise(c2* __restrict__ X, const c2* __restrict__ tw, const c2* __restrict__ twp,
                                 const c2* __restrict__ kfa, const c2* __restrict__ kfb, const c2* __restrict__ kfs, int t,
-                                float csign) {
+                                float csign, const TailPre* pre = nullptr) {
     static_assert(FftPlan<LOG2M>::TAIL4 || !TAILS, "plans that end in a radix-4 pass");
     const int tm = mirror_block(t);
     // the tables of the four pairs whose even position lies in block t first: their L2 round trip runs under the LDS reads
     // and the tail butterflies; the other four (block t') are requested once the butterflies are done and arrive under
     // the first four pairs' arithmetic (all eight at once cost 24 more live registers: spills at 1024 threads)
+    TailPre own;
+    if (!pre) own.template load<LOG2M, TAILS>(tw, twp, kfa, kfb, t);
+    const TailPre& in = pre ? *pre : own;
     c2 wk[4], ka[4], kb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        wk[i] = twp[8 * t + i];
-        ka[i] = kfa[8 * t + i];
-        kb[i] = kfb[8 * t + i];
+        wk[i] = in.wk[i];
+        ka[i] = in.ka[i];
+        kb[i] = in.kb[i];
     }
-    c2 taul = mk(1.f, 0.f), tauh = mk(1.f, 0.f);
-    if (TAILS) {
-        taul = tw[brev_bits(t, LOG2M - 4)];
-        tauh = tw[brev_bits(tm, LOG2M - 4)];
-    }
+    const c2 taul = in.taul, tauh = in.tauh;
     c2 x[16];
 #pragma unroll
     for (int d = 0; d < 8; ++d) x[d] = X[17 * t + d];            // pidx(16 t + d) = 17 t + d

@@ -119,6 +119,56 @@ __device__ __forceinline__ void fft_inverse_to(c2* X, const FftTw<LOG2M, NG>& W,
     fft_inverse_passes<LOG2M, NG, P0, P::N16, FETCH>(X, W, tid, st, tw);
 }
 
+// The same passes for ONE group per thread with the base twiddles requested a pass ahead: `cur` is the twiddle of pass P0 (of
+// the radix-4 tail when P0 == N16), already on its way; a pass requests the next one's before it starts its own LDS reads,
+// so the L2 round trip runs under a whole pass instead of in front of its butterflies (the phase trace: a forward pass
+// that fetches its twiddle itself takes 3.5 k cycles at M = 4096 against 1.7 k for an inverse pass that has it in a register).
+template <int LOG2M, int P0, bool TAIL>
+__device__ __forceinline__ c2 fwd_twiddle(const c2* __restrict__ tw, int tid) {
+    using P = FftPlan<LOG2M>;
+    if constexpr (P0 < P::N16) return FftTw<LOG2M, 1>::template phi<P::b0(P0)>(tw, tid);
+    else if constexpr (P::TAIL4 && TAIL) return FftTw<LOG2M, 1>::tail_twiddle(tw, tid);
+    else return mk(1.f, 0.f);
+}
+// `before_last_barrier()` runs after the last pass's LDS writes and before its barrier: the caller's requests for the stage
+// that follows (the pair stage's tables), issued while the pass's registers are free and the waves wait for each other.
+template <int LOG2M, int P0, bool TAIL, class ST, class F>
+__device__ __forceinline__ void fft_forward_chain(c2* X, const c2* __restrict__ tw, int tid, ST&& st, c2 cur,
+                                                  F&& before_last_barrier) {
+    using P = FftPlan<LOG2M>;
+    constexpr bool LAST = TAIL && P::TAIL4 ? (P0 == P::N16) : (P0 + 1 == P::N16);
+    if constexpr (P0 < P::N16) {
+        const c2 nxt = fwd_twiddle<LOG2M, P0 + 1, TAIL>(tw, opaque(tid));
+        __builtin_amdgcn_sched_barrier(0);
+        pass16_lds<LOG2M, P::b0(P0), false>(X, cur, tid);
+        if constexpr (LAST) before_last_barrier();
+        __syncthreads();
+        st();
+        fft_forward_chain<LOG2M, P0 + 1, TAIL>(X, tw, tid, st, nxt, before_last_barrier);
+    } else if constexpr (P::TAIL4 && TAIL) {
+        pass4_lds<false>(X, cur, tid);
+        before_last_barrier();
+        __syncthreads();
+        st();
+    }
+}
+// Inverse radix-16 passes PCUR-1 .. P0 with fetched twiddles, chained the same way; returns the twiddle of pass P0-1 (the
+// caller's bottom pass), requested under pass P0.
+template <int LOG2M, int P0, int PCUR, class ST>
+__device__ __forceinline__ c2 fft_inverse_chain(c2* X, const c2* __restrict__ tw, int tid, ST&& st, c2 cur) {
+    if constexpr (PCUR > P0) {
+        c2 nxt = mk(1.f, 0.f);
+        if constexpr (PCUR >= 2) nxt = FftTw<LOG2M, 1>::template theta_at<PCUR - 2>(tw, opaque(tid));
+        __builtin_amdgcn_sched_barrier(0);
+        pass16_lds<LOG2M, FftPlan<LOG2M>::b0(PCUR - 1), true>(X, cur, tid);
+        __syncthreads();
+        st();
+        return fft_inverse_chain<LOG2M, P0, PCUR - 1>(X, tw, tid, st, nxt);
+    } else {
+        return cur;
+    }
+}
+
 // Whole transforms of an LDS-resident row; the caller has synchronised after filling X.
 template <int LOG2M, int NG>
 __device__ __forceinline__ void fft_forward(c2* X, const c2* tw, const FftTw<LOG2M, NG>& W, int tid) {
@@ -239,13 +289,17 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
             ++ri;
             st();
         }
-        if constexpr (FUSED) {
+        c2 th_inv = mk(1.f, 0.f);   // FUSED: the first inverse pass's twiddle, requested under the pair pass's barrier
+        if constexpr (DIRECT) {
+            static_assert(NG == 1, "one block of 16 positions per thread");
             // top pass on registers (fft_forward_global's); buffer loads: a point beyond the row's L/2 comes back as zero
             __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)(a.u + off), 0, L * 4, 0x00020000);
             c2 x[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 x[r] = __builtin_bit_cast(c2, __builtin_amdgcn_raw_buffer_load_b64(rU, (tid + (M / 16) * r) * 8, 0, 0));
+            const c2 ph1 = fwd_twiddle<LOG2M, 1, !FUSED>(a.tw, opaque(tid));   // the next pass's base twiddle, a pass ahead
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 8; r < 16; ++r) x[r] = mk(0.f, 0.f);
             st.loads_landed();
@@ -254,12 +308,18 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
             for (int r = 0; r < 16; ++r) X[pidx(tid) + (M / 16 + M / 256) * r] = x[r];
             __syncthreads();
             st();
-            fft_forward_from<LOG2M, NG, 1, false>(X, a.tw, W, tid, st);
-            pass_tail_pointwise<LOG2M, true>(X, a.tw, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
-                                             a.kfs + (size_t)h * 3, opaque(tid), csign);
+            // the pair stage's first tables (and the fused tails' twiddles) are requested under the last forward pass's barrier
+            TailPre pre;
+            fft_forward_chain<LOG2M, 1, !FUSED>(X, a.tw, tid, st, ph1, [&] {
+                pre.template load<LOG2M, FUSED>(a.tw, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2), opaque(tid));
+            });
+            // FUSED: tail + pair stage + tail; otherwise the pair stage alone, in the same block / mirror-block order
+            // (contiguous LDS runs, adjacent table entries)
+            pass_tail_pointwise<LOG2M, true, FUSED>(X, a.tw, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
+                                                    a.kfs + (size_t)h * 3, opaque(tid), csign, &pre);
+            if constexpr (FUSED) th_inv = FftTw<LOG2M, 1>::template theta_at<P::N16 - 1>(a.tw, opaque(tid));
         } else {
             fft_forward_global<LOG2M, NG>(X, u2, Lc, a.tw, W, tid, st);
-            // the pair stage alone, in the same block / mirror-block order (contiguous LDS runs, adjacent table entries)
             static_assert(NG == 1, "one block of 16 positions per thread");
             pass_tail_pointwise<LOG2M, true, false>(X, a.tw, a.twp, a.kfa + (size_t)h * (M / 2), a.kfb + (size_t)h * (M / 2),
                                                     a.kfs + (size_t)h * 3, opaque(tid), csign);
@@ -279,15 +339,17 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
             g2[j] = a.no_act ? v : mk(gelu_f(v.x), gelu_f(v.y));
         };
         if constexpr (DIRECT) {
-            fft_inverse_to<LOG2M, NG, 1, !FUSED, FUSED>(X, W, tid, st, a.tw);
+            // (FUSED: no base twiddle is held over a row -- the one value too many for the 128 registers of a 1024-thread
+            // workgroup; they are fetched a pass ahead instead)
+            c2 th_bottom = mk(1.f, 0.f);
+            if constexpr (FUSED) th_bottom = fft_inverse_chain<LOG2M, 1, P::N16>(X, a.tw, tid, st, th_inv);
+            else fft_inverse_to<LOG2M, NG, 1>(X, W, tid, st);
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 if (i) __builtin_amdgcn_sched_barrier(0);
                 const int g = tid + THREADS * i;
                 c2 x[16];
-                // (FUSED: the bottom pass's base twiddle is fetched here -- held over the row it is the one value too many
-                // for the 128 registers of a 1024-thread workgroup)
-                const c2 th0 = FUSED ? FftTw<LOG2M, NG>::template theta_at<0>(a.tw, opaque(g)) : W.theta[0][i];
+                const c2 th0 = FUSED ? th_bottom : W.theta[0][i];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x[r] = X[pidx(g) + (M / 16 + M / 256) * r];   // = pidx(g + (M/16) r)
                 fft16<true, true, false, true>(x, th0);
