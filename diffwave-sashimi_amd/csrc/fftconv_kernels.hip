@@ -59,8 +59,7 @@ struct WaveStamp {
 
 // Forward passes P0 .. of the plan on an LDS-resident row (a barrier after each).  A thread owns the NG groups
 // g = tid + i*THREADS, THREADS = M/16/NG.
-// TAIL = false: stop before the radix-4 tail (the caller runs it fused with the pair stage: pass_tail_pointwise).
-template <int LOG2M, int NG, int P0, bool TAIL = true, class ST = NoStamp>
+template <int LOG2M, int NG, int P0, class ST = NoStamp>
 __device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ tw, const FftTw<LOG2M, NG>& W, int tid,
                                                  ST&& st = ST()) {
     using P = FftPlan<LOG2M>;
@@ -74,8 +73,8 @@ __device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ t
         }
         __syncthreads();
         st();
-        fft_forward_from<LOG2M, NG, P0 + 1, TAIL>(X, tw, W, tid, st);
-    } else if constexpr (P::TAIL4 && TAIL) {
+        fft_forward_from<LOG2M, NG, P0 + 1>(X, tw, W, tid, st);
+    } else if constexpr (P::TAIL4) {
 #pragma unroll
         for (int i = 0; i < NG; ++i)
             pass4_lds<false>(X, FftTw<LOG2M, NG>::tail_twiddle(tw, opaque(tid) + i * THREADS), tid + i * THREADS);
@@ -84,39 +83,33 @@ __device__ __forceinline__ void fft_forward_from(c2* X, const c2* __restrict__ t
     }
 }
 
-// Inverse passes in mirrored order down to (and including) radix-16 pass P0.  FETCH: the base twiddles are fetched from
-// `tw` where they are used (an L2 hit per pass) instead of read from W -- a kernel at its register limit does not hold W.
-template <int LOG2M, int NG, int P0, int PCUR, bool FETCH = false, class ST = NoStamp>
-__device__ __forceinline__ void fft_inverse_passes(c2* X, const FftTw<LOG2M, NG>& W, int tid, ST&& st = ST(),
-                                                   const c2* __restrict__ tw = nullptr) {
+// Inverse passes in mirrored order down to (and including) radix-16 pass P0.
+template <int LOG2M, int NG, int P0, int PCUR, class ST = NoStamp>
+__device__ __forceinline__ void fft_inverse_passes(c2* X, const FftTw<LOG2M, NG>& W, int tid, ST&& st = ST()) {
     constexpr int THREADS = (FftPlan<LOG2M>::M / 16) / NG;
     if constexpr (PCUR > P0) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             if (i) __builtin_amdgcn_sched_barrier(0);
-            c2 th;
-            if constexpr (FETCH) th = FftTw<LOG2M, NG>::template theta_at<PCUR - 1>(tw, opaque(tid) + i * THREADS);
-            else th = W.theta[PCUR - 1][i];
-            pass16_lds<LOG2M, FftPlan<LOG2M>::b0(PCUR - 1), true>(X, th, tid + i * THREADS);
+            pass16_lds<LOG2M, FftPlan<LOG2M>::b0(PCUR - 1), true>(X, W.theta[PCUR - 1][i], tid + i * THREADS);
         }
         __syncthreads();
         st();
-        fft_inverse_passes<LOG2M, NG, P0, PCUR - 1, FETCH>(X, W, tid, st, tw);
+        fft_inverse_passes<LOG2M, NG, P0, PCUR - 1>(X, W, tid, st);
     }
 }
 
-template <int LOG2M, int NG, int P0, bool TAIL = true, bool FETCH = false, class ST = NoStamp>
-__device__ __forceinline__ void fft_inverse_to(c2* X, const FftTw<LOG2M, NG>& W, int tid, ST&& st = ST(),
-                                               const c2* __restrict__ tw = nullptr) {
+template <int LOG2M, int NG, int P0, class ST = NoStamp>
+__device__ __forceinline__ void fft_inverse_to(c2* X, const FftTw<LOG2M, NG>& W, int tid, ST&& st = ST()) {
     using P = FftPlan<LOG2M>;
     constexpr int THREADS = (P::M / 16) / NG;
-    if constexpr (P::TAIL4 && TAIL) {
+    if constexpr (P::TAIL4) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) pass4_lds<true>(X, mk(1.f, 0.f), tid + i * THREADS);
         __syncthreads();
         st();
     }
-    fft_inverse_passes<LOG2M, NG, P0, P::N16, FETCH>(X, W, tid, st, tw);
+    fft_inverse_passes<LOG2M, NG, P0, P::N16>(X, W, tid, st);
 }
 
 // The same passes for ONE group per thread with the base twiddles requested a pass ahead: `cur` is the twiddle of pass P0 (of
@@ -194,7 +187,7 @@ __device__ __forceinline__ void fft_inverse(c2* X, const c2* tw, const FftTw<LOG
 // the rest of the M-point row is zero.  Even sizes: the top radix-16 pass runs on registers (a thread's 16 points are
 // g + (M/16) r, of which r >= 8 are padding and never loaded) and only its result goes to LDS; odd sizes stage the row
 // in LDS first.  The caller must have passed a barrier since the last read of X.
-template <int LOG2M, int NG, bool TAIL = true, class ST = NoStamp>
+template <int LOG2M, int NG, class ST = NoStamp>
 __device__ __forceinline__ void fft_forward_global(c2* X, const c2* __restrict__ src, int n_valid, const c2* tw,
                                                    const FftTw<LOG2M, NG>& W, int tid, ST&& st = ST()) {
     constexpr int M = 1 << LOG2M, G = M / 16, THREADS = G / NG;
@@ -215,9 +208,8 @@ __device__ __forceinline__ void fft_forward_global(c2* X, const c2* __restrict__
         }
         __syncthreads();
         st();
-        fft_forward_from<LOG2M, NG, 1, TAIL>(X, tw, W, tid, st);
+        fft_forward_from<LOG2M, NG, 1>(X, tw, W, tid, st);
     } else {
-        static_assert(TAIL, "odd sizes run the plain sequence");
         for (int j = tid; j < M; j += THREADS) X[pidx(j)] = (j < n_valid) ? src[j] : mk(0.f, 0.f);
         __syncthreads();
         fft_forward<LOG2M, NG>(X, tw, W, tid);
