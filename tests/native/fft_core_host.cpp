@@ -217,6 +217,8 @@ static void conv_long_row(const float* u, int L, const float* tw_, const float* 
     }                                          \
     return -1
 
+extern "C" int dws_host_mirror_block(int t) { return mirror_block(t); }
+
 extern "C" int dws_host_fft(int log2m, float* data, const float* tw, int inverse) { DISPATCH(transform, data, tw, inverse); }
 
 extern "C" int dws_host_conv_row(int log2m, const float* u, int L, const float* tw, const float* twp, const float* kfa,

@@ -167,3 +167,23 @@ def test_segmented_convolution_of_rows_longer_than_the_transform(host, lg, L, Lt
     ref = np.fft.irfft(np.fft.rfft(np.concatenate([u.astype(np.float64), np.zeros(n - L)])) * np.fft.rfft(K), n=n)[:L]
     err = np.abs(out - ref).max() / np.abs(ref).max()
     assert err < 5e-6, err
+
+
+@pytest.mark.parametrize("lg", [6, 10, 12, 14])
+def test_partner_of_a_position_sits_in_the_mirror_block(host, lg):
+    """The pair stage couples frequency k with M - k.  In the bit-reversed layout the partner of position 16 t + r is
+    position 16 t' + 15 - r with t' = mirror_block(t) = 3 msb(t) - 1 - t (block 0 pairs inside itself): the index fact the
+    fused tail pass (`pass_tail_pointwise`) is built on -- a thread holds the r3 = 0 half of block t and the r3 = 1 half of
+    block t' and finds all eight pairs (x[e], x[15 - e]) in its registers."""
+    M = 1 << lg
+    host.dws_host_mirror_block.restype = ctypes.c_int
+    for t in range(1, M // 16):
+        tm = host.dws_host_mirror_block(t)
+        assert host.dws_host_mirror_block(tm) == t and (tm == t) == (t == 1)
+        for r in range(16):
+            k = _brev(16 * t + r, lg)
+            assert _brev((M - k) % M, lg) == 16 * tm + 15 - r
+    # block 0: k = 0 and M/2 (positions 0, 1) are their own partners, the rest pairs inside the block
+    inside = {r: _brev((M - _brev(r, lg)) % M, lg) for r in range(16)}
+    assert inside[0] == 0 and inside[1] == 1
+    assert {r: inside[r] for r in (2, 4, 6, 8, 10, 12, 14)} == {2: 3, 4: 7, 6: 5, 8: 15, 10: 13, 12: 11, 14: 9}
