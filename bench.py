@@ -498,6 +498,13 @@ def spawn_ranks(n):
         sys.exit(rc)
 
 
+DTYPE_NAMES = {
+    "f32": "f32",
+    "bf16x3": "bf16x3 split (hi/lo bf16 MFMA inputs, fp32 accumulate; ~1e-5 rel)",
+    "bf16x6": "f32-equivalent (3-term bf16 split, 6 products, fp32 accumulate)",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -505,8 +512,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="wnet_h256_d36_T200", choices=list(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
-                    help="WaveNet matrix arithmetic: exact-f32 MFMA (default) or the 3-term bf16 split")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"],
+                    help="WaveNet matrix arithmetic: exact-f32 MFMA (default); bf16x6 = fp32-equivalent 3-term bf16 split "
+                         "(six products, Winograd form); bf16x3 = 2-term split (~1e-5, narrower than fp32)")
     ap.add_argument("--mode", default="sample", choices=["sample", "train"],
                     help="sample: the headline reverse-diffusion step; train: one DP training step "
                          "(forward_train + backward + RCCL gradient all-reduce + Adam)")
@@ -705,7 +713,7 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
         "metric": "audio samples/sec (generate.py-style reverse-diffusion sampling, T=%d)" % T,
         "value": value, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "bf16x3 split (hi/lo bf16 MFMA inputs, fp32 accumulate; ~1e-5 rel)", "data": "synthetic (seeded reference initialisers, x_T ~ N(0,1))",
+        "dtype": DTYPE_NAMES[args.precision], "data": "synthetic (seeded reference initialisers, x_T ~ N(0,1))",
         "config": {"workload": args.config, "backbone": cfg["model"]["_name_"], "batch_per_gpu": B, "L": L, "T": T,
                    "parallelism": "independent clips per GPU, no collective",
                    "sampler": "hipGraph replay, on-device Philox noise"},
@@ -742,7 +750,7 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
         # dominant kernel: the fused residual layer.  Timed with HIP events on its own
         # launch stream inside the engine (eager launches, outside any capture).
         flops, bytes_ = layer_algorithmic_work(cfg)
-        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.precision]
         # every launch position of a step takes its MEDIAN over five eager steps (the first eager step after graph replays
         # runs with cold caches and lazily created events: averaged in, it put this leg 1.5 % above the launch durations
         # rocprof sees inside the timed replays)
@@ -760,14 +768,15 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
             lib.dws_profile_disable()
             step_ms = tot_ms.value / max(n_launch.value, 1) * NLAY
         avg_ms = step_ms / NLAY
-        wino = args.precision == "f32" and os.environ.get("DWS_WN_DIRECT") is None
+        wino = (args.precision == "f32" and os.environ.get("DWS_WN_DIRECT") is None) or args.precision == "bf16x6"
         # `achieved` / `frac` are priced on the flops the kernel EXECUTES (frac <= 1 by construction): the Winograd
         # F(2,3) form does 8 C^2 instead of 12 C^2 flop per position for the convolution.  The direct-convolution
         # algorithmic flops of SURVEY.md 8(d) over the same time are reported beside it as `effective_*`.
         executed = wino_executed_work(cfg) if wino else flops
         ach = executed / (avg_ms * 1e-3) / 1e12
         eff = flops / (avg_ms * 1e-3) / 1e12
-        kname = ("wn_layer_wino_kernel" if wino else "wn_layer_mfma_kernel") if args.precision == "f32" else "wn_layer_bf16x3_kernel"
+        kname = {"f32": "wn_layer_wino_kernel" if wino else "wn_layer_mfma_kernel", "bf16x3": "wn_layer_bf16x3_kernel",
+                 "bf16x6": "wn_layer_bx6_kernel"}[args.precision]
         traffic, traffic_note = None, None
         if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and args.precision == "f32":
             # PMC-derived HBM bytes per launch of this kernel (tools/r04_traffic.sh: rocprofv3 in separate --pmc passes on
@@ -827,19 +836,43 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
                 "algorithmic_bytes_per_step": fc_bytes}
     if (rank == 0 and world == 1 and args.precision == "f32" and cfg["model"]["_name_"] == "wavenet"
             and not args.no_roofline and extras):
-        # Additional, clearly separate measurement (NOT `value`): the opt-in bf16x3 matrix arithmetic
-        # (3-term bf16 split, fp32 accumulate, ~1e-5 relative vs the reference; tests/test_wavenet_gpu.py).
-        net.set_option("precision", "bf16x3")
-        run(max(args.warmup, 1))
-        barrier()
-        t0 = time.perf_counter()
-        run(args.steps)
-        barrier()
-        ms3 = (time.perf_counter() - t0) / args.steps * 1e3
+        # Additional, clearly separate measurements (NOT `value`): the two bf16-split arithmetics of the WaveNet layer.
+        #   bf16x6: fp32-EQUIVALENT (exact 3-term split of every operand, six products, fp32 accumulate, Winograd form);
+        #           its error against float64 is measured beside the f32 path's in tests/test_bf16x6_gpu.py
+        #   bf16x3: 2-term split, ~1e-5 relative: narrower than fp32, reported for comparison only
+        for prec in ("bf16x6", "bf16x3"):
+            net.set_option("precision", prec)
+            run(max(args.warmup, 1))
+            barrier()
+            t0 = time.perf_counter()
+            run(args.steps)
+            barrier()
+            ms3 = (time.perf_counter() - t0) / args.steps * 1e3
+            leg = {"ms_per_step": ms3, "value": B * L / (T * ms3 * 1e-3), "unit": "audio samples/s", "dtype": DTYPE_NAMES[prec]}
+            if prec == "bf16x6":
+                NLAY = cfg["model"]["num_res_layers"]
+                eager = lambda k: _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, k, seed, 0, stream))
+                st = profiled_step_ms(lib, eager, b"wn_layer", 5, NLAY)
+                if st is not None:
+                    flops, bytes_ = layer_algorithmic_work(cfg)
+                    executed = wino_executed_work(cfg)      # fp32-equivalent GEMM flops; the MFMA pipe executes 6x that in bf16
+                    avg = st / NLAY
+                    peak6 = PEAK_BF16_MFMA_TFLOPS / 6.0
+                    leg["roofline"] = {
+                        "kernel": "wn_layer_bx6_kernel<%d,%d>" % (cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
+                        "bound": "mfma", "achieved": executed / (avg * 1e-3) / 1e12, "peak": peak6, "unit": "TFLOP/s",
+                        "frac": executed / (avg * 1e-3) / 1e12 / peak6, "traffic": None, "avg_launch_ms": avg,
+                        "peak_note": "2.5 PFLOP/s dense bf16 MFMA / 6 products per fp32-equivalent multiply-add",
+                        "executed_flops_per_launch": executed, "bf16_mfma_flops_per_launch": 6 * executed,
+                        "algorithmic_bytes_per_launch": bytes_,
+                        "hbm_achieved_GBs": bytes_ / (avg * 1e-3) / 1e9, "hbm_frac": bytes_ / (avg * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                leg["note"] = ("opt-in precision=bf16x6: fp32-equivalent accuracy (error vs a float64 evaluation <= 2x the "
+                               "exact-f32 MFMA path's, tests/test_bf16x6_gpu.py); not the headline value")
+            else:
+                leg["note"] = ("opt-in precision=bf16x3 (hi/lo bf16 MFMA inputs, fp32 accumulate); max rel err vs reference "
+                               "1e-5: narrower than fp32; not the headline value")
+            result["extra_" + prec] = leg
         net.set_option("precision", "f32")
-        result["extra_bf16x3"] = {"ms_per_step": ms3, "value": B * L / (T * ms3 * 1e-3), "unit": "audio samples/s",
-                                  "note": "opt-in precision=bf16x3 (hi/lo bf16 MFMA inputs, fp32 accumulate); "
-                                          "max rel err vs reference 1e-5; not the headline value"}
     del net
     torch.cuda.empty_cache()
     return result

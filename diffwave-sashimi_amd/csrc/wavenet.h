@@ -74,6 +74,12 @@ int launch_wn_layer_bf16x3(int C, int S, const WnLayerArgs& a, hipStream_t s);
 int launch_pack_a_bf16x3(const float* w, void* out, int M, int K, hipStream_t s);
 int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, const float* bias1_all, void* Abt, int NL, int B, int C,
                             hipStream_t s);
+// bf16x6 path (wavenet_bx6.hip): Winograd F(2,3) layer on the bf16 matrix cores, 3-term split, six products
+bool wn_layer_bx6_supported(int C, int S);
+int launch_wn_layer_bx6(int C, int S, const WnLayerArgs& a, hipStream_t s);
+int launch_pack_a1_bx6(const float* w, void* out, int C, hipStream_t s);          // folded [2C][C][3] -> G0..G3 fragments, 3 terms
+int launch_pack_a_bx6(const float* w, void* out, int M, int K, hipStream_t s);    // row-major [M][K] -> fragments, 3 terms
+int launch_gemm_bx6(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
 int launch_wn_final(int S, const WnFinalArgs& a, hipStream_t s);
 
 }  // namespace dws

@@ -1,0 +1,665 @@
+// Fused WaveNet residual layer (`models/wavenet.py:82-121`) on the bf16 matrix cores at fp32-equivalent accuracy:
+// the Winograd F(2,3) form of wavenet_wino.hip (four K = C products per position PAIR (p, p+d) instead of six) with
+// every GEMM operand carried as a 3-term bf16 split and six of the nine partial products accumulated in fp32
+// (bf16_split.h: what is dropped is below a quarter of an fp32 ulp of each product).  precision = "bf16x6".
+//
+// Per tile of 32 pairs (64 positions) and all channels, C/32 waves, a wave owns one (tanh, sigmoid) row-tile pair:
+//   * raw x at the four shifts -d, 0, +d, +2d staged by LDS-DMA exactly as in wavenet_wino.hip (16-byte pieces,
+//     out-of-range shifts read 0 = the conv's zero padding; one contiguous row piece for d <= 16);
+//   * transform pass, all waves together once per chunk of KC channels: t0..t3 (fp32, the same roundings as the
+//     f32 Winograd path), each split into three bf16 terms and stored in the B-fragment order of
+//     v_mfma_f32_32x32x16_bf16: 16-byte items [k-octet][product][term][column], one conflict-free ds_read_b128 per
+//     fragment;
+//   * GEMM1: m_j = G_j t_j for the wave's two row tiles; the A fragments of G0..G3 (three bf16 terms each, packed at
+//     commit: 6 bytes per weight) stream from L2 one (k-block, product) step ahead; 12 MFMAs per step;
+//     step embedding + conv bias enter as one extra k-block per product (A = the fp32 correction row of the f32
+//     Winograd path split in registers, B = the Winograd transform of the in-range indicator: exact in bf16);
+//   * gate in registers, split, -> LDS gate tile [k-octet][term][64 columns];
+//   * GEMM2 [res; skip] = [Wr; Ws] g with the biases as an extra k-block;
+//   * epilogue: each wave transposes its row tiles through a private 8 KB LDS slot and moves them as row-major
+//     16-byte accesses: x' = (x + res) sqrt(.5) with x re-read (L2-hot: this tile staged it), skip += as load-add-store
+//     (one workgroup owns an element per layer, layers are stream-ordered).  The x / skip tiles are requested before
+//     the gate stage.  Clips whose rows are not 16-byte aligned take a per-lane dword path.
+//
+// Work per launch at C = S = 256, B = 16, L = 16000: 204.5 GFLOP of fp32-equivalent GEMM (the f32 Winograd kernel's
+// executed flops) = 1.227 PFLOP of bf16 MFMA = 0.49 ms at 2.5 PFLOP/s, against 1.30 ms at the fp32 matrix rate.
+#include <cstdlib>
+
+#include "bf16_split.h"
+#include "wavenet.h"
+#include "wn_trace.h"
+
+namespace dws {
+
+typedef float bx6_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bx_bf16x8 bx6_load_frag(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(bx_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ bx6_f32x4 bx6_load_f4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(bx6_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bx6_store_f4(bx6_f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
+}
+
+__device__ __forceinline__ float bx6_gate(float t, float s) {   // tanh(t) * sigmoid(s), see fast_gate (wavenet_kernels.hip)
+    const float tc = __builtin_amdgcn_fmed3f(t, -30.f, 30.f);
+    const float e2 = __builtin_amdgcn_exp2f(tc * 2.8853900817779268f);
+    const float en = __builtin_amdgcn_exp2f(s * -1.4426950408889634f);
+    return (e2 - 1.f) * __builtin_amdgcn_rcpf((e2 + 1.f) * (1.f + en));
+}
+
+// ---- weight packing (commit time) ----------------------------------------------------------------------------------
+// Folded dilated-conv weight [2C][C][3] -> Winograd matrices G0..G3 (the f32 path's formulas and roundings,
+// wavenet_wino.hip: wino_dconv_kernel) -> three bf16 terms in A-fragment order:
+//   out[((((mt * NKB + kb) * 4 + j) * 3 + term) * 64 + lane) * 8 + e] = term of G_j[mt*32 + (lane & 31)][kb*16 + 8*(lane >> 5) + e]
+__global__ void pack_a1_bx6_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)2 * C * C * 4) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), j = (int)((i >> 9) & 3);
+    const size_t r = i >> 11;                     // mt * NKB + kb
+    const int nkb = C / 16;
+    const int kb = (int)(r % nkb), mt = (int)(r / nkb);
+    const int o = mt * 32 + (lane & 31), c = kb * 16 + 8 * (lane >> 5) + e;
+    const float* wr = w + ((size_t)o * C + c) * 3;
+    const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+    float g;
+    if (j == 0) g = w0;
+    else if (j == 1) g = 0.5f * ((w0 + w2) + w1);
+    else if (j == 2) g = 0.5f * ((w0 + w2) - w1);
+    else g = w2;
+    __bf16 p0, p1, p2;
+    split3(g, p0, p1, p2);
+    const size_t base = ((r * 4 + j) * 3) * 512 + (size_t)lane * 8 + e;
+    out[base] = __builtin_bit_cast(unsigned short, p0);
+    out[base + 512] = __builtin_bit_cast(unsigned short, p1);
+    out[base + 1024] = __builtin_bit_cast(unsigned short, p2);
+}
+
+// Row-major fp32 W[M][K] -> out[(((mt * NKB + kb) * 3 + term) * 64 + lane) * 8 + e]
+__global__ void pack_a_bx6_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int M, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * K) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const size_t r = i >> 9;
+    const int nkb = K / 16;
+    const int kb = (int)(r % nkb), mt = (int)(r / nkb);
+    const float v = w[(size_t)(mt * 32 + (lane & 31)) * K + kb * 16 + 8 * (lane >> 5) + e];
+    __bf16 p0, p1, p2;
+    split3(v, p0, p1, p2);
+    const size_t base = (r * 3) * 512 + (size_t)lane * 8 + e;
+    out[base] = __builtin_bit_cast(unsigned short, p0);
+    out[base + 512] = __builtin_bit_cast(unsigned short, p1);
+    out[base + 1024] = __builtin_bit_cast(unsigned short, p2);
+}
+
+int launch_pack_a1_bx6(const float* w, void* out, int C, hipStream_t s) {
+    const size_t n = (size_t)2 * C * C * 4;
+    hipLaunchKernelGGL(pack_a1_bx6_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, (unsigned short*)out, C);
+    return DWS_OK;
+}
+
+int launch_pack_a_bx6(const float* w, void* out, int M, int K, hipStream_t s) {
+    DWS_CHECK(M % 32 == 0 && K % 16 == 0, DWS_ERR_UNSUPPORTED, "pack_a_bx6: M=%d K=%d", M, K);
+    const size_t n = (size_t)M * K;
+    hipLaunchKernelGGL(pack_a_bx6_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, (unsigned short*)out, M, K);
+    return DWS_OK;
+}
+
+// ---- the layer kernel ----------------------------------------------------------------------------------------------
+template <int C, int S>
+struct Bx6Tile {
+    static constexpr int WAVES = C / 32;          // one (tanh, sigmoid) tile pair per wave
+    static constexpr int NTH = WAVES * 64;
+    static constexpr int NP = 32;                 // position pairs per workgroup (64 positions)
+    static constexpr int KC = (C >= 256) ? 32 : 16;   // channels per staged chunk (between two workgroup barriers)
+    static constexpr int NCB = C / KC;
+    static constexpr int NKB = C / 16;            // k-blocks of 16 channels
+    static constexpr int MS = S / C;              // skip tiles per wave
+    static constexpr int RAW_FLOATS = KC * 4 * NP;          // one raw chunk: [row][shift][32] (or [row][128] contiguous)
+    static constexpr int BOP_BYTES = (KC / 8) * 4 * 3 * NP * 16;   // one transformed chunk: [octet][product][term][column] items
+    static constexpr int STAGE_FLOATS = 2 * RAW_FLOATS + 2 * BOP_BYTES / 4;
+    static constexpr int GATE_BYTES = (C / 8) * 3 * 64 * 16;       // gate tile: [octet][term][column] items
+    static constexpr int MAIN_FLOATS = STAGE_FLOATS > GATE_BYTES / 4 ? STAGE_FLOATS : GATE_BYTES / 4;
+    static constexpr int TR_FLOATS = 32 * 64;     // a wave's transpose slot: one row tile x 64 columns
+    static constexpr int LDS_FLOATS = MAIN_FLOATS + WAVES * TR_FLOATS;
+    static constexpr int TITEMS = (KC / 4) * NP * 2;        // transform items: (4-channel group, column, product pair)
+    static_assert(C % 32 == 0 && S % C == 0 && C % KC == 0 && KC % 16 == 0 && KC % (2 * WAVES) == 0 &&
+                  (TITEMS % NTH == 0) && LDS_FLOATS * 4 <= 163840, "channel counts");
+};
+
+template <int C, int S, bool EXTRA>
+__global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel(WnLayerArgs a, int log2d) {
+    using T = Bx6Tile<C, S>;
+    constexpr int KC = T::KC, MS = T::MS, WAVES = T::WAVES, NCB = T::NCB, NTH = T::NTH, NKB = T::NKB;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    float* const Xraw = lds;                                            // 2 raw chunks (LDS-DMA target)
+    char* const Bop = reinterpret_cast<char*>(lds + 2 * T::RAW_FLOATS); // 2 transformed chunks (B operands)
+    char* const gt = reinterpret_cast<char*>(lds);                      // gate tile (aliases the staging buffers)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int L = a.L, dil = 1 << log2d;
+    float* const trw = lds + T::MAIN_FLOATS + wave * T::TR_FLOATS;
+
+    const int nblk = (L + 2 * dil - 1) >> (log2d + 1);     // blocks of 2d
+    const int ntl = ((nblk << log2d) + 31) >> 5;           // tiles of 32 pairs per batch element
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
+    const int q0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
+    const int q = q0 + l31;                                // first-half position number of this lane's column
+    const int p = ((q >> log2d) << (log2d + 1)) + (q & (dil - 1));
+
+    const float* __restrict__ xb = a.x_in + (size_t)b * C * L;
+    unsigned long long* __restrict__ trc = a.trace ? a.trace + ((size_t)blockIdx.x * WAVES + wave) * 32 : nullptr;
+    auto stamp = [&](int i) {
+        if (trc) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) trc[i] = t;
+        }
+    };
+    stamp(0);
+
+    // ---- operands of the correction k-blocks, fetched first (their latency hides behind the first staging wait)
+    const int mt1[2] = {wave, C / 32 + wave};
+    int mt2[1 + MS];
+    mt2[0] = wave;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) mt2[1 + m] = C / 32 + wave * MS + m;
+    float av1[2][4], ab1[2], av2[1 + MS];
+    {
+        const float* Abt = a.Abt + (size_t)b * a.abt_bstride + step_row_off(a.step_idx, a.abt_tstride);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = mt1[m] * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av1[m][j] = Abt[j * 2 * C + row];
+            ab1[m] = a.bias1[row];
+        }
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m) av2[m] = a.bias2[mt2[m] * 32 + l31];
+    }
+
+    // ---- staging of raw x (wavenet_wino.hip: same three forms).  16-byte accesses need every row 16-byte aligned.
+#ifdef BX6_DBG_NO_VEC
+    const bool vec_epi = false;
+#else
+    const bool vec_epi = true;
+#endif
+    const bool al16 = (L % 4 == 0) && ((((size_t)a.x_in | (size_t)a.x_out | (size_t)a.skip) & 15) == 0);
+    const bool contig = al16 && log2d <= 4;
+    const bool x4 = contig || (al16 && log2d >= 2);
+    constexpr int RPW = KC / WAVES;                // channel rows per wave and chunk (as pairs of adjacent rows)
+    __amdgpu_buffer_rsrc_t rXall = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, C * L * 4, 0x00020000);
+    const int pbase = (q0 >> log2d) << (log2d + 1);          // first position of the tile's block (d < 32: a multiple of 64)
+    const int ob = contig ? 32 + (p - pbase) - dil : l31;    // shift s of this lane's column sits at ob + s * os in a staged row
+    const int os = contig ? dil : 32;
+    // columns of the [res; skip] GEMM: tile n = 0 the first halves, n = 1 the partners (d >= 32: two runs of 32
+    // consecutive positions); contiguous staging (d <= 16): positions [pbase, pbase+32) and [pbase+32, pbase+64), the
+    // gate tile is written in that order
+    const int x0l = p - pbase, x1l = x0l + dil;
+    const int gcol0 = contig ? x0l : l31, gcol1 = contig ? x1l : 32 + l31;
+    int voffA, voffB;
+    if (contig) {
+        const int pp = pbase - 32 + 4 * (lane & 31);
+        voffA = ((unsigned)pp < (unsigned)L) ? (lhi * L + pp) * 4 : 0x7ffffff0;
+        voffB = 0;
+    } else if (x4) {
+        const int s4 = (lane >> 3) & 3, qq = q0 + 4 * (lane & 7);
+        const int pp = ((qq >> log2d) << (log2d + 1)) + (qq & (dil - 1)) + (s4 - 1) * dil;
+        voffA = ((unsigned)pp < (unsigned)L) ? (lhi * L + pp) * 4 : 0x7ffffff0;
+        voffB = 0;
+    } else {
+        voffA = (p + (lhi - 1) * dil) * 4;
+        voffB = (p + (lhi + 1) * dil) * 4;
+    }
+    auto stage_dma = [&](int cb) {
+        float* xs = Xraw + (cb & 1) * T::RAW_FLOATS;
+#pragma unroll
+        for (int i = 0; i < RPW / 2; ++i) {
+            const int cc = 2 * (wave + WAVES * i);
+            if (x4) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rXall, xs + cc * 128, 16, voffA, (cb * KC + cc) * L * 4, 0, 0);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)(cb * KC + cc + h) * L), 0, L * 4, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + (cc + h) * 128, 4, voffA, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, xs + (cc + h) * 128 + 64, 4, voffB, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- transform pass: raw chunk c1 -> t_j = Winograd input transform, three bf16 terms each, in B-fragment order.
+    // Item = (column, group of 4 channels, product pair): 12 LDS reads, 8 transforms, 8 splits, six 8-byte writes.
+    auto transform = [&](int c1) {
+        const float* xs = Xraw + (c1 & 1) * T::RAW_FLOATS;
+        char* bo = Bop + (c1 & 1) * T::BOP_BYTES;
+#pragma unroll
+        for (int k = 0; k < T::TITEMS / NTH; ++k) {
+            const int i = tid + NTH * k;
+            const int gi = __builtin_amdgcn_readfirstlane(i >> 6);      // wave-uniform part of the item number
+            const int g4 = (gi * 2 + lhi) % (KC / 4);
+            const int jp = __builtin_amdgcn_readfirstlane((gi * 2) / (KC / 4));   // KC/4 even: both halves of a wave share jp
+            float ta[4], tb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* xr = xs + (g4 * 4 + e) * 128 + ob;
+                const float d1 = xr[os], d2 = xr[2 * os];
+                if (jp == 0) {
+                    const float d0 = xr[0];
+                    ta[e] = d0 - d2; tb[e] = d1 + d2;
+                } else {
+                    const float d3 = xr[3 * os];
+                    ta[e] = d2 - d1; tb[e] = d1 - d3;
+                }
+            }
+            bx_bf16x4 pa[3], pb[3];
+            split3x4(ta, pa[0], pa[1], pa[2]);
+            split3x4(tb, pb[0], pb[1], pb[2]);
+            char* dst = bo + ((((g4 >> 1) * 4 + 2 * jp) * 3) * 32 + l31) * 16 + (g4 & 1) * 8;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                *reinterpret_cast<bx_bf16x4*>(dst + t * 512) = pa[t];
+                *reinterpret_cast<bx_bf16x4*>(dst + (3 + t) * 512) = pb[t];
+            }
+        }
+    };
+
+    // ---- GEMM1: m_j[2C x 32] = G_j[2C x C] . t_j[C x 32], j = 0..3; this wave: row tiles `wave` and C/32 + wave
+    bx_f32x16 acc[2][4];
+    __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A1, 0, 2 * C * 4 * C * 6, 0x00020000);
+    const int lane16 = lane * 16;
+    auto load_a1 = [&](bx_bf16x8 (&dst)[2][3], int kb, int j) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dst[m][t] = bx6_load_frag(rA1, lane16, (((mt1[m] * NKB + kb) * 4 + j) * 3 + t) * 1024);
+    };
+
+    stage_dma(0);
+    if (NCB > 1) stage_dma(1);
+    bx_bf16x8 a_cur[2][3], a_nxt[2][3];
+    load_a1(a_cur, 0, 0);
+    // chunk 0 has landed (this wave's part; the barrier makes it everyone's): all but the loads issued after it -- chunk 1
+    // and the 6 A fragments.  hipcc does not make a barrier wait for LDS-DMA.
+    if (NCB > 1) {
+        if (x4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((RPW / 2 + 6) & 15) | (((RPW / 2 + 6) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * RPW + 6) & 15) | (((2 * RPW + 6) >> 4) << 14));
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+    }
+    __syncthreads();
+    stamp(1);
+    {   // correction k-block: k = 0 the step-embedding row (x the Winograd transform of the in-range indicator of the four
+        // shifts), k = 1 of product 1 the conv bias (m1 enters both outputs of a pair with +1)
+        const float v0 = ((unsigned)(p - dil) < (unsigned)L) ? 1.f : 0.f;
+        const float v1 = ((unsigned)p < (unsigned)L) ? 1.f : 0.f;
+        const float v2 = ((unsigned)(p + dil) < (unsigned)L) ? 1.f : 0.f;
+        const float v3 = ((unsigned)(p + 2 * dil) < (unsigned)L) ? 1.f : 0.f;
+        const float bi[4] = {v0 - v2, v1 + v2, v2 - v1, v1 - v3};
+        const __bf16 z = (__bf16)0.f;
+        bx_f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 b0 = (__bf16)(lhi ? 0.f : bi[j]), b1 = (__bf16)((lhi || j != 1) ? 0.f : 1.f);
+            const bx_bf16x8 bf = {b0, b1, z, z, z, z, z, z};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                bx_bf16x8 af[3];
+                frag_rank2(av1[m][j], j == 1 ? ab1[m] : 0.f, lhi == 0, af);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf, zero, 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf, acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf, acc[m][j], 0, 0, 0);
+            }
+        }
+    }
+    transform(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 6);   // chunk 1 has landed too (younger: only the 6 A fragments)
+    __syncthreads();                          // transformed chunk 0 visible, raw chunk 1 complete
+
+    constexpr int SPC = (KC / 16) * 4;        // (k-block, product) steps per chunk
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (cb + 2 < NCB) stage_dma(cb + 2);       // into the raw buffer chunk cb occupied (transformed an iteration ago)
+        if (cb + 1 < NCB) transform(cb + 1);
+        const char* tb = Bop + (cb & 1) * T::BOP_BYTES + lhi * (4 * 3 * 512) + l31 * 16;
+#pragma unroll
+        for (int st = 0; st < SPC; ++st) {
+            const int it = st >> 2, j = st & 3;
+            const int kb = cb * (KC / 16) + it;
+            int kbn = kb, jn = j + 1;
+            if (jn == 4) { jn = 0; kbn = kb + 1; }
+#ifdef BX6_DBG_REDUNDANT_LOAD
+            if (kbn >= NKB) { kbn = NKB - 1; jn = 3; }
+            load_a1(a_nxt, kbn, jn);
+#else
+            if (st + 1 < SPC || cb + 1 < NCB) load_a1(a_nxt, kbn, jn);   // (no load left in flight behind the last step)
+#endif
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole step (12 MFMAs) ahead of its use
+            bx_bf16x8 bq[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bq[t] = *reinterpret_cast<const bx_bf16x8*>(tb + ((2 * it * 4 + j) * 3 + t) * 512);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][BX6_IA[t]], bq[BX6_IB[t]], acc[m][j], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a_cur[m][t] = a_nxt[m][t];
+        }
+        stamp(8 + 2 * cb);
+        // transformed chunk cb+1 visible after the barrier; the LDS-DMA of chunk cb+2 must have landed too (hipcc does not
+        // count LDS-DMA among the accesses a barrier waits for): the only younger loads are the 6 A fragments of the next step
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+        __syncthreads();
+        stamp(9 + 2 * cb);
+    }
+    stamp(2);
+
+    // ---- x and running-skip tiles of this wave's output rows, requested before the gate stage (row-major 16-byte pieces:
+    // lane = (row lane>>4 of a group of four rows, column quad lane&15; quads 0..7 = column tile 0, 8..15 = tile 1)
+    const int L4 = L * 4;
+    const bool first = a.first_layer, last = a.last_layer;
+    __amdgpu_buffer_rsrc_t rXo = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x_out + (size_t)b * C * L), 0, C * L * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rSk = __builtin_amdgcn_make_buffer_rsrc((void*)(a.skip + (size_t)b * S * L), 0, S * L * 4, 0x00020000);
+    const int p0 = ((q0 >> log2d) << (log2d + 1)) + (q0 & (dil - 1));   // position of column 0 of tile 0 (d >= 32: q0 % 32 == 0 keeps it a multiple of 32)
+    int voff4;
+    {
+        const int n4 = (lane & 15) >> 3;
+        const int pos4 = (contig ? pbase + 32 * n4 : p0 + n4 * dil) + 4 * (lane & 7);
+        voff4 = (pos4 < L) ? ((lane >> 4) * L + pos4) * 4 : 0x7ffffff0;
+    }
+    // (S = 2C: three row tiles per wave would take 96 registers here -- those instances fetch each tile in the epilogue;
+    // they run two workgroups per CU, which cover each other's waits)
+#ifdef BX6_DBG_NO_PRELOAD
+    constexpr bool PRELOAD = false;
+#else
+    constexpr bool PRELOAD = MS == 1;
+#endif
+    // a tile that is not read (the first layer's skip, the last layer's x) asks for an offset past the buffer: reads 0
+    const int voff4x = last ? 0x7ffffff0 : voff4, voff4s = first ? 0x7ffffff0 : voff4;
+    auto load_pre = [&](int m, bx6_f32x4 (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (m == 0) dst[i] = bx6_load_f4(rXall, voff4x, (wave * 32 + 4 * i) * L4);
+            else dst[i] = bx6_load_f4(rSk, voff4s, ((wave * MS + (m - 1)) * 32 + 4 * i) * L4);
+        }
+    };
+    bx6_f32x4 pre[PRELOAD ? 1 + MS : 1][8];
+    if (PRELOAD && al16 && vec_epi) {
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m) load_pre(m, pre[PRELOAD ? m : 0]);
+#ifdef BX6_DBG_PRE_WAIT
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+    }
+
+    // ---- gate: g = tanh(H_t (+mel_t)) * sigmoid(H_s (+mel_s)) for both outputs of every pair, split -> LDS gate tile
+    const float* melb = (EXTRA && a.melc) ? a.melc + (size_t)(a.mel_bstride ? b : 0) * 2 * C * L : nullptr;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        float g0[4], g1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = qd * 4 + e;
+            const int ch = wave * 32 + e + 8 * qd + 4 * lhi;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int pos = p + n * dil;
+                float ht, hs;
+                if (n == 0) {
+                    ht = (acc[0][0][r] + acc[0][1][r]) + acc[0][2][r];
+                    hs = (acc[1][0][r] + acc[1][1][r]) + acc[1][2][r];
+                } else {
+                    ht = (acc[0][1][r] - acc[0][2][r]) - acc[0][3][r];
+                    hs = (acc[1][1][r] - acc[1][2][r]) - acc[1][3][r];
+                }
+                if (EXTRA && melb && pos < L) {
+                    ht += melb[(size_t)ch * L + pos];
+                    hs += melb[(size_t)(C + ch) * L + pos];
+                }
+                const float g = bx6_gate(ht, hs);
+                if (n == 0) g0[e] = g; else g1[e] = g;
+            }
+        }
+        bx_bf16x4 s0[3], s1[3];
+        split3x4(g0, s0[0], s0[1], s0[2]);
+        split3x4(g1, s1[0], s1[1], s1[2]);
+        char* dst = gt + ((wave * 4 + qd) * 3 * 64) * 16 + lhi * 8;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            *reinterpret_cast<bx_bf16x4*>(dst + (t * 64 + gcol0) * 16) = s0[t];
+            *reinterpret_cast<bx_bf16x4*>(dst + (t * 64 + gcol1) * 16) = s1[t];
+        }
+    }
+    stamp(3);
+
+    // ---- GEMM2: [res; skip][(C+S) x 64] = [Wr; Ws][(C+S) x C] . g[C x 64] (+ bias k-block); this wave: res tile `wave`
+    // and its skip tiles, both column tiles
+    __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 6, 0x00020000);
+    bx_bf16x8 c_cur[1 + MS][3], c_nxt[1 + MS][3];
+    auto load_a2 = [&](bx_bf16x8 (&dst)[1 + MS][3], int kb) {
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dst[m][t] = bx6_load_frag(rA2, lane16, ((mt2[m] * NKB + kb) * 3 + t) * 1024);
+    };
+    load_a2(c_cur, 0);
+    bx_f32x16 acc2[1 + MS][2];
+    {
+        const __bf16 z = (__bf16)0.f, one = (__bf16)(lhi ? 0.f : 1.f);
+        const bx_bf16x8 bf = {one, z, z, z, z, z, z, z};
+        bx_f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m) {
+            bx_bf16x8 af[3];
+            frag_rank2(av2[m], 0.f, lhi == 0, af);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf, zero, 0, 0, 0);
+                acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf, acc2[m][n], 0, 0, 0);
+                acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf, acc2[m][n], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // gate tile complete
+    stamp(4);
+    const char* gb = gt + lhi * (3 * 64 * 16) + l31 * 16;
+#pragma unroll 2
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int kbn = (kb + 1 < NKB) ? kb + 1 : kb;
+        load_a2(c_nxt, kbn);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* gk = gb + kb * (2 * 3 * 64 * 16);
+        bx_bf16x8 bq[2][3];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bq[n][t] = *reinterpret_cast<const bx_bf16x8*>(gk + (t * 64 + n * 32) * 16);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int m = 0; m < 1 + MS; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c_cur[m][BX6_IA[t]], bq[n][BX6_IB[t]], acc2[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) c_cur[m][t] = c_nxt[m][t];
+    }
+    stamp(5);
+
+    // ---- epilogue
+    const float rs = 0.70710678118654752440f;
+    if (al16 && vec_epi) {
+        // row tile by row tile through this wave's own LDS slot (no other wave touches it: no barrier), out as 16-byte rows
+#pragma unroll
+        for (int m = 0; m < 1 + MS; ++m) {
+            if (m == 0 && last) continue;   // the last layer's residual output feeds nothing (`wavenet.py:165`)
+            if (!PRELOAD) load_pre(m, pre[0]);
+#ifdef BX6_DBG_COMPARE
+            {
+                bx6_f32x4 chk[8];
+                load_pre(m, chk);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (chk[i][e] != pre[PRELOAD ? m : 0][i][e] && blockIdx.x < 8)
+                            printf("bx6 mismatch blk %d wave %d lane %d m %d i %d e %d early %g late %g d %d\n", (int)blockIdx.x, wave, lane, m, i, e,
+                                   pre[PRELOAD ? m : 0][i][e], chk[i][e], dil);
+            }
+#endif
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) trw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 64 + n * 32 + l31] = acc2[m][n][r];
+            // one wave, LDS operations of a wave execute in order: only the compiler has to be kept from moving the reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int row0 = (m == 0) ? wave * 32 : (wave * MS + (m - 1)) * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bx6_f32x4 v = *reinterpret_cast<const bx6_f32x4*>(trw + ((lane >> 4) + 4 * i) * 64 + 4 * (lane & 15));
+                bx6_f32x4 o = pre[PRELOAD ? m : 0][i] + v;
+                if (m == 0) o = o * rs;
+                bx6_store_f4(o, m == 0 ? rXo : rSk, voff4, (row0 + 4 * i) * L4);
+#ifdef BX6_DBG_STORE_NOP
+                asm volatile("s_nop %0" :: "n"(BX6_DBG_STORE_NOP) : "memory");
+#else
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+            }
+            asm volatile("" ::: "memory");   // the next row tile overwrites the slot
+        }
+    } else {
+        // rows not 16-byte aligned: per-lane dwords straight from the accumulator layout
+        int voffn[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int pos = contig ? pbase + 32 * n + l31 : p + n * dil;
+            voffn[n] = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (!last) {
+                const int s0 = (wave * 32) * L4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int so = s0 + ((r & 3) + 8 * (r >> 2)) * L4;
+                    const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rXall, voffn[n], so, 0));
+                    const float v = (x + acc2[0][n][r]) * rs;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rXo, voffn[n], so, 0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                const int s0 = ((wave * MS + m) * 32) * L4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int so = s0 + ((r & 3) + 8 * (r >> 2)) * L4;
+                    const float old = first ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rSk, voffn[n], so, 0));
+                    const float v = old + acc2[1 + m][n][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voffn[n], so, 0);
+                }
+            }
+        }
+    }
+    stamp(6);
+    if (trc) {
+        __builtin_amdgcn_s_waitcnt(0);   // everything (stores included) retired
+        stamp(7);
+    }
+}
+
+template <int C, int S>
+static int launch_bx6_t(const WnLayerArgs& a, int log2d, hipStream_t s) {
+    ProfileScope ps("wn_layer_bx6", s);
+    using T = Bx6Tile<C, S>;
+    const int dil = 1 << log2d;
+    const int nblk = (a.L + 2 * dil - 1) / (2 * dil);
+    const int ntl = (nblk * dil + 31) / 32;
+    const int ntiles = a.B * ntl;
+    static const bool trace = std::getenv("DWS_BX6_TRACE") != nullptr;
+    if (trace && !a.melc) {
+        wino_trace_launch(ntiles, T::WAVES, a, s, [&](const WnLayerArgs& at) {
+            hipLaunchKernelGGL((wn_layer_bx6_kernel<C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, at, log2d);
+        }, "bx6");
+        return DWS_OK;
+    }
+    if (a.melc) hipLaunchKernelGGL((wn_layer_bx6_kernel<C, S, true>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
+    else hipLaunchKernelGGL((wn_layer_bx6_kernel<C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
+    return DWS_OK;
+}
+
+bool wn_layer_bx6_supported(int C, int S) {
+    return (C == 64 && S == 64) || (C == 128 && S == 128) || (C == 128 && S == 256) || (C == 256 && S == 256);
+}
+
+int launch_wn_layer_bx6(int C, int S, const WnLayerArgs& a, hipStream_t s) {
+    int log2d = 0;
+    while ((1 << log2d) < a.dilation) ++log2d;
+    DWS_CHECK((1 << log2d) == a.dilation, DWS_ERR_UNSUPPORTED, "wn_layer_bx6: dilation %d is not a power of two", a.dilation);
+    DWS_CHECK((int64_t)a.L + 4 * (int64_t)a.dilation < ((int64_t)1 << 28), DWS_ERR_UNSUPPORTED, "wn_layer_bx6: L too large");
+    DWS_CHECK((int64_t)(C > S ? C : S) * a.L * 4 < ((int64_t)1 << 31), DWS_ERR_UNSUPPORTED,
+              "wn_layer_bx6: %d channels x L=%d exceed a 2 GiB tensor per clip", C > S ? C : S, a.L);
+    DWS_CHECK(a.hsave == nullptr, DWS_ERR_UNSUPPORTED, "wn_layer_bx6: the training forward runs with precision=f32");
+    if (C == 64 && S == 64) return launch_bx6_t<64, 64>(a, log2d, s);
+    if (C == 128 && S == 128) return launch_bx6_t<128, 128>(a, log2d, s);
+    if (C == 128 && S == 256) return launch_bx6_t<128, 256>(a, log2d, s);
+    if (C == 256 && S == 256) return launch_bx6_t<256, 256>(a, log2d, s);
+    return set_error(DWS_ERR_UNSUPPORTED, "wn_layer_bx6: (C=%d,S=%d) not instantiated", C, S);
+}
+
+// ---- the arithmetic alone, for the GEMM-level accuracy test: C[M][N] = A[M][K] . B[K][N], fp32 in and out, every
+// operand split in registers, one wave per 32 x 32 output tile (tests/test_bf16x6_gpu.py; not a fast GEMM)
+__global__ __launch_bounds__(64) void gemm_bx6_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm,
+                                                      int M, int N, int K) {
+    const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+    const int mt = blockIdx.y, nt = blockIdx.x;
+    bx_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kb = 0; kb < K / 16; ++kb) {
+        bx_bf16x8 af[3], bf[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kb * 16 + 8 * lhi + e;
+            __bf16 p0, p1, p2;
+            split3(A[(size_t)(mt * 32 + l31) * K + k], p0, p1, p2);
+            af[0][e] = p0; af[1][e] = p1; af[2][e] = p2;
+            split3(B[(size_t)k * N + nt * 32 + l31], p0, p1, p2);
+            bf[0][e] = p0; bf[1][e] = p1; bf[2][e] = p2;
+        }
+        mfma6(acc, af, bf);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        Cm[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * N + nt * 32 + l31] = acc[r];
+}
+
+int launch_gemm_bx6(const float* A, const float* B, float* Cm, int M, int N, int K, hipStream_t s) {
+    DWS_CHECK(M > 0 && N > 0 && K > 0 && M % 32 == 0 && N % 32 == 0 && K % 16 == 0, DWS_ERR_UNSUPPORTED,
+              "gemm_bf16x6: M=%d N=%d must be multiples of 32, K=%d of 16", M, N, K);
+    hipLaunchKernelGGL(gemm_bx6_kernel, dim3(N / 32, M / 32), dim3(64), 0, s, A, B, Cm, M, N, K);
+    return DWS_OK;
+}
+
+}  // namespace dws
+
+extern "C" int dws_gemm_bf16x6(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, void* stream) {
+    DWS_CHECK(A && B && C, DWS_ERR_INVALID, "dws_gemm_bf16x6: null argument");
+    DWS_CHECK(M <= (1 << 20) && N <= (1 << 20) && K <= (1 << 20), DWS_ERR_UNSUPPORTED, "dws_gemm_bf16x6: dimension too large");
+    return dws::launch_gemm_bx6(A, B, C, (int)M, (int)N, (int)K, (hipStream_t)stream);
+}

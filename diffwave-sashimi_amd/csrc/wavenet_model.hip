@@ -14,6 +14,7 @@ struct WaveNetModel : dws_model {
     int Cin, Cout, C, S, NL, cycle, Ein, Emid, Eout, MB;
     bool cond, mfma_layer, mfma_final;
     bool bf16x3 = false;             // precision option (see include/dws.h)
+    bool bf16x6 = false;             // precision option: 3-term split, six products, Winograd form (wavenet_bx6.hip)
     bool wino_opt = true;            // conv_algo option: Winograd F(2,3) along the dilation stride (f32 path) or direct
     // the Winograd launcher addresses a clip's [C][L] tensor through one 32-bit buffer descriptor: over-long clips
     // (L >= ~2.1 M samples at C = 256) stay on the direct kernel, which has no such bound.  prepare() marks the model
@@ -21,7 +22,9 @@ struct WaveNetModel : dws_model {
     bool wino_fits(int64_t nL) const {
         return (int64_t)std::max(C, S) * nL * 4 < ((int64_t)1 << 31) && nL + 4 * ((int64_t)1 << (cycle - 1)) < ((int64_t)1 << 28);
     }
-    bool wino() const { return wino_opt && mfma_layer && !bf16x3 && wn_layer_wino_supported(C, S) && (L == 0 || wino_fits(L)); }
+    bool wino() const { return wino_opt && mfma_layer && !bf16x3 && !bf16x6 && wn_layer_wino_supported(C, S) && (L == 0 || wino_fits(L)); }
+    // the step-embedding correction rows in the Winograd layout [4][2C] (both Winograd layer kernels read it)
+    bool wino_rows() const { return wino() || bf16x6; }
 
     // folded / packed weights
     DevBuf Wi;                       // init conv [C][Cin]
@@ -109,11 +112,17 @@ struct WaveNetModel : dws_model {
 
     int set_option(const std::string& key, const std::string& value) override {
         if (key == "precision") {
-            if (value == "f32") { bf16x3 = false; dirty = true; trained_fwd = false; return DWS_OK; }
+            if (value == "f32") { bf16x3 = bf16x6 = false; dirty = true; trained_fwd = false; return DWS_OK; }
             if (value == "bf16x3") {
                 DWS_CHECK(wn_layer_bf16x3_supported(C, S), DWS_ERR_UNSUPPORTED,
                           "precision=bf16x3 is not built for (res_channels=%d, skip_channels=%d)", C, S);
-                bf16x3 = true; dirty = true; trained_fwd = false;
+                bf16x3 = true; bf16x6 = false; dirty = true; trained_fwd = false;
+                return DWS_OK;
+            }
+            if (value == "bf16x6") {
+                DWS_CHECK(mfma_layer && wn_layer_bx6_supported(C, S), DWS_ERR_UNSUPPORTED,
+                          "precision=bf16x6 is not built for (res_channels=%d, skip_channels=%d)", C, S);
+                bf16x6 = true; bf16x3 = false; dirty = true; trained_fwd = false;
                 return DWS_OK;
             }
         }
@@ -152,7 +161,12 @@ struct WaveNetModel : dws_model {
             DWS_TRY(bias2[n].ensure((size_t)(C + S) * 4));
             stack_params.add(P(p + ".res_conv.bias"), bias2[n].f(), (size_t)C);
             stack_params.add(P(p + ".skip_conv.bias"), bias2[n].f() + C, (size_t)S);
-            if (mfma_layer) {
+            if (mfma_layer && bf16x6) {   // 3 bf16 terms per weight, packed straight from the folded weights
+                DWS_TRY(A1[n].ensure((size_t)2 * C * 4 * C * 6));
+                DWS_TRY(A2[n].ensure((size_t)(C + S) * C * 6));
+                DWS_TRY(launch_pack_a1_bx6(Wd(n), A1[n].p, C, s));
+                DWS_TRY(launch_pack_a_bx6(Wrs[n].f(), A2[n].p, C + S, C, s));
+            } else if (mfma_layer) {
                 DWS_TRY(A1[n].ensure((size_t)2 * C * 4 * C * 4));
                 if (wino()) DWS_TRY(launch_wino_dconv(Wd(n), tmp_pack.f(), C, s));
                 else DWS_TRY(launch_permute_dconv(Wd(n), tmp_pack.f(), C, bf16x3 ? WN_BX3_KC : WN_LAYER_KC, s));
@@ -327,7 +341,7 @@ struct WaveNetModel : dws_model {
 
     int forward_train(const float* audio, const float* steps, float* out, hipStream_t s) override {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
-        DWS_CHECK(!bf16x3, DWS_ERR_UNSUPPORTED, "training runs with precision=f32 (bf16x3 backward is not built)");
+        DWS_CHECK(!bf16x3 && !bf16x6, DWS_ERR_UNSUPPORTED, "training runs with precision=f32 (no bf16-split backward is built)");
         DWS_CHECK(melBm == 0 || (melBm == B && mfma_bwd), DWS_ERR_UNSUPPORTED,
                   "mel-conditional training needs one mel per clip (got %lld for B=%lld) and the MFMA adjoints (channels %% 32 == 0)",
                   (long long)melBm, (long long)B);
@@ -348,7 +362,7 @@ struct WaveNetModel : dws_model {
     const float* train_audio = nullptr;
 
     // floats of one (layer, clip) row of the step-embedding correction fragments, by layer kernel
-    int abt_row() const { return wino() ? 4 * 2 * C : (2 * C / 32) * (bf16x3 ? 512 : 256); }
+    int abt_row() const { return wino_rows() ? 4 * 2 * C : (2 * C / 32) * (bf16x3 ? 512 : 256); }
 
     // everything of the forward that depends on the diffusion step only (`wavenet.py:153-155,89`; a1, a2 of SURVEY 8):
     // embedding -> MLP -> every layer's fc_t (one stacked GEMV) -> the layer kernels' correction fragments, for `rows`
@@ -362,7 +376,7 @@ struct WaveNetModel : dws_model {
                                    1, s, pre2));
         DWS_TRY(launch_linear_rows(h2_, Wt_all.f(), bt_all.f(), pt, rows, Eout, NL * C, 0, s));
         if (mfma_layer && bf16x3) DWS_TRY(launch_wn_bias_tap_bf16(Wd_all.f(), pt, b1_all.f(), abt, NL, rows, C, s));
-        else if (wino()) DWS_TRY(launch_wn_wino_bias(Wd_all.f(), pt, (float*)abt, NL, rows, C, s));
+        else if (wino_rows()) DWS_TRY(launch_wn_wino_bias(Wd_all.f(), pt, (float*)abt, NL, rows, C, s));
         else if (mfma_layer) DWS_TRY(launch_wn_bias_tap(Wd_all.f(), pt, (float*)abt, NL, rows, C, s));
         return DWS_OK;
     }
@@ -432,6 +446,7 @@ struct WaveNetModel : dws_model {
             a.dilation = 1 << (n % cycle);
             a.first_layer = (n == 0); a.last_layer = (n == NL - 1);
             if (mfma_layer && bf16x3) DWS_TRY(launch_wn_layer_bf16x3(C, S, a, s));
+            else if (bf16x6) DWS_TRY(launch_wn_layer_bx6(C, S, a, s));
             else if (wino()) DWS_TRY(launch_wn_layer_wino(C, S, a, s));
             else if (mfma_layer) DWS_TRY(launch_wn_layer_mfma(C, S, a, s));
             else DWS_TRY(launch_wn_layer_generic(C, S, a, s));

@@ -130,6 +130,10 @@ int dws_model_update_params(dws_model* m, int32_t count, const char* const* name
  *               = "bf16x3" WaveNet residual layers on the bf16 matrix cores with a 3-term hi/lo split
  *                          (W_hi x_hi + W_hi x_lo + W_lo x_hi, fp32 accumulate): ~1e-5 relative, 5.3x the
  *                          matrix rate.  Not part of the reference surface.
+ *               = "bf16x6" WaveNet residual layers on the bf16 matrix cores at fp32-EQUIVALENT accuracy: every GEMM
+ *                          operand as an exact 3-term bf16 split (24 significand bits), the six partial products above
+ *                          2^-26 accumulated in fp32, Winograd F(2,3) form (the f32 path's algorithm and roundings).
+ *                          Inference only.  Error against a float64 evaluation: that of the f32 path.
  *   "conv_algo" = "winograd" (default) WaveNet residual layers (precision f32) with the dilated 3-tap convolution in
  *                          Winograd F(2,3) form along the dilation stride: 8 C^2 instead of 12 C^2 flop per position,
  *                          one extra fp32 rounding in the weights and in the inputs (same 1e-6 class error); the
@@ -214,6 +218,11 @@ int dws_sampler_steps(dws_model* m, float* x, const float* alpha, const float* a
  * [B][n_mels][T/hop + 1] = log(max(mel_basis . |STFT|, clip)).  All pointers are device pointers. */
 int dws_mel_spectrogram(const float* audio, int64_t B, int64_t T, const float* window, const float* mel_basis,
                         int32_t n_fft, int32_t hop, int32_t n_mels, float clip, float* out, void* stream);
+
+/* The arithmetic of precision="bf16x6" alone (accuracy tests; not a tuned GEMM): C[M][N] = A[M][K] . B[K][N], row-major
+ * fp32 device tensors, every operand split into three bf16 terms in registers, six bf16 MFMA products per term pair
+ * accumulated in fp32 -- exactly what the bf16x6 layer kernels execute per k-block.  M, N multiples of 32, K of 16. */
+int dws_gemm_bf16x6(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, void* stream);
 
 /* Timing of the dominant kernel, measured with HIP events on the stream the
  * kernel was launched on (bench.py roofline leg).  Enables per-launch event

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--algo", default="winograd")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"])
     args = ap.parse_args()
     cfg = dict(bench.CONFIGS[args.config])
     if args.batch:
@@ -28,6 +29,7 @@ def main():
     dev = torch.device("cuda:0")
     net = bench.build_model(cfg, dev)
     net.set_option("conv_algo", args.algo)
+    net.set_option("precision", args.precision)
     B, L = cfg["B"], cfg["L"]
     x = torch.randn(B, 1, L, device=dev)
     t = torch.full((B, 1), 17.0, device=dev)
@@ -52,7 +54,7 @@ def main():
         v = sorted(per[d])
         print("d=%5d  n=%3d  median %.4f ms  min %.4f  max %.4f" % (d, len(v), v[len(v) // 2], v[0], v[-1]))
         tot += sum(v) / len(v) * (NL // cyc)
-    print("sum over one forward (%d layers): %.3f ms (%s)" % (NL, tot, args.algo))
+    print("sum over one forward (%d layers): %.3f ms (%s, %s)" % (NL, tot, args.algo, args.precision))
 
 
 if __name__ == "__main__":
