@@ -176,7 +176,7 @@ def forward_gemm_flops(cfg, B):
     return flops + 2 * m["d_model"] ** 2 * L * B
 
 
-def cpu_baseline(cfg, seconds_budget=25.0, light=False):
+def cpu_baseline(cfg, seconds_budget=25.0, light=False, config_name=None):
     """The oracle (reference-equivalent PyTorch-CPU graph: conv1d per layer, weight-norm
     per call, no hoisting) timed on this box's host cores at B=1; bounded sample.
     MKL-DNN convolutions of this size get *slower* with hundreds of threads, so a few
@@ -263,7 +263,109 @@ def cpu_baseline(cfg, seconds_budget=25.0, light=False):
         t1 = one()
         out["single_thread_value"] = L / (T * t1)
         torch.set_num_threads(best)
+    if config_name is not None and per_step < 8.0:
+        out["whole_host"] = cpu_whole_host(config_name, best)
     return out
+
+
+_WHOLE_HOST_WORKER = r'''
+import json, os, sys, time
+cpus = [int(c) for c in os.environ["DWS_CPUSET"].split(",")]
+os.sched_setaffinity(0, cpus)
+os.environ["OMP_NUM_THREADS"] = str(len(cpus))
+sys.path.insert(0, os.environ["DWS_ROOT"])
+import torch
+torch.set_num_threads(len(cpus))
+import bench
+from oracle import sashimi as osa, wavenet as own
+from diffwave_sashimi_amd.models import construct_model
+cfg = bench.CONFIGS[os.environ["DWS_CONFIG"]]
+torch.manual_seed(0)
+sd = {k: v.detach() for k, v in construct_model(dict(cfg["model"])).state_dict().items()}
+L, T = cfg["L"], cfg["diffusion"]["T"]
+audio, steps = torch.randn(1, 1, L), torch.full((1, 1), float(T - 1))
+mel = torch.rand(1, 80, cfg["Tmel"]) * 13.5 - 11.5 if "Tmel" in cfg else None
+fwd = own.wavenet_forward if cfg["model"]["_name_"] == "wavenet" else osa.sashimi_forward
+def one():
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        fwd(sd, cfg["model"], audio, steps, mel_spec=mel)
+    return time.perf_counter() - t0
+one()
+open(os.environ["DWS_READY"], "w").close()                    # warmed up: wait for the common start
+while not os.path.exists(os.environ["DWS_GO"]):
+    time.sleep(0.01)
+ts = [one() for _ in range(int(os.environ["DWS_NSTEPS"]))]
+print(json.dumps({"steps_s": ts}))
+'''
+
+
+def _physical_cores():
+    """One logical CPU per physical core (SMT siblings dropped), from /proc/cpuinfo; all logical CPUs if that fails."""
+    try:
+        seen, cur = {}, {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                seen.setdefault((cur.get("physical id"), cur.get("core id")), int(cur["processor"]))
+                cur = {}
+        if cur:
+            seen.setdefault((cur.get("physical id"), cur.get("core id")), int(cur["processor"]))
+        allowed = os.sched_getaffinity(0)
+        cores = sorted(c for c in seen.values() if c in allowed)
+        return cores or sorted(allowed)
+    except Exception:   # noqa: BLE001
+        return sorted(os.sched_getaffinity(0))
+
+
+def cpu_whole_host(config_name, threads, nsteps=2):
+    """BASELINE.md section 2's CPU figure: the WHOLE host, as N concurrent B = 1 workers of `threads` threads each, every
+    worker pinned to its own physical cores (one process of hundreds of threads is slower than 16: MKL-DNN's convolutions
+    of this size do not scale).  All workers warm up, start their timed steps together, and the aggregate rate is
+    N x L / (T x the slowest worker's mean step)."""
+    import subprocess
+    import tempfile
+    cores = _physical_cores()
+    n = max(1, len(cores) // threads)
+    cfg = CONFIGS[config_name]
+    L, T = cfg["L"], cfg["diffusion"]["T"]
+    tmp = tempfile.mkdtemp(prefix="dws_whole_host_")
+    go = os.path.join(tmp, "go")
+    procs = []
+    for w in range(n):
+        cs = cores[w * threads:(w + 1) * threads]
+        env = dict(os.environ, DWS_CPUSET=",".join(map(str, cs)), DWS_ROOT=ROOT, DWS_CONFIG=config_name,
+                   DWS_READY=os.path.join(tmp, "ready%d" % w), DWS_GO=go, DWS_NSTEPS=str(nsteps))
+        procs.append(subprocess.Popen([sys.executable, "-c", _WHOLE_HOST_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    t0 = time.perf_counter()
+    try:
+        while not all(os.path.exists(os.path.join(tmp, "ready%d" % w)) for w in range(n)):
+            if time.perf_counter() - t0 > 240 or any(p.poll() not in (None, 0) for p in procs):
+                raise RuntimeError("a whole-host worker did not come up: " + "; ".join((p.stderr.read() or "")[-300:]
+                                                                                       for p in procs if p.poll() not in (None, 0)))
+            time.sleep(0.05)
+        open(go, "w").close()
+        means = []
+        for p in procs:
+            o, e = p.communicate(timeout=600)
+            if p.returncode != 0:
+                raise RuntimeError(e[-500:])
+            ts = json.loads(o.strip().splitlines()[-1])["steps_s"]
+            means.append(sum(ts) / len(ts))
+    except Exception as e:   # noqa: BLE001 -- reported in the line, the headline survives
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    slow = max(means)
+    return {"value": n * L / (T * slow), "unit": "audio samples/s", "workers": n, "threads_per_worker": threads,
+            "cores": n * threads, "physical_cores": len(cores), "steps_per_worker": nsteps,
+            "ms_per_step_b1_slowest_worker": slow * 1e3, "ms_per_step_b1_fastest_worker": min(means) * 1e3,
+            "sample": "%d concurrent B=1 workers x %d threads, each pinned to its own physical cores; %d forward steps each "
+                      "after a warm-up, common start; rate = workers x L / (T x slowest worker's mean step)" % (n, threads, nsteps)}
 
 
 def cpu_train_baseline(cfg, seconds_budget=30.0):
@@ -366,6 +468,11 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
     per_rank_param_digest = ddist.gather_over_ranks(digest, red_dev)
     ms = elapsed / args.steps * 1e3
     dp_overhead = None
+    if world > 1:      # the exchange as the last timed step saw it, per rank: first bucket launch -> last wait()
+        red = net._dws_grad_reducer
+        dp_overhead = {"allreduce_ms_per_rank": ddist.gather_over_ranks(float(red.allreduce_ms() or 0.0), red_dev),
+                       "buckets": len(red.buckets), "bucket_mbytes": [b.flat.numel() * 4 / 2 ** 20 for b in red.buckets],
+                       "gradient_slots": red.last_stats}
     if world == 1 and not ddist.dist.is_initialized() and os.environ.get("DWS_BENCH_NO_DP_OVERHEAD") is None:
         # What data parallelism adds to ONE rank's step besides the wire time: the same steps inside a 1-rank RCCL group
         # (apply_gradient_allreduce: gradients written into the flat buckets, hooks, bucketed asynchronous all-reduces,
@@ -387,7 +494,9 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
             red = net._dws_grad_reducer
             dp_overhead = {"dp_overhead_ms": ms_pg - ms, "ms_per_step_in_1rank_rccl_group": ms_pg, "ms_per_step_plain": ms,
                            "buckets": len(red.buckets), "bucket_mbytes": [b.flat.numel() * 4 / 2 ** 20 for b in red.buckets],
-                           "gradient_slots": red.last_stats}
+                           "gradient_slots": red.last_stats,
+                           # first bucket launch -> last wait() of the last step (HIP events on the gradients' stream)
+                           "allreduce_ms": red.allreduce_ms()}
             red.remove()
             del net._dws_grad_reducer
         except Exception as e:      # noqa: BLE001 -- reported in the line
@@ -560,8 +669,11 @@ def main():
         # A failing leg must not take the headline line with it: it is reported as an error string instead.
         result["extra_configs"] = extra_legs(args, world, rank, dev, ddist, red_dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg)
+        result["cpu_baseline"] = cpu_baseline(cfg, config_name=None if args.batch else args.config)
         result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        wh = result["cpu_baseline"].get("whole_host") or {}
+        if "value" in wh:      # against ALL physical cores of the host, not the best single process
+            result["gpu_over_cpu_whole_host"] = result["value"] / wh["value"]
     if rank == 0:
         print(json.dumps(result))
     ddist.barrier()   # rank 0's roofline / extra legs are done: every rank leaves the process group together

@@ -269,6 +269,10 @@ int dws_model_read_tap(dws_model* m, const char* tap, float* dst, int64_t capaci
         const int64_t n = m->B * m->d.out_channels * m->L;
         DWS_CHECK(m->smp_eps.p && capacity >= n, DWS_ERR_INVALID, "tap sampler_eps: no sampler step has run, or capacity %lld < %lld",
                   (long long)capacity, (long long)n);
+        // the buffer is sized by the last sampler step: after a prepare() to a larger shape it no longer matches
+        DWS_CHECK(m->smp_eps.bytes >= (size_t)n * 4 && m->smp_eps_B == m->B && m->smp_eps_L == m->L, DWS_ERR_STATE,
+                  "tap sampler_eps: the last sampler step ran at B=%lld L=%lld, the model is prepared for B=%lld L=%lld",
+                  (long long)m->smp_eps_B, (long long)m->smp_eps_L, (long long)m->B, (long long)m->L);
         DWS_HIP(hipMemcpyAsync(dst, m->smp_eps.p, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
         return DWS_OK;
     }

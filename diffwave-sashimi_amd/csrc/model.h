@@ -103,6 +103,7 @@ struct dws_model {
     std::vector<float> smp_host_tables;  // host copy of what is resident (upload skipped when identical)
     dws::DevBuf smp_state;    // int32 step index
     dws::DevBuf smp_eps;      // eps[B, Cout, L]
+    int64_t smp_eps_B = 0, smp_eps_L = 0;   // shape of the sampler step that last wrote it
     const int* step_idx = nullptr;   // set by the sampler around forward(): step-table mode, row *step_idx (device memory)
     hipGraphExec_t smp_graph = nullptr;
     hipStream_t smp_stream = nullptr;  // capture/replay stream (the caller's may be the null stream)

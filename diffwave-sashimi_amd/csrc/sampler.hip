@@ -143,6 +143,7 @@ static int run_steps(dws_model* m, float* x, int T, int t_start, int n_steps, co
     if (m->dirty) DWS_TRY(m->commit(s));
     const size_t n = (size_t)m->B * m->d.out_channels * m->L;
     DWS_TRY(m->smp_eps.ensure(n * 4));
+    m->smp_eps_B = m->B; m->smp_eps_L = m->L;
     DWS_TRY(m->build_step_table(T, s));   // step-only part of the network for t = 0..T-1 (kept while weights and T stay)
     int* t_dev = static_cast<int*>(m->smp_state.p);
 

@@ -364,6 +364,7 @@ struct SashimiModel : dws_model {
                 DWS_TRY(ensure_rocfft_stage(st));
             } else if (fits && st->force_rocfft) {   // the `L` buffers were re-sent with shorter kernels: back to the segmented path
                 st->force_rocfft = false;
+                st->rocfft = false;           // (build_kernel sets it again if a block of the stage still needs the fallback)
                 st->seg = true;
                 drop_graph();
                 DWS_TRY(st->y.ensure((size_t)B * st->H * st->L * 4));
@@ -1350,6 +1351,18 @@ struct SashimiModel : dws_model {
             DWS_TRY(scratch_out.ensure((size_t)B * Cout * L * 4));
             return final_stage(last_x, scratch_out.f(), dst, s);
         }
+        // function-level taps: the step embedding, the embedding MLP's output and the stacked
+        // fc_t rows of the last per-clip forward; the network's final TransposedLayerNorm (`sashimi.py:309`)
+        struct { const char* name; const DevBuf* buf; size_t n; } small[] = {
+            {"emb", &emb, (size_t)B * Ein}, {"emb_mlp", &h2, (size_t)B * Eout}, {"part_t", &part_t, (size_t)B * pt_total},
+            {"nfin", &nfin, last_x ? (size_t)B * D * L : 0}};
+        for (auto& e : small)
+            if (t == e.name) {
+                DWS_CHECK(e.buf->p && e.n > 0 && capacity >= (int64_t)e.n, DWS_ERR_INVALID, "tap '%s': %zu floats, capacity %lld",
+                          tap, e.n, (long long)capacity);
+                DWS_HIP(hipMemcpyAsync(dst, e.buf->p, e.n * 4, hipMemcpyDeviceToDevice, s));
+                return DWS_OK;
+            }
         if (t.rfind("k:", 0) == 0) {  // S4 kernel of the block with this prefix: L * k, k = [2][H][L] (s4.py:796-805)
             if (dirty) DWS_TRY(commit(s));
             for (auto* l : all)

@@ -24,6 +24,7 @@
 // Work per launch at C = S = 256, B = 16, L = 16000: 204.5 GFLOP of fp32-equivalent GEMM (the f32 Winograd kernel's
 // executed flops) = 1.227 PFLOP of bf16 MFMA = 0.49 ms at 2.5 PFLOP/s, against 1.30 ms at the fp32 matrix rate.
 #include <cstdlib>
+#include <type_traits>
 
 #include "bf16_split.h"
 #include "wavenet.h"
@@ -31,17 +32,29 @@
 
 namespace dws {
 
+#ifndef BX6_T_PER_MFMA
+#define BX6_T_PER_MFMA 7   // transform instructions dealt out behind each MFMA of a chunk's first step
+#endif
+
 typedef float bx6_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bx_bf16x8 bx6_load_frag(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(bx_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// The activation streams (x in, x' out, running skip in / out: each element touched once per launch, 1 GB in all) carry the
+// nontemporal policy so that they do not push the weight fragments -- 3.75 MB that every tile re-reads -- out of the
+// 4 MB L2 of an XCD.
+#ifdef BX6_ABL_NO_NT
+#define BX6_NT 0
+#else
+#define BX6_NT 2
+#endif
 __device__ __forceinline__ bx6_f32x4 bx6_load_f4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(bx6_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return __builtin_bit_cast(bx6_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, BX6_NT));
 }
 __device__ __forceinline__ void bx6_store_f4(bx6_f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, BX6_NT);
 }
 
 __device__ __forceinline__ float bx6_gate(float t, float s) {   // tanh(t) * sigmoid(s), see fast_gate (wavenet_kernels.hip)
@@ -185,11 +198,6 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     }
 
     // ---- staging of raw x (wavenet_wino.hip: same three forms).  16-byte accesses need every row 16-byte aligned.
-#ifdef BX6_DBG_NO_VEC
-    const bool vec_epi = false;
-#else
-    const bool vec_epi = true;
-#endif
     const bool al16 = (L % 4 == 0) && ((((size_t)a.x_in | (size_t)a.x_out | (size_t)a.skip) & 15) == 0);
     const bool contig = al16 && log2d <= 4;
     const bool x4 = contig || (al16 && log2d >= 2);
@@ -217,13 +225,23 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         voffA = (p + (lhi - 1) * dil) * 4;
         voffB = (p + (lhi + 1) * dil) * 4;
     }
-    auto stage_dma = [&](int cb) {
-        float* xs = Xraw + (cb & 1) * T::RAW_FLOATS;
+    // The K loop visits the channel chunks in an order ROTATED by the tile number: workgroups that run in lockstep on the
+    // CUs of an XCD then ask the L2 for different parts of the weight matrices at any moment (every tile streams all of
+    // A1 / A2, 3.75 MB at C = 256, and that stream -- not the MFMAs -- bounds GEMM1)
+#ifdef BX6_ABL_NO_ROT
+    const int rot = 0;
+#else
+    const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) % NCB));
+#endif
+    auto chunk_of = [&](int cb) { const int c = cb + rot; return c >= NCB ? c - NCB : c; };
+    auto stage_dma = [&](int cbi) {
+        float* xs = Xraw + (cbi & 1) * T::RAW_FLOATS;
+        const int cb = chunk_of(cbi);
 #pragma unroll
         for (int i = 0; i < RPW / 2; ++i) {
             const int cc = 2 * (wave + WAVES * i);
             if (x4) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rXall, xs + cc * 128, 16, voffA, (cb * KC + cc) * L * 4, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rXall, xs + cc * 128, 16, voffA, (cb * KC + cc) * L * 4, 0, BX6_NT);
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -269,6 +287,21 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
                 *reinterpret_cast<bx_bf16x4*>(dst + (3 + t) * 512) = pb[t];
             }
         }
+        // The residual x of this wave's 32 output rows passes through the staging buffers exactly once: the wave keeps a
+        // copy in its (until the epilogue unused) transpose slot, row-major [row][64 columns] as the epilogue reads it --
+        // shifts 0 and +d of a staged row sit at floats 32..95 in both staging forms.  No second read of x from memory.
+        if (al16) {
+            const int ch0 = chunk_of(c1) * KC;
+            if (ch0 / 32 == wave) {
+                const int r0 = ch0 % 32;
+#pragma unroll
+                for (int i = 0; i < KC / 4; ++i) {
+                    const int rr = (lane >> 4) + 4 * i;
+                    const bx6_f32x4 v = *reinterpret_cast<const bx6_f32x4*>(xs + rr * 128 + 32 + 4 * (lane & 15));
+                    *reinterpret_cast<bx6_f32x4*>(trw + (r0 + rr) * 64 + 4 * (lane & 15)) = v;
+                }
+            }
+        }
     };
 
     // ---- GEMM1: m_j[2C x 32] = G_j[2C x C] . t_j[C x 32], j = 0..3; this wave: row tiles `wave` and C/32 + wave
@@ -285,7 +318,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     stage_dma(0);
     if (NCB > 1) stage_dma(1);
     bx_bf16x8 a_cur[2][3], a_nxt[2][3];
-    load_a1(a_cur, 0, 0);
+    load_a1(a_cur, chunk_of(0) * (KC / 16), 0);
     // chunk 0 has landed (this wave's part; the barrier makes it everyone's): all but the loads issued after it -- chunk 1
     // and the 6 A fragments.  hipcc does not make a barrier wait for LDS-DMA.
     if (NCB > 1) {
@@ -326,36 +359,64 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     __syncthreads();                          // transformed chunk 0 visible, raw chunk 1 complete
 
     constexpr int SPC = (KC / 16) * 4;        // (k-block, product) steps per chunk
-    for (int cb = 0; cb < NCB; ++cb) {
-        if (cb + 2 < NCB) stage_dma(cb + 2);       // into the raw buffer chunk cb occupied (transformed an iteration ago)
-        if (cb + 1 < NCB) transform(cb + 1);
+    // One (k-block, product) step: prefetch of the next step's A fragments, three B fragments from LDS, 12 MFMAs.
+    // WITH_T: the transform pass of the NEXT chunk rides in this step's MFMA stream -- its ~80 VALU / LDS instructions are
+    // dealt out between the 12 MFMAs (an MFMA holds the matrix pipe for 32 cycles; the wave issues other work meanwhile)
+    // instead of standing in front of them with the matrix pipe idle (both waves of a SIMD reach it at the same time).
+    auto do_step = [&](int cb, auto ST, auto WITH_T) {
+        constexpr int st = decltype(ST)::value;
+        constexpr bool with_t = decltype(WITH_T)::value;
+        constexpr int it = st >> 2, j = st & 3;
+        int itn = it, jn = j + 1, cbn = cb;
+        if (jn == 4) { jn = 0; ++itn; }
+        if (itn == KC / 16) { itn = 0; ++cbn; }
         const char* tb = Bop + (cb & 1) * T::BOP_BYTES + lhi * (4 * 3 * 512) + l31 * 16;
+        if (st + 1 < SPC || cb + 1 < NCB) load_a1(a_nxt, chunk_of(cbn) * (KC / 16) + itn, jn);   // (no load left in flight behind the last step)
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole step (12 MFMAs) ahead of its use
+        bx_bf16x8 bq[3];
 #pragma unroll
-        for (int st = 0; st < SPC; ++st) {
-            const int it = st >> 2, j = st & 3;
-            const int kb = cb * (KC / 16) + it;
-            int kbn = kb, jn = j + 1;
-            if (jn == 4) { jn = 0; kbn = kb + 1; }
-#ifdef BX6_DBG_REDUNDANT_LOAD
-            if (kbn >= NKB) { kbn = NKB - 1; jn = 3; }
-            load_a1(a_nxt, kbn, jn);
-#else
-            if (st + 1 < SPC || cb + 1 < NCB) load_a1(a_nxt, kbn, jn);   // (no load left in flight behind the last step)
-#endif
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole step (12 MFMAs) ahead of its use
-            bx_bf16x8 bq[3];
+        for (int t = 0; t < 3; ++t) bq[t] = *reinterpret_cast<const bx_bf16x8*>(tb + ((2 * it * 4 + j) * 3 + t) * 512);
+        if (with_t) transform(cb + 1);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) bq[t] = *reinterpret_cast<const bx_bf16x8*>(tb + ((2 * it * 4 + j) * 3 + t) * 512);
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][BX6_IA[t]], bq[BX6_IB[t]], acc[m][j], 0, 0, 0);
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][BX6_IA[t]], bq[BX6_IB[t]], acc[m][j], 0, 0, 0);
+#ifndef BX6_ABL_NO_INTERLEAVE
+        if (with_t) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) a_cur[m][t] = a_nxt[m][t];
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x302, BX6_T_PER_MFMA, 0);   // then VALU / DS read / DS write of the transform
+            }
         }
+#endif
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a_cur[m][t] = a_nxt[m][t];
+    };
+    auto do_steps_from1 = [&](int cb) {
+        if constexpr (SPC == 4) {
+            do_step(cb, std::integral_constant<int, 1>{}, std::false_type{});
+            do_step(cb, std::integral_constant<int, 2>{}, std::false_type{});
+            do_step(cb, std::integral_constant<int, 3>{}, std::false_type{});
+        } else {
+            do_step(cb, std::integral_constant<int, 1>{}, std::false_type{});
+            do_step(cb, std::integral_constant<int, 2>{}, std::false_type{});
+            do_step(cb, std::integral_constant<int, 3>{}, std::false_type{});
+            do_step(cb, std::integral_constant<int, 4>{}, std::false_type{});
+            do_step(cb, std::integral_constant<int, 5>{}, std::false_type{});
+            do_step(cb, std::integral_constant<int, 6>{}, std::false_type{});
+            do_step(cb, std::integral_constant<int, 7>{}, std::false_type{});
+        }
+    };
+    static_assert(SPC == 4 || SPC == 8, "steps per chunk");
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (cb + 2 < NCB) stage_dma(cb + 2);       // into the raw buffer chunk cb occupied (transformed an iteration ago)
+        if (cb + 1 < NCB) do_step(cb, std::integral_constant<int, 0>{}, std::true_type{});
+        else do_step(cb, std::integral_constant<int, 0>{}, std::false_type{});
+        do_steps_from1(cb);
         stamp(8 + 2 * cb);
         // transformed chunk cb+1 visible after the barrier; the LDS-DMA of chunk cb+2 must have landed too (hipcc does not
         // count LDS-DMA among the accesses a barrier waits for): the only younger loads are the 6 A fragments of the next step
@@ -380,27 +441,20 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     }
     // (S = 2C: three row tiles per wave would take 96 registers here -- those instances fetch each tile in the epilogue;
     // they run two workgroups per CU, which cover each other's waits)
-#ifdef BX6_DBG_NO_PRELOAD
-    constexpr bool PRELOAD = false;
-#else
     constexpr bool PRELOAD = MS == 1;
-#endif
     // a tile that is not read (the first layer's skip, the last layer's x) asks for an offset past the buffer: reads 0
-    const int voff4x = last ? 0x7ffffff0 : voff4, voff4s = first ? 0x7ffffff0 : voff4;
+    const int voff4s = first ? 0x7ffffff0 : voff4;
     auto load_pre = [&](int m, bx6_f32x4 (&dst)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (m == 0) dst[i] = bx6_load_f4(rXall, voff4x, (wave * 32 + 4 * i) * L4);
+            if (m == 0) dst[i] = *reinterpret_cast<const bx6_f32x4*>(trw + ((lane >> 4) + 4 * i) * 64 + 4 * (lane & 15));
             else dst[i] = bx6_load_f4(rSk, voff4s, ((wave * MS + (m - 1)) * 32 + 4 * i) * L4);
         }
     };
     bx6_f32x4 pre[PRELOAD ? 1 + MS : 1][8];
-    if (PRELOAD && al16 && vec_epi) {
+    if (PRELOAD && al16) {
 #pragma unroll
-        for (int m = 0; m < 1 + MS; ++m) load_pre(m, pre[PRELOAD ? m : 0]);
-#ifdef BX6_DBG_PRE_WAIT
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
+        for (int m = 1; m < 1 + MS; ++m) load_pre(m, pre[PRELOAD ? m : 0]);
     }
 
     // ---- gate: g = tanh(H_t (+mel_t)) * sigmoid(H_s (+mel_s)) for both outputs of every pair, split -> LDS gate tile
@@ -453,7 +507,9 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
 #pragma unroll
             for (int t = 0; t < 3; ++t) dst[m][t] = bx6_load_frag(rA2, lane16, ((mt2[m] * NKB + kb) * 3 + t) * 1024);
     };
-    load_a2(c_cur, 0);
+    const int rot2 = rot * (KC / 16);          // the same rotation of the k-block order in GEMM2
+    auto kblock_of = [&](int kb) { const int k = kb + rot2; return k >= NKB ? k - NKB : k; };
+    load_a2(c_cur, kblock_of(0));
     bx_f32x16 acc2[1 + MS][2];
     {
         const __bf16 z = (__bf16)0.f, one = (__bf16)(lhi ? 0.f : 1.f);
@@ -479,9 +535,9 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
 #pragma unroll 2
     for (int kb = 0; kb < NKB; ++kb) {
         const int kbn = (kb + 1 < NKB) ? kb + 1 : kb;
-        load_a2(c_nxt, kbn);
+        load_a2(c_nxt, kblock_of(kbn));
         __builtin_amdgcn_sched_barrier(0);
-        const char* gk = gb + kb * (2 * 3 * 64 * 16);
+        const char* gk = gb + kblock_of(kb) * (2 * 3 * 64 * 16);
         bx_bf16x8 bq[2][3];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -503,25 +559,13 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
 
     // ---- epilogue
     const float rs = 0.70710678118654752440f;
-    if (al16 && vec_epi) {
+    if (al16) {
         // row tile by row tile through this wave's own LDS slot (no other wave touches it: no barrier), out as 16-byte rows
 #pragma unroll
         for (int m = 0; m < 1 + MS; ++m) {
             if (m == 0 && last) continue;   // the last layer's residual output feeds nothing (`wavenet.py:165`)
-            if (!PRELOAD) load_pre(m, pre[0]);
-#ifdef BX6_DBG_COMPARE
-            {
-                bx6_f32x4 chk[8];
-                load_pre(m, chk);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (chk[i][e] != pre[PRELOAD ? m : 0][i][e] && blockIdx.x < 8)
-                            printf("bx6 mismatch blk %d wave %d lane %d m %d i %d e %d early %g late %g d %d\n", (int)blockIdx.x, wave, lane, m, i, e,
-                                   pre[PRELOAD ? m : 0][i][e], chk[i][e], dil);
-            }
-#endif
+            if (!PRELOAD || m == 0) load_pre(m, pre[0]);      // (m = 0: the x rows out of the wave's own slot, before it is overwritten)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -535,11 +579,12 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
                 bx6_f32x4 o = pre[PRELOAD ? m : 0][i] + v;
                 if (m == 0) o = o * rs;
                 bx6_store_f4(o, m == 0 ? rXo : rSk, voff4, (row0 + 4 * i) * L4);
-#ifdef BX6_DBG_STORE_NOP
-                asm volatile("s_nop %0" :: "n"(BX6_DBG_STORE_NOP) : "memory");
-#else
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
+                // gfx950 hazard, found by the bit-for-bit determinism test: a VALU write (here the next v_pk_add / v_pk_mul) to
+                // the data registers of a 16-byte buffer store in the slot right behind it changes what the store writes
+                // for the last lanes of each 16-lane group (their last dword) -- hipcc's hazard recognizer leaves the wait
+                // state out when the store carries an SGPR offset.  One wait state removes it (measured: 0 -> wrong in
+                // 2 of 3 runs, 1 / 2 / 4 / 16 -> never); two are kept.
+                asm volatile("s_nop 1" ::: "memory");
             }
             asm volatile("" ::: "memory");   // the next row tile overwrites the slot
         }

@@ -684,7 +684,8 @@ __global__ __launch_bounds__(256, 2) void wn_final_mfma_kernel(WnFinalArgs a) {
     // the skip tile [S][P]: 16-byte LDS-DMA when the rows allow it (one instruction = 256 consecutive floats of the tile =
     // 256 / P whole rows; columns past L get an out-of-range offset and read 0) -- no VALU, no VGPRs, a quarter of the
     // instructions; the 1/sqrt(n_layers) factor then sits in the packed weights (af_scaled).  Otherwise a dword loop.
-    if ((L & 3) == 0 && (((size_t)sk & 15) == 0) && (a.af_scaled || a.scale == 1.f)) {
+    // (one 32-bit buffer descriptor spans a clip's [S][L] tensor: clips of 2 GiB and more keep the size_t dword loop)
+    if ((L & 3) == 0 && (((size_t)sk & 15) == 0) && (a.af_scaled || a.scale == 1.f) && (long long)S * L * 4 < (1ll << 31)) {
         constexpr int F4_ROW = P / 4, RPI = 256 / P, NI = S / RPI / WAVES;
         static_assert(S % (RPI * WAVES) == 0, "DMA split");
         __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)sk, 0, S * L * 4, 0x00020000);

@@ -611,6 +611,7 @@ struct WaveNetModel : dws_model {
         }
         // step-only terms: the per-clip rows of the last forward and the sampler's step table (parity / debugging)
         struct { const char* name; const DevBuf* buf; size_t n; } small[] = {
+            {"emb", &emb, (size_t)B * Ein}, {"emb_mlp", &h2, (size_t)B * Eout},
             {"part_t", &part_t, (size_t)B * NL * C}, {"abt", &Abt, mfma_layer ? (size_t)NL * B * abt_row() : 0},
             {"tab_part_t", &tab_pt, (size_t)tab_T * NL * C}, {"tab_abt", &tab_abt, mfma_layer ? (size_t)NL * tab_T * abt_row() : 0}};
         for (auto& e : small)

@@ -121,6 +121,7 @@ class GradientAllReducer:
         if cur:
             self._close(cur, cur_key)
         self._callback_queued = False
+        self._t_first, self._span = None, None
         self.last_stats = None      # {"in_place": slots found in the arena, "copied": slots copied in and back} of the last backward
         self._handles = []
         for p in params:
@@ -133,7 +134,30 @@ class GradientAllReducer:
         self.buckets.append(b)
 
     def _launch(self, b):
+        if self._t_first is None:      # the exchange of a backward starts here: stamp it (allreduce_ms)
+            self._t_first = self._stamp()
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _stamp(self):
+        """A point in time on the gradients' device: a recorded CUDA event, or the host clock for CPU tensors."""
+        dev = self.buckets[0].flat.device if self.buckets else torch.device("cpu")
+        if dev.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+            return ev
+        import time
+        return time.perf_counter()
+
+    def allreduce_ms(self):
+        """Milliseconds from the launch of the first bucket's all-reduce to the completion of the last ``wait()`` of the
+        most recent backward -- the gradient exchange as the step sees it (exposed + overlapped).  None before the first."""
+        if self._span is None:
+            return None
+        t0, t1 = self._span
+        if isinstance(t0, float):
+            return (t1 - t0) * 1e3
+        t1.synchronize()
+        return t0.elapsed_time(t1)
 
     def grad_views(self):
         """A fresh view of its bucket slot for every parameter (id(p) -> tensor shaped like p): the engine's backward
@@ -151,9 +175,7 @@ class GradientAllReducer:
             Variable._execution_engine.queue_callback(self._finalize)
         bi, pi = self.where[p]
         b = self.buckets[bi]
-        if pi in b.ready:       # gradient accumulated twice in one backward: re-copy, do not recount
-            pass
-        off, n = b.offsets[pi]
+        off, n = b.offsets[pi]      # (a gradient accumulated twice in one backward is re-copied below, not recounted)
         g = _real_view(p.grad)
         in_place = (g.data_ptr() == b.flat.data_ptr() + off * b.flat.element_size() and g.is_contiguous()
                     and g.dtype == b.flat.dtype)
@@ -171,12 +193,19 @@ class GradientAllReducer:
                            "copied": sum(len(b.foreign) for b in self.buckets)}
         # Buckets with parameters that got no gradient this backward: every rank has the same graph,
         # so every rank reaches this point with the same set; missing slots contribute zeros.
+        # A slot that got no gradient may still BE a retained ``p.grad`` (a view of the arena from an earlier backward, kept
+        # because the caller did not set the gradients to None): its value is set aside, not wiped, and put back afterwards.
+        kept = []
         for b in self.buckets:
             if b.work is None and b.ready:
                 for pi, p in enumerate(b.params):
                     if pi not in b.ready:
                         off, n = b.offsets[pi]
-                        b.flat[off:off + n].zero_()
+                        slot = b.flat[off:off + n]
+                        g = None if p.grad is None else _real_view(p.grad)
+                        if g is not None and g.data_ptr() == slot.data_ptr():
+                            kept.append((slot, slot.clone()))
+                        slot.zero_()
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
@@ -188,6 +217,12 @@ class GradientAllReducer:
                         off, n = b.offsets[pi]
                         _real_view(p.grad).copy_(b.flat[off:off + n].view_as(_real_view(p.grad)))
             b.work, b.pending, b.ready, b.foreign = None, len(b.params), set(), set()
+        for slot, value in kept:
+            slot.copy_(value)
+        self.last_stats["kept"] = len(kept)
+        if self._t_first is not None:
+            self._span = (self._t_first, self._stamp())
+        self._t_first = None
         self._callback_queued = False
 
     def remove(self):

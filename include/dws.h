@@ -178,7 +178,10 @@ int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, f
  * `capacity` floats).  WaveNet: "pre_final" = ReLU(final_conv[0](skip)) [B,S,L],
  * "skip" [B,S,L], "x" (last residual output) [B,C,L]; the step-only terms: "part_t"
  * [B, n_layers*C] / "abt" (per-clip rows of the last forward) and "tab_part_t"
- * [T, n_layers*C] / "tab_abt" (the sampler's step table).  Both models:
+ * [T, n_layers*C] / "tab_abt" (the sampler's step table).  Function-level taps of the last per-clip forward, both
+ * models: "emb" [B, embed_dim_in] (`models/utils.py:20-27`), "emb_mlp" [B, embed_dim_out] (the two swish layers), "part_t"
+ * (every block's fc_t row); SaShiMi also "nfin" [B, d_model, L] = the final TransposedLayerNorm, "out:<layer prefix>" the
+ * output of a layer and "k:<block prefix>" its S4 kernel.  Both models:
  * "sampler_eps" = the network output of the sampler's last reverse step [B,Cout,L]. */
 int dws_model_read_tap(dws_model* m, const char* tap, float* dst, int64_t capacity, void* stream);
 
