@@ -697,6 +697,15 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
             if not args.no_cpu_baseline:     # the oracle on this box's host cores beside the leg (B = 1, bounded)
                 out[name]["cpu_baseline"] = cpu_baseline(dict(CONFIGS[name]), seconds_budget=10.0, light=True)
                 out[name]["gpu_over_cpu"] = out[name]["value"] / out[name]["cpu_baseline"]["value"]
+            # the same leg with the H <= 64 tails on the bf16 matrix cores at fp32-equivalent accuracy (3-term split, six
+            # products: csrc/sashimi_chain6.hip; error vs float64 = the f32 path's, tests/test_sashimi_bf16x6_gpu.py)
+            a6 = copy.copy(a)
+            a6.precision, a6.no_roofline, a6.steps = "bf16x6", True, max(steps // 2, 10)
+            r6 = sample_bench(a6, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False, full=False)
+            out[name]["extra_bf16x6"] = {"ms_per_step": r6["ms_per_step"], "value": r6["value"], "unit": r6["unit"],
+                                         "dtype": "f32, register-chained tails (H <= 64) f32-equivalent on bf16 MFMA "
+                                                  "(3-term split, 6 products, fp32 accumulate)",
+                                         "note": "opt-in precision=bf16x6; not the leg's value"}
         except Exception as e:      # noqa: BLE001 -- reported, not swallowed
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()

@@ -19,7 +19,9 @@
 // 192 (H = 64) MFMAs per wave: 32 % / 56 % of the MFMA roof.  Here a tile is one straight line of code per wave.
 // The weights (6 H^2 floats: 24 KB at H = 32, 96 KB at H = 64) sit in LDS in A-fragment order, loaded once per
 // workgroup; every wave reads each fragment once per tile (16 B/clk per CU at full MFMA rate).
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "sashimi.h"
 #include "sashimi_mfma.h"
@@ -101,6 +103,15 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
     const float invH = 1.f / (float)H;
 
 #define CH_SOFF(t, r) ((32 * (t) + ((r) & 3) + 8 * ((r) >> 2)) * L4)
+    // DWS_CHAIN_TRACE=1 (tools only): every wave stamps the phases of its SECOND tile (steady state: weights in LDS, the
+    // partner waves of its SIMD in their own tiles) into trace[workgroup][wave][16]
+    unsigned long long* __restrict__ trc = a.trace ? a.trace + ((size_t)blockIdx.x * T::WAVES + wave) * 16 : nullptr;
+    int tile_no = 0;
+#define CH_STAMP(i)                                                        \
+    if (trc && tile_no == 1) {                                             \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+        if (lane == 0) trc[i] = t_;                                        \
+    }
     // (Requesting g and x -- or g alone -- of the NEXT tile under the current tile's GEMM-2 was measured: 141.7 / 138.5 vs
     // 135.7 / 139.4 us at H = 64, 90.0 vs 88.9 at H = 32: no gain.  Counters (profiles/r03_c*_chain*_pmc.txt): MFMA busy 66 % /
     // 52 % of the cycles at H = 64 / 32, the non-MFMA VALU work -- GELU is half of it -- another 18 % / 25 %: the kernel is
@@ -109,6 +120,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
     // scratch tile (24 instead of 96-112 VMEM instructions per tile at H = 32): 90.5 vs 88.9 us -- the address path was not
     // the limit either.)
     for (int tile = blockIdx.x * T::WAVES + wave; tile < ntiles; tile += gridDim.x * T::WAVES) {
+        CH_STAMP(0)
         const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
         const int l0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
         const int pos = l0 + l31;
@@ -134,6 +146,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
                     x1[t][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voff, CH_SOFF(t, r), 0));
         }
 
+        CH_STAMP(1)
         // ---- GEMM-o: o[2H x 32] = Wo g + bo
         f32x16 ao[TO];
 #pragma unroll
@@ -168,6 +181,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        CH_STAMP(2)
         // ---- GLU + residual: x1 = x (+ mel) + o_a * sigmoid(o_b); LN2 down the channel column
         float s1 = 0.f;
 #pragma unroll
@@ -193,6 +207,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[t][r] = alpha * (x1[t][r] + ln_m);
 
+        CH_STAMP(3)
         // ---- GEMM-1: u[ff H x 32] = GELU(W1 y + b1)
         f32x16 u[TF];
 #pragma unroll
@@ -226,6 +241,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        CH_STAMP(4)
         // the U-Net skip of this tile: requested now, needed after GEMM-2
         f32x16 ad[TH];
         if (has_add) {
@@ -242,6 +258,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
             for (int r = 0; r < 16; ++r) u[m][r] = dws_gelu(u[m][r]);
 
         __builtin_amdgcn_sched_barrier(0);
+        CH_STAMP(5)
         // ---- GEMM-2: f[H x 32] = W2 u + b2;  out = x1 + f (+ skip)
         f32x16 f[TH];
 #pragma unroll
@@ -276,6 +293,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        CH_STAMP(6)
         float so = 0.f;
 #pragma unroll
         for (int t = 0; t < TH; ++t)
@@ -287,6 +305,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
                 so += v;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, voff, CH_SOFF(t, r), 0);
             }
+        CH_STAMP(7)
         if constexpr (YNEXT) {
             // ---- the next block's S4 input: LN1_next down the columns of the output + its step-embedding projection, which
             // enters as a rank-1 product (A = e column, B = row of ones): one MFMA per row tile puts e[row] into every column
@@ -316,8 +335,42 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain_kernel
                 }
             }
         }
+        CH_STAMP(8)
+        ++tile_no;
     }
 #undef CH_SOFF
+#undef CH_STAMP
+}
+
+// DWS_CHAIN_TRACE=1 (tools only): mean shader-clock ticks per phase of the traced tile of every wave, on stderr
+template <typename F>
+static void chain_trace_launch(int H, int nwg, int waves, S4TailArgs a, hipStream_t s, F launch) {
+    static const char* names[9] = {"", "issue g,x loads", "GEMM-o (incl. load wait)", "GLU+res+LN2", "GEMM-1", "GELU (+skip request)",
+                                   "GEMM-2", "out stores", "next LN1 + stores"};
+    unsigned long long* d = nullptr;
+    const size_t n = (size_t)nwg * waves * 16;
+    if (hipMalloc(&d, n * 8) != hipSuccess) return;
+    (void)hipMemsetAsync(d, 0, n * 8, s);
+    a.trace = d;
+    launch(a);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(n);
+    (void)hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    double ph[9] = {0}, life = 0;
+    size_t cnt = 0;
+    for (size_t w = 0; w < (size_t)nwg * waves; ++w) {
+        const unsigned long long* t = &h[w * 16];
+        if (!t[0] || !t[8]) continue;            // the wave had fewer than two tiles
+        for (int i = 1; i < 9; ++i) ph[i] += (double)(t[i] - t[i - 1]);
+        life += (double)(t[8] - t[0]);
+        ++cnt;
+    }
+    if (!cnt) return;
+    fprintf(stderr, "[chain trace] H=%d L=%d B=%d wgs=%d waves/wg=%d ynext=%d traced waves %zu; mean ticks per phase of a wave's 2nd tile:",
+            H, a.L, a.B, nwg, waves, a.ynext ? 1 : 0, cnt);
+    for (int i = 1; i < 9; ++i) fprintf(stderr, " %s %.0f |", names[i], ph[i] / cnt);
+    fprintf(stderr, " tile %.0f\n", life / cnt);
 }
 
 bool s4_tail_chain_supported(int H, int ff) { return ff == 2 && (H == 32 || H == 64); }
@@ -340,6 +393,13 @@ static int launch_chain_t(const S4TailArgs& a, hipStream_t s) {
     }
     const int ntiles = a.B * ceil_div(a.L, 32);
     const int grid = std::min(slots, ceil_div(ntiles, T::WAVES));
+    static const bool trace = std::getenv("DWS_CHAIN_TRACE") != nullptr;
+    if (trace && a.ynext) {
+        chain_trace_launch(H, grid, T::WAVES, a, s, [&](const S4TailArgs& at) {
+            hipLaunchKernelGGL((s4_tail_chain_kernel<H, 2, true>), dim3(grid), dim3(T::THREADS), lds, s, at);
+        });
+        return DWS_OK;
+    }
     if (a.ynext) hipLaunchKernelGGL((s4_tail_chain_kernel<H, 2, true>), dim3(grid), dim3(T::THREADS), lds, s, a);
     else hipLaunchKernelGGL((s4_tail_chain_kernel<H, 2, false>), dim3(grid), dim3(T::THREADS), lds, s, a);
     return DWS_OK;

@@ -1,0 +1,397 @@
+// Register-chained S4 tail (sashimi_chain.hip: everything of DiffWaveBlock.forward after the S4 convolution,
+// `sashimi.py:177-184`, `s4.py:1435`, for H = 32, 64) with its three GEMMs on the bf16 matrix cores at fp32-equivalent
+// accuracy: every operand as an exact 3-term bf16 split, six partial products per term pair, fp32 accumulate
+// (bf16_split.h).  precision = "bf16x6".
+//
+// Why here: the f32 chain kernel is arithmetic-bound on ONE pipe -- v_mfma_f32_32x32x2_f32 runs at the VALU rate and
+// shares the VALU's issue, so the tile's GELU / GLU / LayerNorm work adds to its MFMA time (phase trace
+// profiles/r05_chain_phase_trace.txt: 2 x (25.2 k MFMA + ~7 k VALU) cycles of a 69 k-cycle tile pair per SIMD).  Six bf16
+// MFMAs cost 6/16 of the f32 MFMA they replace and run beside the VALU.
+//
+// The chain carries over: the accumulator layout of a 32-row tile (register r of tile t = row 32 t + (r & 3) + 8 (r >> 2) +
+// 4 lhi) is also a legal B-operand layout of v_mfma_f32_32x32x16_bf16 for the NEXT GEMM -- registers 8 hb .. 8 hb + 7 of
+// tile t are the eight k values a lane supplies to k-block 2 t + hb (its k half = lhi) -- once the weight columns are
+// packed in that order (chain16_permute_cols).  A lane splits its own eight fp32 values into three bf16x8 fragments in
+// registers: no LDS round trip, no shuffle, no barrier between the stages, as before.
+//
+// Weights: 6 H^2 x 6 bytes (three bf16 terms) in LDS in A-fragment order -- 36 KB at H = 32, 144 KB at H = 64.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bf16_split.h"
+#include "sashimi.h"
+#include "sashimi_mfma.h"
+
+namespace dws {
+
+typedef float c6_f32x4 __attribute__((ext_vector_type(4)));
+
+// Column order of the 16-wide k-blocks: out[row][kappa] = W[row][32 t + 16 hb + (i & 3) + 8 (i >> 2) + 4 h],
+// kappa = 32 t + 16 hb + 8 h + i  (t = source row tile, hb = its register half, h = the lane half that supplies it)
+__global__ void chain16_permute_cols_kernel(const float* __restrict__ w, float* __restrict__ out, int M, int K) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * K) return;
+    const int row = (int)(idx / K), kp = (int)(idx % K);
+    const int t = kp >> 5, hb = (kp >> 4) & 1, h = (kp >> 3) & 1, i = kp & 7;
+    out[idx] = w[(size_t)row * K + 32 * t + 16 * hb + (i & 3) + 8 * (i >> 2) + 4 * h];
+}
+
+int launch_chain16_permute_cols(const float* w, float* out, int M, int K, hipStream_t s) {
+    DWS_CHECK(K % 32 == 0, DWS_ERR_INVALID, "chain16_permute_cols: K=%d", K);
+    hipLaunchKernelGGL(chain16_permute_cols_kernel, dim3(ceil_div((int64_t)M * K, 256)), dim3(256), 0, s, w, out, M, K);
+    return DWS_OK;
+}
+
+template <int H, int FFE>
+struct Chain6Cfg {
+    static constexpr int TH = H / 32, TO = 2 * H / 32, TF = FFE * H / 32;
+    static constexpr int WAVES = (H >= 64) ? 8 : 4;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int KBH = H / 16, KBF = FFE * H / 16;                 // k-blocks of an H / ff H contraction
+    static constexpr int WO_BYTES = 2 * H * H * 6, W1_BYTES = FFE * H * H * 6, W2_BYTES = FFE * H * H * 6;
+    static constexpr int W_BYTES = WO_BYTES + W1_BYTES + W2_BYTES;
+    static constexpr int B_FLOATS = 2 * H + FFE * H + H;                    // bo | b1 | b2
+    static constexpr int LDS_BYTES = W_BYTES + B_FLOATS * 4;
+    static_assert(H % 32 == 0 && LDS_BYTES <= 163840, "shape");
+};
+
+__device__ __forceinline__ float c6_xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+
+// eight fp32 values of an accumulator-layout tile (register half hb) -> the three bf16x8 B fragments of one k-block
+__device__ __forceinline__ void c6_bfrag(const bx_f32x16& v, int hb, bx_bf16x8 (&out)[3]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 p0, p1, p2;
+        split3(v[8 * hb + i], p0, p1, p2);
+        out[0][i] = p0; out[1][i] = p1; out[2][i] = p2;
+    }
+}
+
+// acc[m] (+)= W[m] . B for all MT row tiles and NKB k-blocks; fragments of W at w + ((m NKB + kb) 3 + term) 1024 + lane 16;
+// src[t] are the accumulator-layout tiles whose registers are the B operand (k-block kb <- tile kb >> 1, half kb & 1).
+// bias: acc starts from a rank-1 k-block (A = bias column in three terms, B = a row of ones).
+template <int MT, int NKB, int NS>
+__device__ __forceinline__ void c6_gemm(bx_f32x16 (&acc)[MT], const char* __restrict__ w, const float* __restrict__ bias,
+                                        const bx_f32x16 (&src)[NS], int lane, int l31, int lhi) {
+    static_assert(NKB == 2 * NS, "two k-blocks per source tile");
+    constexpr int MU = (MT % 2 == 0) ? 2 : 1, NU = MT / MU;      // row tiles per unit: two accumulators alternate in the MFMA stream
+    const char* wl = w + lane * 16;
+    {
+        const __bf16 z = (__bf16)0.f, one = (__bf16)(lhi ? 0.f : 1.f);
+        const bx_bf16x8 bf = {one, z, z, z, z, z, z, z};
+        bx_f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            bx_bf16x8 af[3];
+            frag_rank2(bias[m * 32 + l31], 0.f, lhi == 0, af);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf, zero, 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf, acc[m], 0, 0, 0);
+        }
+    }
+    bx_bf16x8 a_cur[MU][3], a_nxt[MU][3];
+    auto load_a = [&](bx_bf16x8 (&dst)[MU][3], int kb, int u) {
+#pragma unroll
+        for (int mm = 0; mm < MU; ++mm)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                dst[mm][t] = *reinterpret_cast<const bx_bf16x8*>(wl + (((u * MU + mm) * NKB + kb) * 3 + t) * 1024);
+    };
+    load_a(a_cur, 0, 0);
+    bx_bf16x8 bq[3], bn[3];
+    c6_bfrag(src[0], 0, bq);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const bool last_u = (u + 1 == NU);
+            const int kbn = last_u ? kb + 1 : kb, un = last_u ? 0 : u + 1;
+            if (kbn < NKB) load_a(a_nxt, kbn, un);
+            __builtin_amdgcn_sched_barrier(0);   // the fragment reads stay a whole unit ahead of their MFMAs
+            // the split of the NEXT k-block's operand rides in this unit's MFMA stream (the MFMAs do not depend on it)
+            if (last_u && kb + 1 < NKB) c6_bfrag(src[(kb + 1) >> 1], (kb + 1) & 1, bn);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int mm = 0; mm < MU; ++mm)
+                    acc[u * MU + mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mm][BX6_IA[t]], bq[BX6_IB[t]], acc[u * MU + mm], 0, 0, 0);
+#ifndef C6_NO_INTERLEAVE
+            if (last_u && kb + 1 < NKB) {
+#pragma unroll
+                for (int i = 0; i < 6 * MU; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 48 / (6 * MU), 0);   // a share of the 44 split instructions
+                }
+            }
+#endif
+#pragma unroll
+            for (int mm = 0; mm < MU; ++mm)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a_cur[mm][t] = a_nxt[mm][t];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bq[t] = bn[t];
+    }
+}
+
+template <int H, int FFE, bool YNEXT>
+__global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain6_kernel(S4TailArgs a) {
+    using T = Chain6Cfg<H, FFE>;
+    constexpr int TH = T::TH, TO = T::TO, TF = T::TF;
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char lds6[];
+    char* const wo = lds6;                                   // [TO][KBH][3][64] 16-byte fragments
+    char* const w1 = wo + T::WO_BYTES;                       // [TF][KBH][3][64]
+    char* const w2 = w1 + T::W1_BYTES;                       // [TH][KBF][3][64]
+    float* const bo = reinterpret_cast<float*>(w2 + T::W2_BYTES);   // [2H]
+    float* const b1 = bo + 2 * H;                            // [FFE*H]
+    float* const b2 = b1 + FFE * H;                          // [H]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int L = a.L, L4 = L * 4;
+
+    {   // weights and biases -> LDS, once per workgroup (the only barrier of the kernel)
+        const c6_f32x4* so = reinterpret_cast<const c6_f32x4*>(a.Ao_c6);
+        const c6_f32x4* s1 = reinterpret_cast<const c6_f32x4*>(a.A1_c6);
+        const c6_f32x4* s2 = reinterpret_cast<const c6_f32x4*>(a.A2_c6);
+        c6_f32x4* d = reinterpret_cast<c6_f32x4*>(lds6);
+        for (int i = tid; i < T::WO_BYTES / 16; i += T::THREADS) d[i] = so[i];
+        for (int i = tid; i < T::W1_BYTES / 16; i += T::THREADS) d[T::WO_BYTES / 16 + i] = s1[i];
+        for (int i = tid; i < T::W2_BYTES / 16; i += T::THREADS) d[(T::WO_BYTES + T::W1_BYTES) / 16 + i] = s2[i];
+        for (int i = tid; i < 2 * H; i += T::THREADS) bo[i] = a.bo[i];
+        for (int i = tid; i < FFE * H; i += T::THREADS) b1[i] = a.b1[i];
+        for (int i = tid; i < H; i += T::THREADS) b2[i] = a.b2[i];
+    }
+    __syncthreads();
+
+    const float ln_m = a.ln_m[0], ln_s = a.ln_s[0];
+    const float n1_m = YNEXT ? a.n1_m[0] : 0.f, n1_s = YNEXT ? a.n1_s[0] : 0.f;
+    const bool has_mel = a.mel != nullptr, has_add = a.addend != nullptr;
+    const float one = lhi ? 0.f : 1.f;
+    const int ntl = (L + 31) / 32, ntiles = a.B * ntl;
+    const float invH = 1.f / (float)H;
+
+#define C6_SOFF(t, r) ((32 * (t) + ((r) & 3) + 8 * ((r) >> 2)) * L4)
+    unsigned long long* __restrict__ trc = a.trace ? a.trace + ((size_t)blockIdx.x * T::WAVES + wave) * 16 : nullptr;
+    int tile_no = 0;
+#define C6_STAMP(i)                                                        \
+    if (trc && tile_no == 1) {                                             \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+        if (lane == 0) trc[i] = t_;                                        \
+    }
+    for (int tile = blockIdx.x * T::WAVES + wave; tile < ntiles; tile += gridDim.x * T::WAVES) {
+        C6_STAMP(0)
+        const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
+        const int l0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
+        const int pos = l0 + l31;
+        const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
+        __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        bx_f32x16 g[TH], x1[TH];
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rG, voff, C6_SOFF(t, r), 0));
+                x1[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, C6_SOFF(t, r), 0));
+            }
+        if (has_mel) {
+            __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.mel + (size_t)(a.mel_bstride ? b : 0) * H * L), 0, H * L4, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    x1[t][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voff, C6_SOFF(t, r), 0));
+        }
+        C6_STAMP(1)
+        // ---- GEMM-o: o[2H x 32] = Wo g + bo
+        bx_f32x16 ao[TO];
+        c6_gemm<TO, T::KBH, TH>(ao, wo, bo, g, lane, l31, lhi);
+        C6_STAMP(2)
+        // ---- GLU + residual: x1 = x (+ mel) + o_a * sigmoid(o_b); LN2 down the channel column
+        float s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x1[t][r] = fmaf(ao[t][r], dws_sigmoid(ao[TH + t][r]), x1[t][r]);
+                s1 += x1[t][r];
+            }
+        const float mean = c6_xhalf_sum(s1) * invH;
+        float sv = 0.f;
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x1[t][r] -= mean;                       // x1 holds the centred value from here on
+                sv = fmaf(x1[t][r], x1[t][r], sv);
+            }
+        const float alpha = ln_s / sqrtf(c6_xhalf_sum(sv) * invH);
+        bx_f32x16 y[TH];
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[t][r] = alpha * (x1[t][r] + ln_m);
+        C6_STAMP(3)
+        // ---- GEMM-1: u[ff H x 32] = GELU(W1 y + b1)
+        bx_f32x16 u[TF];
+        c6_gemm<TF, T::KBH, TH>(u, w1, b1, y, lane, l31, lhi);
+        C6_STAMP(4)
+#ifndef C6_AD_LATE
+        // the U-Net skip of this tile: requested now, needed after GEMM-2
+        bx_f32x16 ad[TH];
+        if (has_add) {
+            __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.addend + (size_t)b * H * L), 0, H * L4, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ad[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, voff, C6_SOFF(t, r), 0));
+        }
+#endif
+#pragma unroll
+        for (int m = 0; m < TF; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[m][r] = dws_gelu(u[m][r]);
+        C6_STAMP(5)
+        // ---- GEMM-2: f[H x 32] = W2 u + b2;  out = x1 + f (+ skip)
+        bx_f32x16 f[TH];
+        c6_gemm<TH, T::KBF, TF>(f, w2, b2, u, lane, l31, lhi);
+        C6_STAMP(6)
+#ifdef C6_AD_LATE
+        // the U-Net skip of this tile
+        bx_f32x16 ad[TH];
+        if (has_add) {
+            __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.addend + (size_t)b * H * L), 0, H * L4, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ad[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, voff, C6_SOFF(t, r), 0));
+        }
+#endif
+        float so = 0.f;
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (x1[t][r] + mean) + f[t][r];
+                if (has_add) v += ad[t][r];
+                f[t][r] = v;
+                so += v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, voff, C6_SOFF(t, r), 0);
+            }
+        C6_STAMP(7)
+        if constexpr (YNEXT) {
+            // ---- the next block's S4 input: LN1_next down the columns of the output + its step-embedding projection, which
+            // enters as an exact rank-1 product on the f32 matrix instruction (A = e column, B = row of ones)
+            __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
+            const float* eb = a.e_next + (size_t)b * a.e_stride + step_row_off(a.e_step, a.e_tstride);
+            const float m2 = c6_xhalf_sum(so) * invH;
+            float sv2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    f[t][r] -= m2;
+                    sv2 = fmaf(f[t][r], f[t][r], sv2);
+                }
+            const float al2 = n1_s / sqrtf(c6_xhalf_sum(sv2) * invH);
+#pragma unroll
+            for (int t = 0; t < TH; ++t) {
+                const float ev = lhi ? 0.f : eb[t * 32 + l31];
+                bx_f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                const bx_f32x16 et = __builtin_amdgcn_mfma_f32_32x32x2f32(ev, one, z, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float yv = fmaf(al2, f[t][r] + n1_m, et[r]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), rY, voff, C6_SOFF(t, r), 0);
+                }
+            }
+        }
+        C6_STAMP(8)
+        ++tile_no;
+    }
+#undef C6_SOFF
+#undef C6_STAMP
+}
+
+bool s4_tail_chain6_supported(int H, int ff) { return ff == 2 && (H == 32 || H == 64); }
+
+template <typename F>
+static void chain6_trace_launch(int H, int nwg, int waves, S4TailArgs a, hipStream_t s, F launch) {
+    static const char* names[9] = {"", "issue g,x loads", "GEMM-o (incl. load wait, split of g)", "GLU+res+LN2", "GEMM-1 (incl. split of y)",
+                                   "GELU (+skip request)", "GEMM-2 (incl. split of u)", "out stores", "next LN1 + stores"};
+    unsigned long long* d = nullptr;
+    const size_t n = (size_t)nwg * waves * 16;
+    if (hipMalloc(&d, n * 8) != hipSuccess) return;
+    (void)hipMemsetAsync(d, 0, n * 8, s);
+    a.trace = d;
+    launch(a);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(n);
+    (void)hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    double ph[9] = {0}, life = 0;
+    size_t cnt = 0;
+    for (size_t w = 0; w < (size_t)nwg * waves; ++w) {
+        const unsigned long long* t = &h[w * 16];
+        if (!t[0] || !t[8]) continue;
+        for (int i = 1; i < 9; ++i) ph[i] += (double)(t[i] - t[i - 1]);
+        life += (double)(t[8] - t[0]);
+        ++cnt;
+    }
+    if (!cnt) return;
+    fprintf(stderr, "[chain6 trace] H=%d L=%d B=%d wgs=%d waves/wg=%d ynext=%d traced waves %zu; mean ticks per phase of a wave's 2nd tile:",
+            H, a.L, a.B, nwg, waves, a.ynext ? 1 : 0, cnt);
+    for (int i = 1; i < 9; ++i) fprintf(stderr, " %s %.0f |", names[i], ph[i] / cnt);
+    fprintf(stderr, " tile %.0f\n", life / cnt);
+}
+
+template <int H>
+static int launch_chain6_t(const S4TailArgs& a, hipStream_t s) {
+    using T = Chain6Cfg<H, 2>;
+    ProfileScope ps("s4_tail_mfma_chain6", s);
+    const size_t lds = (size_t)T::LDS_BYTES;
+    static int slots = 0;
+    if (slots == 0) {
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain6_kernel<H, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain6_kernel<H, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0, ncu = 0, per_cu = 0;
+        DWS_HIP(hipGetDevice(&dev));
+        DWS_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        DWS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s4_tail_chain6_kernel<H, 2, true>, T::THREADS, lds));
+        DWS_CHECK(ncu > 0 && per_cu > 0, DWS_ERR_HIP, "s4_tail_chain6: occupancy query returned %d x %d", ncu, per_cu);
+        slots = ncu * per_cu;
+    }
+    const int ntiles = a.B * ceil_div(a.L, 32);
+    const int grid = std::min(slots, ceil_div(ntiles, T::WAVES));
+    static const bool trace = std::getenv("DWS_CHAIN_TRACE") != nullptr;
+    if (trace && a.ynext) {
+        chain6_trace_launch(H, grid, T::WAVES, a, s, [&](const S4TailArgs& at) {
+            hipLaunchKernelGGL((s4_tail_chain6_kernel<H, 2, true>), dim3(grid), dim3(T::THREADS), lds, s, at);
+        });
+        return DWS_OK;
+    }
+    if (a.ynext) hipLaunchKernelGGL((s4_tail_chain6_kernel<H, 2, true>), dim3(grid), dim3(T::THREADS), lds, s, a);
+    else hipLaunchKernelGGL((s4_tail_chain6_kernel<H, 2, false>), dim3(grid), dim3(T::THREADS), lds, s, a);
+    return DWS_OK;
+}
+
+int launch_s4_tail_chain6(int H, const S4TailArgs& a, hipStream_t s) {
+    DWS_CHECK(a.Ao_c6 && a.A1_c6 && a.A2_c6, DWS_ERR_STATE, "s4_tail_chain6: the split chain-ordered weights were not packed");
+    if (H == 32) return launch_chain6_t<32>(a, s);
+    if (H == 64) return launch_chain6_t<64>(a, s);
+    return set_error(DWS_ERR_UNSUPPORTED, "s4_tail_chain6: H=%d not instantiated", H);
+}
+
+}  // namespace dws

@@ -34,6 +34,11 @@ struct S4TailArgs {
     const float* Ao_c;
     const float* A1_c;
     const float* A2_c;
+    // precision = "bf16x6" (sashimi_chain6.hip): the three weights as 3-term bf16 fragments of v_mfma_f32_32x32x16_bf16 in
+    // the 16-wide chain order; non-null selects the split kernel for H <= 64
+    const void* Ao_c6;
+    const void* A1_c6;
+    const void* A2_c6;
     unsigned long long* trace;   // nullable (tools only, DWS_TAIL_TRACE=1): s_memtime stamps [workgroup][wave][16] of the
                                  // LDS-tile kernel's phases
 };
@@ -60,6 +65,9 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s);
 bool s4_tail_chain_supported(int H, int ff);
 int launch_s4_tail_chain(int H, const S4TailArgs& a, hipStream_t s);
 int launch_chain_permute_cols(const float* w, float* out, int M, int K, hipStream_t s);
+bool s4_tail_chain6_supported(int H, int ff);
+int launch_s4_tail_chain6(int H, const S4TailArgs& a, hipStream_t s);
+int launch_chain16_permute_cols(const float* w, float* out, int M, int K, hipStream_t s);
 int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s);
 bool pw_mfma_supported(int mode, int K, int M, int p);
 bool pw_mfma_ln_supported(int M);

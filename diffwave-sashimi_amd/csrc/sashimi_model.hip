@@ -110,6 +110,7 @@ struct SLayer {
     DevBuf W1, W2, Wp;    // folded ff / pool weights
     DevBuf Ao, A1, A2, rs1, Ap;  // MFMA-packed copies (+ row sums of W1 for the folded LayerNorm)
     DevBuf Ao_c, A1_c, A2_c;     // H <= 64: the same weights with chain-ordered columns (sashimi_chain.hip)
+    DevBuf Ao_c6, A1_c6, A2_c6;  // precision = bf16x6: 3-term bf16 fragments in the 16-wide chain order (sashimi_chain6.hip)
     bool mfma = false, mfma2 = false;
     DevBuf Kf;            // rocFFT path: [H][L+1] complex spectrum of the two-sided kernel (n = 2L)
     DevBuf kfa, kfb, kfs; // fused path: pair-ordered spectrum at the power-of-two size (fftconv.h)
@@ -179,6 +180,18 @@ struct SashimiModel : dws_model {
     int mel_T = 0;
     CondTrainWs cws;
     DevBuf gW0f, gW1f, gWcf;
+
+    bool bf16x6 = false;      // precision option: the H <= 64 tails on the bf16 matrix cores, 3-term split (sashimi_chain6.hip)
+    int set_option(const std::string& key, const std::string& value) override {
+        if (key == "precision") {
+            if (value == "f32" || value == "bf16x6") {
+                if ((value == "bf16x6") != bf16x6) { bf16x6 = !bf16x6; dirty = true; drop_graph(); trained_fwd = false; }
+                return DWS_OK;
+            }
+            return set_error(DWS_ERR_UNSUPPORTED, "sashimi: precision=%s is not built (f32 | bf16x6)", value.c_str());
+        }
+        return dws_model::set_option(key, value);
+    }
 
     ~SashimiModel() override {
         for (auto* l : all) delete l;
@@ -497,6 +510,20 @@ struct SashimiModel : dws_model {
                         DWS_TRY(launch_chain_permute_cols(l->W2.f(), chain_tmp.f(), H, FF * H, s));
                         DWS_TRY(launch_pack_a_frag(chain_tmp.f(), l->A2_c.f(), H, FF * H, s));
                     }
+                    if (bf16x6 && s4_tail_chain6_supported(H, FF)) {
+                        DWS_TRY(chain_tmp.ensure((size_t)FF * H * H * 4));
+                        DWS_TRY(l->Ao_c6.ensure((size_t)2 * H * H * 6));
+                        DWS_TRY(l->A1_c6.ensure((size_t)FF * H * H * 6));
+                        DWS_TRY(l->A2_c6.ensure((size_t)FF * H * H * 6));
+                        DWS_TRY(launch_chain16_permute_cols(P(l->prefix + ".layer.output_linear.0.weight"), chain_tmp.f(), 2 * H, H, s));
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->Ao_c6.p, 2 * H, H, s));
+                        DWS_TRY(launch_chain16_permute_cols(l->W1.f(), chain_tmp.f(), FF * H, H, s));
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A1_c6.p, FF * H, H, s));
+                        DWS_TRY(launch_chain16_permute_cols(l->W2.f(), chain_tmp.f(), H, FF * H, s));
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A2_c6.p, H, FF * H, s));
+                    } else {
+                        l->Ao_c6.release(); l->A1_c6.release(); l->A2_c6.release();
+                    }
                 }
                 DWS_TRY(build_kernel(l, s));
                 if (cond) {
@@ -736,6 +763,7 @@ struct SashimiModel : dws_model {
             t.A2 = l->A2.f(); t.b2 = P(p + ".ff.ff.2.conv.bias");
             t.addend = addend; t.out = l->out.f(); t.B = nB; t.L = Ls;
             t.Ao_c = l->Ao_c.f(); t.A1_c = l->A1_c.f(); t.A2_c = l->A2_c.f();
+            if (bf16x6) { t.Ao_c6 = l->Ao_c6.p; t.A1_c6 = l->A1_c6.p; t.A2_c6 = l->A2_c6.p; }
             if (next) {     // next block: feeds_next(l, next) holds, the stage's y buffer is free once this block's convolution ran
                 t.ynext = next->y;
                 t.n1_m = next->m; t.n1_s = next->s;

@@ -1,0 +1,95 @@
+"""precision="bf16x6" for the SaShiMi backbone: the register-chained S4 tails (H <= 64: `s4.py:1435` output_linear + GLU,
+`sashimi.py:60-75` FF, `sashimi.py:177-184`) on the bf16 matrix cores with the 3-term split of `csrc/bf16_split.h`
+(`csrc/sashimi_chain6.hip`).  Same acceptance as the WaveNet layer (tests/test_bf16x6_gpu.py): measured against a
+FLOAT64 evaluation of the oracle graph, the split path's error must stay within 2x the exact-f32 MFMA path's."""
+import pytest
+import torch
+
+from oracle import sashimi as oss
+from tests import cases
+from tests.conftest import REL_TOL, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _f64(net, cfg, audio, steps, mel=None):
+    sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        return oss.sashimi_forward(sd64, cfg, audio.double(), steps, mel_spec=None if mel is None else mel.double(),
+                                   return_pre_final=True)
+
+
+@pytest.mark.parametrize("name", ["ss_d64_short", "ss_unet_d64"])
+def test_sashimi_bf16x6_error_against_float64_is_that_of_the_f32_path(gpu, name):
+    cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES[name]
+    L = cfg["L"]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    audio, steps = cases.wavenet_inputs(B, L, cfg["in_channels"], iseed)
+    ref, ref_pre = _f64(net, cfg, audio, steps)
+    out = {}
+    with torch.no_grad():
+        for prec in ("f32", "bf16x6"):
+            net.set_option("precision", prec)
+            eps = net((audio.to(gpu), steps.to(gpu)))
+            out[prec] = (eps.cpu(), net.read_tap("pre_final", (B, cfg["d_model"], L)).cpu())
+        net.set_option("precision", "f32")
+        again = net((audio.to(gpu), steps.to(gpu))).cpu()
+    assert torch.equal(again, out["f32"][0])                 # switching back restores the f32 path bit for bit
+    assert not torch.equal(out["bf16x6"][0], out["f32"][0])  # and the split tails really are another arithmetic
+    e = {p: (rel_err(out[p][0], ref), rel_err(out[p][1], ref_pre)) for p in out}
+    rms = {p: float(((out[p][1].double() - ref_pre) ** 2).mean().sqrt() / (ref_pre ** 2).mean().sqrt()) for p in out}
+    direct = rel_err(out["bf16x6"][1], out["f32"][1])
+    print(f"{name}: max-rel error vs float64 (eps, pre_final) f32-MFMA {e['f32'][0]:.3e} {e['f32'][1]:.3e} | bf16x6 "
+          f"{e['bf16x6'][0]:.3e} {e['bf16x6'][1]:.3e}; rms-rel pre_final f32 {rms['f32']:.3e} bf16x6 {rms['bf16x6']:.3e}; "
+          f"bf16x6 vs f32 path directly {direct:.3e}")
+    for k in (0, 1):
+        assert e["bf16x6"][k] <= 2.0 * e["f32"][k], (name, k, e)
+    assert rms["bf16x6"] <= 2.0 * rms["f32"], (name, rms)
+    assert direct < 5e-6
+    g = load_golden("sashimi")     # the reference's own fp32 forward: as close to it as the f32 path is
+    assert rel_err(out["bf16x6"][0], g[f"{name}/eps"]) < max(1.5 * rel_err(out["f32"][0], g[f"{name}/eps"]), REL_TOL / 100)
+
+
+def test_sashimi_bf16x6_conditional_d32_matches_reference(gpu):
+    """H = 32 and 64 chained tails with the mel term in the residual (`sashimi.py:160-175`), BASELINE config 4's widths."""
+    name = "ss_cond_d32"
+    cfg, B, Tmel, wseed, iseed, _ = cases.SASHIMI_COND_CASES[name]
+    g = load_golden("sashimi_cond")
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    net.set_option("precision", "bf16x6")
+    audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
+    with torch.no_grad():
+        for Bm in (1, B):
+            mel = cases.mel_inputs(Bm, Tmel, iseed).to(gpu)
+            eps = net((audio.to(gpu), steps.to(gpu)), mel_spec=mel)
+            keys = [k for k in g.files if k.startswith(name + "/eps") and (f"bm{Bm}" in k)]
+            assert keys, list(g.files)[:8]
+            err = rel_err(eps, g[keys[0]])
+            assert err < REL_TOL / 100, f"{name} Bm={Bm}: {err:.3e}"
+
+
+def test_sashimi_bf16x6_sampler_graph_equals_the_per_step_loop(gpu):
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES["ss_d64_short"]
+    L = cfg["L"]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    net.set_option("precision", "bf16x6")
+    T = 5
+    dh = calc_diffusion_hyperparams(T, 1e-4, 0.05)
+    gen = torch.Generator().manual_seed(5)
+    x_T = torch.randn(B, 1, L, generator=gen)
+    noise = torch.randn(T, B, 1, L, generator=gen)
+    a = sampling(net, (B, 1, L), dh, x_T=x_T, noise=noise, use_graph=True).cpu()
+    b = sampling(net, (B, 1, L), dh, x_T=x_T, noise=noise, use_graph=False).cpu()
+    assert torch.equal(a, b)
+    net.set_option("precision", "f32")
+    c = sampling(net, (B, 1, L), dh, x_T=x_T, noise=noise, use_graph=True).cpu()
+    assert rel_err(a, c) < 1e-4
+
+
+def test_sashimi_rejects_unknown_precision(gpu):
+    net = cases.build_ours(cases.SASHIMI_CASES["ss_tiny"][0], 1).to(gpu)
+    with pytest.raises(NotImplementedError):
+        net.set_option("precision", "bf16x3")
+    net.set_option("precision", "bf16x6")      # accepted: no tail of this tiny model is on the chain kernel, nothing changes
+    net.set_option("precision", "f32")
