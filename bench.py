@@ -748,6 +748,30 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
     return out
 
 
+def wavenet_traffic(precision, kname, executed):
+    """PMC-derived HBM bytes per launch of the WaveNet layer kernel (tools/r05_traffic.sh: rocprofv3 in separate --pmc
+    passes on the bench command, corrected as the guide prescribes).  The newest profiles/r*_wavenet_traffic_<precision>.json
+    is used only if it was measured on THIS kernel: same name, and SQ_INSTS_MFMA x (flops per instruction) within 1 % of
+    the executed flops (bf16x6: 32768 flops per bf16 MFMA, six per fp32-equivalent term; its correction and bias k-blocks
+    add 1.6 % to the count, so the window is 3 % there) -- a file left over from another kernel version is refused, not
+    silently reported.  Returns (bytes or None, file name or the reason of the refusal)."""
+    import glob
+    per_inst, tol = (4096.0, 0.01) if precision == "f32" else (32768.0 / 6.0, 0.03)
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wavenet_traffic_%s.json" % precision)), reverse=True)
+    if precision == "f32":
+        tfiles += sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wavenet_traffic.json")), reverse=True)
+    for tfile in tfiles:
+        tj = json.load(open(tfile))
+        cnt = tj.get("sq_insts_mfma_per_launch")
+        if not tj.get("kernel", "").startswith(kname):
+            return None, "%s refused: measured on %s" % (os.path.basename(tfile), tj.get("kernel"))
+        if cnt is None or abs(cnt * per_inst / executed - 1) > tol:
+            return None, "%s refused: SQ_INSTS_MFMA x %.0f = %s vs executed flops %.4g" % (
+                os.path.basename(tfile), per_inst, cnt and "%.4g" % (cnt * per_inst), executed)
+        return tj["hbm_bytes_per_launch"], os.path.basename(tfile)
+    return None, None
+
+
 def profiled_step_ms(lib, run_eager_steps, name, nprof, per_step):
     """ms one step spends in the kernels whose name contains `name`: `nprof` eager steps are timed launch by launch
     (HIP events on the launch stream) and every launch position of the step takes its MEDIAN over the repeats -- the
@@ -899,23 +923,8 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
         kname = {"f32": "wn_layer_wino_kernel" if wino else "wn_layer_mfma_kernel", "bf16x3": "wn_layer_bf16x3_kernel",
                  "bf16x6": "wn_layer_bx6_kernel"}[args.precision]
         traffic, traffic_note = None, None
-        if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and args.precision == "f32":
-            # PMC-derived HBM bytes per launch of this kernel (tools/r04_traffic.sh: rocprofv3 in separate --pmc passes on
-            # the same command, corrected as the guide prescribes).  The newest profiles/r*_wavenet_traffic.json is used
-            # only if it was measured on THIS kernel: same name, and SQ_INSTS_MFMA x 4096 within 1 % of the executed flops
-            # computed above -- a file left over from another kernel version is refused, not silently reported.
-            import glob
-            for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wavenet_traffic.json")), reverse=True):
-                tj = json.load(open(tfile))
-                cnt = tj.get("sq_insts_mfma_per_launch")
-                if not tj.get("kernel", "").startswith(kname):
-                    traffic_note = "%s refused: measured on %s" % (os.path.basename(tfile), tj.get("kernel"))
-                elif cnt is None or abs(cnt * 4096 / executed - 1) > 0.01:
-                    traffic_note = "%s refused: SQ_INSTS_MFMA x 4096 = %s vs executed flops %.4g" % (
-                        os.path.basename(tfile), cnt and "%.4g" % (cnt * 4096), executed)
-                else:
-                    traffic, traffic_note = tj["hbm_bytes_per_launch"], os.path.basename(tfile)
-                break
+        if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and args.precision in ("f32", "bf16x6"):
+            traffic, traffic_note = wavenet_traffic(args.precision, kname, executed)
         result["roofline"] = {
             "kernel": "%s<%d,%d>" % (kname, cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
@@ -937,10 +946,30 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
         step_ms = profiled_step_ms(lib, eager, b"s4_tail", nprof, nblocks)
         if step_ms is not None:
             ach = flops / (step_ms * 1e-3) / 1e12
+            # counter-derived HBM bytes per step of the two families (tools/r05_traffic_sashimi.sh): the newest
+            # profiles/r*_sashimi_traffic_<config>.json, used only if it was measured on THESE kernels -- same config, f32
+            # tails (SQ_INSTS_MFMA x 4096 within 5 % of the tail flops computed above), whole steps (dispatches % blocks == 0)
+            traffic, traffic_fc, traffic_note = None, None, None
+            if args.precision == "f32" and not args.batch:
+                import glob
+                for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sashimi_traffic_%s.json" % args.config)), reverse=True):
+                    tj = json.load(open(tfile))
+                    ft, ff_ = tj["families"].get("s4_tail", {}), tj["families"].get("fftconv", {})
+                    cnt = ft.get("sq_insts_mfma_per_launch")
+                    if tj.get("config") != args.config or not ft.get("dispatches") or ft["dispatches"] % nblocks:
+                        traffic_note = "%s refused: config / dispatch count" % os.path.basename(tfile)
+                    elif cnt is None or abs(cnt * 4096 * nblocks / flops - 1) > 0.05:
+                        traffic_note = "%s refused: SQ_INSTS_MFMA x 4096 x %d = %.4g vs tail flops %.4g" % (
+                            os.path.basename(tfile), nblocks, (cnt or 0) * 4096 * nblocks, flops)
+                    else:
+                        traffic = ft["hbm_bytes_per_launch"] * nblocks
+                        traffic_fc = ff_.get("hbm_bytes_per_launch", 0) * nblocks if ff_.get("dispatches") else None
+                        traffic_note = os.path.basename(tfile)
+                    break
             result["roofline"] = {
                 "kernel": "s4_tail_mfma_kernel<H,...> (all %d block launches of a step)" % nblocks, "bound": "mfma",
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "ms_per_step_in_kernel": step_ms, "launches_timed": nprof * nblocks,
+                "traffic": traffic, "traffic_source": traffic_note, "ms_per_step_in_kernel": step_ms, "launches_timed": nprof * nblocks,
                 "algorithmic_flops_per_step": flops, "algorithmic_bytes_per_step": bytes_,
                 "hbm_achieved_GBs": bytes_ / (step_ms * 1e-3) / 1e9,
                 "note": "fp32 MFMA and VALU do not co-issue on gfx950 (DESIGN.md 6): the GELU/GLU/LN VALU work of the "
@@ -954,7 +983,7 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
                 "kernel": "fftconv_kernel<log2 M, M/16> (all %d block launches of a step)" % nblocks, "bound": "hbm",
                 "achieved": fc_bytes / (fc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": fc_bytes / (fc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "ms_per_step_in_kernel": fc_ms,
-                "algorithmic_bytes_per_step": fc_bytes}
+                "algorithmic_bytes_per_step": fc_bytes, "traffic": traffic_fc}
     if (rank == 0 and world == 1 and args.precision == "f32" and cfg["model"]["_name_"] == "wavenet"
             and not args.no_roofline and extras):
         # Additional, clearly separate measurements (NOT `value`): the two bf16-split arithmetics of the WaveNet layer.
@@ -982,7 +1011,9 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
                     leg["roofline"] = {
                         "kernel": "wn_layer_bx6_kernel<%d,%d>" % (cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
                         "bound": "mfma", "achieved": executed / (avg * 1e-3) / 1e12, "peak": peak6, "unit": "TFLOP/s",
-                        "frac": executed / (avg * 1e-3) / 1e12 / peak6, "traffic": None, "avg_launch_ms": avg,
+                        "frac": executed / (avg * 1e-3) / 1e12 / peak6, "avg_launch_ms": avg,
+                        **dict(zip(("traffic", "traffic_source"), wavenet_traffic("bf16x6", "wn_layer_bx6_kernel", executed)
+                                   if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 else (None, None))),
                         "peak_note": "2.5 PFLOP/s dense bf16 MFMA / 6 products per fp32-equivalent multiply-add",
                         "executed_flops_per_launch": executed, "bf16_mfma_flops_per_launch": 6 * executed,
                         "algorithmic_bytes_per_launch": bytes_,
