@@ -17,6 +17,7 @@
 // Weights: 6 H^2 x 6 bytes (three bf16 terms) in LDS in A-fragment order -- 36 KB at H = 32, 144 KB at H = 64.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "bf16_split.h"
@@ -326,6 +327,310 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain6_kerne
 }
 
 bool s4_tail_chain6_supported(int H, int ff) { return ff == 2 && (H == 32 || H == 64); }
+
+// =====================================================================================================================
+// H = 128: the same chain, one wave per SIMD.  A wave still owns 32 positions and ALL channels of them (g, x1, the GLU
+// pre-activations, u: up to 128 + 128 + 64 accumulator-layout registers at a time -- 512 registers per lane, so four waves
+// per CU), but the weights (6 H^2 x 6 bytes = 576 KB) no longer fit in LDS: they STREAM through a ring of 24 KB chunks
+// (one k-block of all row tiles of a GEMM; 24 chunks per tile, the same sequence for every tile) that the four waves fill
+// by LDS-DMA several chunks ahead and all read -- every byte of weights crosses L2 -> CU once per 128 positions.
+// One workgroup barrier per chunk (48 MFMAs per wave) both publishes the chunk that has landed and frees the slot that
+// was consumed before it; the stream does not stop at tile boundaries (the next tile's first chunks arrive under GEMM-2).
+// Fragment order in memory: k-block major, [k-block][row tile][term][lane] (pack_a_bx6_kmajor).
+__global__ void pack_a_bx6_kmajor_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int M, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * K) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const size_t r = i >> 9;                       // kb * MT + mt
+    const int MT = M / 32;
+    const int mt = (int)(r % MT), kb = (int)(r / MT);
+    const float v = w[(size_t)(mt * 32 + (lane & 31)) * K + kb * 16 + 8 * (lane >> 5) + e];
+    __bf16 p0, p1, p2;
+    split3(v, p0, p1, p2);
+    const size_t base = (r * 3) * 512 + (size_t)lane * 8 + e;
+    out[base] = __builtin_bit_cast(unsigned short, p0);
+    out[base + 512] = __builtin_bit_cast(unsigned short, p1);
+    out[base + 1024] = __builtin_bit_cast(unsigned short, p2);
+}
+
+int launch_pack_a_bx6_kmajor(const float* w, void* out, int M, int K, hipStream_t s) {
+    DWS_CHECK(M % 32 == 0 && K % 16 == 0, DWS_ERR_UNSUPPORTED, "pack_a_bx6_kmajor: M=%d K=%d", M, K);
+    hipLaunchKernelGGL(pack_a_bx6_kmajor_kernel, dim3(ceil_div((int64_t)M * K, 256)), dim3(256), 0, s, w, (unsigned short*)out, M, K);
+    return DWS_OK;
+}
+
+template <int H, int FFE>
+struct Wide6Cfg {
+    static constexpr int TH = H / 32, TO = 2 * H / 32, TF = FFE * H / 32;
+    static constexpr int WAVES = 4, THREADS = 256;
+    static constexpr int KBH = H / 16, KBF = FFE * H / 16;
+    static constexpr int CHUNK = TO * 3 * 1024;                            // bytes: one k-block of the 2H-row GEMMs
+    static constexpr int KPC2 = TO / TH;                                   // k-blocks of GEMM-2 per chunk
+    static constexpr int NCH = KBH + KBH + KBF / KPC2;                     // chunks per tile
+    static constexpr int NSLOT = 5, AHEAD = NSLOT - 1;                     // ring slots; chunks requested ahead of use
+    static constexpr int DPW = CHUNK / 1024 / WAVES;                       // LDS-DMA instructions per wave and chunk
+    static constexpr int B_FLOATS = 2 * H + FFE * H + H;
+    static constexpr int LDS_BYTES = NSLOT * CHUNK + B_FLOATS * 4;
+    static_assert(TO == TF && TO % TH == 0 && KBF % KPC2 == 0 && (CHUNK / 1024) % WAVES == 0 && LDS_BYTES <= 163840, "shape");
+};
+
+template <int H, int FFE, bool YNEXT>
+__global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
+    using T = Wide6Cfg<H, FFE>;
+    constexpr int TH = T::TH, TO = T::TO, TF = T::TF;
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char ldsw[];
+    float* const bo = reinterpret_cast<float*>(ldsw + T::NSLOT * T::CHUNK);
+    float* const b1 = bo + 2 * H;
+    float* const b2 = b1 + FFE * H;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int L = a.L, L4 = L * 4;
+    for (int i = tid; i < 2 * H; i += T::THREADS) bo[i] = a.bo[i];
+    for (int i = tid; i < FFE * H; i += T::THREADS) b1[i] = a.b1[i];
+    for (int i = tid; i < H; i += T::THREADS) b2[i] = a.b2[i];
+
+    // ---- the weight stream: chunk number gc (counted over all tiles of this workgroup) lives in slot gc % NSLOT
+    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.Ao_c6, 0, T::NCH * T::CHUNK, 0x00020000);
+    int gc = 0;                                                            // next chunk to consume (uniform)
+    auto request = [&](int c) {                                            // this wave's share of chunk c
+        const int src = (c % T::NCH) * T::CHUNK, slot = (c % T::NSLOT) * T::CHUNK;
+#pragma unroll
+        for (int i = 0; i < T::DPW; ++i) {
+            const int piece = (wave + T::WAVES * i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, reinterpret_cast<float*>(ldsw + slot + piece), 16, lane * 16, src + piece, 0, 0);
+        }
+    };
+    const int ntl = (L + 127) / 128, ntiles = a.B * ntl;                   // workgroup tiles of 128 positions
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_chunks = my_tiles * T::NCH;
+#pragma unroll
+    for (int c = 0; c < T::AHEAD; ++c) request(c);
+    // chunk gc has landed everywhere and the slot consumed before it is free again: one barrier for both, then the request
+    // for the chunk AHEAD of this one goes into the freed slot
+    auto next_chunk = [&]() -> const char* {
+        // this wave's part of chunk gc has landed: everything but its requests for the AHEAD - 1 chunks behind it (other
+        // VMEM issued since only makes the wait stricter); at the end of the stream fewer requests follow: wait for all
+        if (gc + T::AHEAD <= total_chunks)
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (((T::AHEAD - 1) * T::DPW) & 15) | ((((T::AHEAD - 1) * T::DPW) >> 4) << 14));
+        else
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (gc + T::AHEAD < total_chunks) request(gc + T::AHEAD);
+        const char* p = ldsw + (gc % T::NSLOT) * T::CHUNK + lane * 16;
+        ++gc;
+        return p;
+    };
+    // acc[m] = W[m] . B + bias over NKB k-blocks whose fragments arrive KPC k-blocks per chunk, [k-block][row tile][term]
+    auto gemm = [&](auto& acc, auto MT_, auto NKB_, auto KPC_, const float* bias, const auto& src) {
+        constexpr int MT = decltype(MT_)::value, NKB = decltype(NKB_)::value, KPC = decltype(KPC_)::value;
+        constexpr int NU = MT / 2;
+        {
+            const __bf16 z = (__bf16)0.f, one = (__bf16)(lhi ? 0.f : 1.f);
+            const bx_bf16x8 bf = {one, z, z, z, z, z, z, z};
+            bx_f32x16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                bx_bf16x8 af[3];
+                frag_rank2(bias[m * 32 + l31], 0.f, lhi == 0, af);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf, zero, 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf, acc[m], 0, 0, 0);
+            }
+        }
+        bx_bf16x8 bq[3], bn[3];
+        c6_bfrag(src[0], 0, bq);
+#pragma unroll
+        for (int ch = 0; ch < NKB / KPC; ++ch) {
+            const char* wl = next_chunk();
+            bx_bf16x8 a_cur[2][3], a_nxt[2][3];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a_cur[mm][t] = *reinterpret_cast<const bx_bf16x8*>(wl + (mm * 3 + t) * 1024);
+#pragma unroll
+            for (int kl = 0; kl < KPC; ++kl) {
+                const int kb = ch * KPC + kl;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const bool last_u = (u + 1 == NU);
+                    const int kln = last_u ? kl + 1 : kl, un = last_u ? 0 : u + 1;
+                    if (kln < KPC) {
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                            for (int t = 0; t < 3; ++t)
+                                a_nxt[mm][t] = *reinterpret_cast<const bx_bf16x8*>(wl + (((kln * MT) + un * 2 + mm) * 3 + t) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (last_u && kb + 1 < NKB) c6_bfrag(src[(kb + 1) >> 1], (kb + 1) & 1, bn);
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm)
+                            acc[u * 2 + mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mm][BX6_IA[t]], bq[BX6_IB[t]], acc[u * 2 + mm], 0, 0, 0);
+                    if (last_u && kb + 1 < NKB) {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) a_cur[mm][t] = a_nxt[mm][t];
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bq[t] = bn[t];
+            }
+        }
+    };
+
+    const float ln_m = a.ln_m[0], ln_s = a.ln_s[0];
+    const float n1_m = YNEXT ? a.n1_m[0] : 0.f, n1_s = YNEXT ? a.n1_s[0] : 0.f;
+    const bool has_mel = a.mel != nullptr, has_add = a.addend != nullptr;
+    const float one = lhi ? 0.f : 1.f;
+    const float invH = 1.f / (float)H;
+#define W6_SOFF(t, r) ((32 * (t) + ((r) & 3) + 8 * ((r) >> 2)) * L4)
+    for (int wt = blockIdx.x; wt < ntiles; wt += gridDim.x) {
+        const int b = __builtin_amdgcn_readfirstlane(wt / ntl);
+        const int l0 = __builtin_amdgcn_readfirstlane((wt % ntl) * 128 + wave * 32);
+        const int pos = l0 + l31;
+        const int voff = pos < L ? (4 * lhi * L + pos) * 4 : OOB;
+        __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * H * L), 0, H * L4, 0x00020000);
+        bx_f32x16 g[TH], x1[TH];
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rG, voff, W6_SOFF(t, r), 0));
+                x1[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, voff, W6_SOFF(t, r), 0));
+            }
+        if (has_mel) {
+            __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.mel + (size_t)(a.mel_bstride ? b : 0) * H * L), 0, H * L4, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    x1[t][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, voff, W6_SOFF(t, r), 0));
+        }
+        // ---- GEMM-o, GLU + residual, LN2
+        bx_f32x16 ao[TO];
+        gemm(ao, std::integral_constant<int, TO>{}, std::integral_constant<int, T::KBH>{}, std::integral_constant<int, 1>{}, bo, g);
+        float s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x1[t][r] = fmaf(ao[t][r], dws_sigmoid(ao[TH + t][r]), x1[t][r]);
+                s1 += x1[t][r];
+            }
+        const float mean = c6_xhalf_sum(s1) * invH;
+        float sv = 0.f;
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x1[t][r] -= mean;
+                sv = fmaf(x1[t][r], x1[t][r], sv);
+            }
+        const float alpha = ln_s / sqrtf(c6_xhalf_sum(sv) * invH);
+        bx_f32x16 y[TH];
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[t][r] = alpha * (x1[t][r] + ln_m);
+        // ---- GEMM-1, GELU
+        bx_f32x16 u[TF];
+        gemm(u, std::integral_constant<int, TF>{}, std::integral_constant<int, T::KBH>{}, std::integral_constant<int, 1>{}, b1, y);
+        bx_f32x16 ad[TH];
+        if (has_add) {
+            __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.addend + (size_t)b * H * L), 0, H * L4, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ad[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, voff, W6_SOFF(t, r), 0));
+        }
+#pragma unroll
+        for (int m = 0; m < TF; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[m][r] = dws_gelu(u[m][r]);
+        // ---- GEMM-2, output
+        bx_f32x16 f[TH];
+        gemm(f, std::integral_constant<int, TH>{}, std::integral_constant<int, T::KBF>{}, std::integral_constant<int, T::KPC2>{}, b2, u);
+        float so = 0.f;
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (x1[t][r] + mean) + f[t][r];
+                if (has_add) v += ad[t][r];
+                f[t][r] = v;
+                so += v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, voff, W6_SOFF(t, r), 0);
+            }
+        if constexpr (YNEXT) {
+            __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ynext + (size_t)b * H * L), 0, H * L4, 0x00020000);
+            const float* eb = a.e_next + (size_t)b * a.e_stride + step_row_off(a.e_step, a.e_tstride);
+            const float m2 = c6_xhalf_sum(so) * invH;
+            float sv2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    f[t][r] -= m2;
+                    sv2 = fmaf(f[t][r], f[t][r], sv2);
+                }
+            const float al2 = n1_s / sqrtf(c6_xhalf_sum(sv2) * invH);
+#pragma unroll
+            for (int t = 0; t < TH; ++t) {
+                const float ev = lhi ? 0.f : eb[t * 32 + l31];
+                bx_f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                const bx_f32x16 et = __builtin_amdgcn_mfma_f32_32x32x2f32(ev, one, z, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float yv = fmaf(al2, f[t][r] + n1_m, et[r]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), rY, voff, W6_SOFF(t, r), 0);
+                }
+            }
+        }
+    }
+#undef W6_SOFF
+}
+
+bool s4_tail_wide6_supported(int H, int ff) { return ff == 2 && H == 128; }
+
+int launch_s4_tail_wide6(int H, const S4TailArgs& a, hipStream_t s) {
+    DWS_CHECK(H == 128 && a.Ao_c6, DWS_ERR_STATE, "s4_tail_wide6: H=%d / weights not packed", H);
+    using T = Wide6Cfg<128, 2>;
+    ProfileScope ps("s4_tail_mfma_wide6", s);
+    static int ncu = 0;
+    if (ncu == 0) {
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_wide6_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_wide6_kernel<128, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        int dev = 0;
+        DWS_HIP(hipGetDevice(&dev));
+        DWS_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int ntiles = a.B * ceil_div(a.L, 128);
+    const int grid = std::min(ncu, ntiles);
+    if (a.ynext) hipLaunchKernelGGL((s4_tail_wide6_kernel<128, 2, true>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((s4_tail_wide6_kernel<128, 2, false>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, a);
+    return DWS_OK;
+}
+
+
 
 template <typename F>
 static void chain6_trace_launch(int H, int nwg, int waves, S4TailArgs a, hipStream_t s, F launch) {

@@ -68,6 +68,11 @@ int launch_chain_permute_cols(const float* w, float* out, int M, int K, hipStrea
 bool s4_tail_chain6_supported(int H, int ff);
 int launch_s4_tail_chain6(int H, const S4TailArgs& a, hipStream_t s);
 int launch_chain16_permute_cols(const float* w, float* out, int M, int K, hipStream_t s);
+// H = 128: the chain with one wave per SIMD and the weights streamed through an LDS ring; Ao_c6 then points at ONE blob
+// [Wo | W1 | W2] of k-block-major fragments (pack_a_bx6_kmajor)
+bool s4_tail_wide6_supported(int H, int ff);
+int launch_s4_tail_wide6(int H, const S4TailArgs& a, hipStream_t s);
+int launch_pack_a_bx6_kmajor(const float* w, void* out, int M, int K, hipStream_t s);
 int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s);
 bool pw_mfma_supported(int mode, int K, int M, int p);
 bool pw_mfma_ln_supported(int M);

@@ -558,6 +558,8 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     const int alt = getenv("DWS_TAIL_CFG") ? atoi(getenv("DWS_TAIL_CFG")) : 0;
     // H <= 64: the register-chained kernel (sashimi_chain.hip: a wave owns 32 positions, no LDS round trip between the
     // GEMMs, no barrier); DWS_TAIL_NO_CHAIN=1 keeps the LDS-tile kernel below (A/B runs, tests)
+    if (alt == 0 && a.Ao_c6 && s4_tail_wide6_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr)
+        return launch_s4_tail_wide6(H, a, s);       // precision = bf16x6, H = 128: one wave per SIMD, streamed weights
     if (alt == 0 && a.Ao_c6 && s4_tail_chain6_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr)
         return launch_s4_tail_chain6(H, a, s);      // precision = bf16x6: the same chain on the bf16 matrix cores, 3-term split
     if (alt == 0 && a.Ao_c && s4_tail_chain_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr)

@@ -5,7 +5,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 PART=${1:-1}
 if [ "$PART" = 1 ]; then
-  /usr/bin/time -f "%e s wall" -o $O/r05_bench_default_wallclock.txt python bench.py > $O/r05_bench_default.json 2> $O/r05_bench_default.err
+  SECONDS=0
+  python bench.py > $O/r05_bench_default.json 2> $O/r05_bench_default.err
+  echo "$SECONDS s wall (python bench.py, all legs)" > $O/r05_bench_default_wallclock.txt
   python bench.py --precision bf16x6 --no-extra > $O/r05_bench_c2_bf16x6.json 2>> $O/r05_bench_default.err
   for C in unet_d64_n6_T200 unet_d32_n6_T50_cond; do
     python bench.py --config $C --no-extra --no-cpu-baseline > $O/r05_bench_${C}.json 2>> $O/r05_bench_default.err
@@ -17,7 +19,7 @@ if [ "$PART" = 1 ]; then
   for f in $O/r05_bench_*.json; do echo "== $f"; python - "$f" <<'PY'
 import json, sys
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][0])
 except Exception as e:
     print("unreadable:", e); sys.exit(0)
 print({k: d.get(k) for k in ("value", "ms_per_step", "dtype")}, "roofline frac", (d.get("roofline") or {}).get("frac"))
