@@ -464,6 +464,29 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
         const int pos = contig ? pbase + 32 * n + l31 : p + n * dil;
         voffn[n] = (pos < L) ? (4 * lhi * L + pos) * 4 : 0x7ffffff0;
     }
+    constexpr bool TR_OK = 2 * XS >= WAVES * 2048;
+#ifdef DWS_WINO_DWORD_EPI
+    const bool vec_epi = false;
+#else
+    const bool vec_epi = TR_OK && al16 && ((((size_t)a.x_out | (size_t)a.skip) & 15) == 0);
+#endif
+    typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+    float* const trw = Tt + wave * 2048;
+    const int p0 = ((q0 >> log2d) << (log2d + 1)) + (q0 & (dil - 1));
+    const int n4 = (lane & 15) >> 3;
+    const int pos4 = (contig ? pbase + 32 * n4 : p0 + n4 * dil) + 4 * (lane & 7);
+    const int voff4 = (pos4 < L) ? ((lane >> 4) * L + pos4) * 4 : 0x7ffffff0;
+    const int voff4s = first ? 0x7ffffff0 : voff4;      // the first layer starts the running sum: reads 0
+    f32x4 sk[TR_OK ? MS : 1][TR_OK ? 8 : 1];
+    if constexpr (TR_OK) {
+        if (vec_epi) {   // requested here: their HBM round trip passes under GEMM2
+#pragma unroll
+            for (int m = 0; m < MS; ++m)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    sk[m][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rSk, voff4s, ((wave * MS + m) * 32 + 4 * i) * L4, 2));
+        }
+    }
     // (Measured and dropped, same box: one row tile of [res; skip] at a time, so that the x' stores go out under the skip
     // tile's MFMAs: 58.1 against 58.8 / 59.5 ms per step in back-to-back runs -- inside the run-to-run spread.)
     f32x4 c_cur[1 + MS], c_nxt[1 + MS];
@@ -501,35 +524,64 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     // no-return float atomic (one add per element and layer, layers are stream-ordered: the same bits as load-add-store,
     // without the load).  Buffer instructions: the row rides in the scalar offset, the lane part is one 32-bit offset per
     // column; a position past L gets an out-of-range offset and is dropped.
+    // Round 5: where the rows are 16-byte aligned and the two transformed-chunk buffers (dead since GEMM1) give every wave an
+    // 8 KB slot, the tiles leave as row-major 16-byte rows -- each row tile transposed through the wave's own slot (no other
+    // wave touches it: no barrier), skip as load-add-store (one workgroup owns an element per layer): 16 + 16 MS wide VMEM
+    // instructions per lane instead of 32 + 32 MS dword stores / atomics, whose ISSUE was the epilogue's time (12-18 k cycles
+    // per tile, `profiles/r04_wino_phase_trace.txt`).  DWS_WINO_DWORD_EPI (build flag) keeps the dword form for A/B runs.
+    if (TR_OK && vec_epi) {
+      if constexpr (TR_OK) {
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int voff = voffn[n];
-        if (!last) {
-            const int s0 = (wave * 32) * L4;
+        for (int m = 0; m < 1 + MS; ++m) {
+            if (m == 0 && last) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc2[0][n][r] * rs;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rXo, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MS; ++m) {
-            const int s0 = ((wave * MS + m) * 32) * L4;
-            if (first) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc2[1 + m][n][r];   // (bit_cast straight from a vector element picks element 0)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voff,
-                                                          s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
-                }
-            } else {
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc2[1 + m][n][r], rSk, voff,
-                                                                    s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
+                    trw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 64 + n * 32 + l31] = (m == 0) ? acc2[0][n][r] * rs : acc2[m][n][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave, its LDS operations execute in order
+            const int row0 = (m == 0) ? wave * 32 : (wave * MS + (m - 1)) * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(trw + ((lane >> 4) + 4 * i) * 64 + 4 * (lane & 15));
+                if (m > 0) v += sk[m > 0 ? m - 1 : 0][i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4e, v), m == 0 ? rXo : rSk, voff4, (row0 + 4 * i) * L4, 2);
+                asm volatile("s_nop 1" ::: "memory");   // gfx950: no VALU write to a 16-byte store's data in the next slot (wavenet_bx6.hip)
+            }
+            asm volatile("" ::: "memory");
+        }
+      }
+    } else {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int voff = voffn[n];
+            if (!last) {
+                const int s0 = (wave * 32) * L4;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc2[0][n][r] * rs;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rXo, voff, s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
+                }
+            }
+    #pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                const int s0 = ((wave * MS + m) * 32) * L4;
+                if (first) {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc2[1 + m][n][r];   // (bit_cast straight from a vector element picks element 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voff,
+                                                              s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
+                    }
+                } else {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc2[1 + m][n][r], rSk, voff,
+                                                                        s0 + ((r & 3) + 8 * (r >> 2)) * L4, 0);
+                }
             }
         }
-    }
+}
     stamp(6);
     if (trc) {
         __builtin_amdgcn_s_waitcnt(0);   // everything (stores included) retired
