@@ -46,6 +46,14 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline(gpu):
     fl = d["full_loop"]
     assert fl["T"] == 200 and fl["finite"] and abs(fl["ms_per_step"] - fl["ms"] / 200) < 1e-9
     assert 0.9 < fl["ratio_to_timed_ms_per_step"] < 1.15, fl
+    # the fp32-equivalent split leg (precision=bf16x6): its own dtype string and roofline against 2.5 PFLOP/s / 6; never `value`
+    x6 = d["extra_bf16x6"]
+    assert x6["dtype"].startswith("f32-equivalent") and x6["ms_per_step"] > 0 and d["dtype"] == "f32"
+    assert abs(x6["roofline"]["peak"] - 2500.0 / 6) < 1e-6 and 0 < x6["roofline"]["frac"] < 1
+    # the whole host beside the best single process: N pinned B = 1 workers
+    wh = cb["whole_host"]
+    assert "error" not in wh and wh["workers"] >= 1 and wh["cores"] == wh["workers"] * wh["threads_per_worker"] and wh["value"] > 0
+    assert abs(d["gpu_over_cpu_whole_host"] - d["value"] / wh["value"]) < 1e-6 * d["gpu_over_cpu_whole_host"]
 
 
 def test_two_ranks_aggregate(gpu):
