@@ -611,6 +611,7 @@ DTYPE_NAMES = {
     "f32": "f32",
     "bf16x3": "bf16x3 split (hi/lo bf16 MFMA inputs, fp32 accumulate; ~1e-5 rel)",
     "bf16x6": "f32-equivalent (3-term bf16 split, 6 products, fp32 accumulate)",
+    "f16x3": "f32-class (2-term fp16 split of power-of-two scaled operands, 3 products, fp32 accumulate; 22 bits per operand)",
 }
 
 
@@ -621,9 +622,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="wnet_h256_d36_T200", choices=list(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6", "f16x3"],
                     help="WaveNet matrix arithmetic: exact-f32 MFMA (default); bf16x6 = fp32-equivalent 3-term bf16 split "
-                         "(six products, Winograd form); bf16x3 = 2-term split (~1e-5, narrower than fp32)")
+                         "(six products, Winograd form); f16x3 = 2-term fp16 split of scaled operands (three products, same kernel and "
+                         "same float64 acceptance); bf16x3 = 2-term bf16 split (~1e-5, narrower than fp32)")
     ap.add_argument("--mode", default="sample", choices=["sample", "train"],
                     help="sample: the headline reverse-diffusion step; train: one DP training step "
                          "(forward_train + backward + RCCL gradient all-reduce + Adam)")
@@ -756,7 +758,8 @@ def wavenet_traffic(precision, kname, executed):
     add 1.6 % to the count, so the window is 3 % there) -- a file left over from another kernel version is refused, not
     silently reported.  Returns (bytes or None, file name or the reason of the refusal)."""
     import glob
-    per_inst, tol = (4096.0, 0.01) if precision == "f32" else (32768.0 / 6.0, 0.03)
+    # (both split precisions run the same kernel template: the MFMA count per launch tells a bf16x6 file from an f16x3 one)
+    per_inst, tol = {"f32": (4096.0, 0.01), "bf16x6": (32768.0 / 6.0, 0.03), "f16x3": (32768.0 / 3.0, 0.03)}[precision]
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wavenet_traffic_%s.json" % precision)), reverse=True)
     if precision == "f32":
         tfiles += sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wavenet_traffic.json")), reverse=True)
@@ -895,7 +898,8 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
         # dominant kernel: the fused residual layer.  Timed with HIP events on its own
         # launch stream inside the engine (eager launches, outside any capture).
         flops, bytes_ = layer_algorithmic_work(cfg)
-        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.precision]
+        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0,
+                "f16x3": PEAK_BF16_MFMA_TFLOPS / 3.0}[args.precision]      # fp16 and bf16 MFMA run at the same dense rate
         # every launch position of a step takes its MEDIAN over five eager steps (the first eager step after graph replays
         # runs with cold caches and lazily created events: averaged in, it put this leg 1.5 % above the launch durations
         # rocprof sees inside the timed replays)
@@ -913,7 +917,7 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
             lib.dws_profile_disable()
             step_ms = tot_ms.value / max(n_launch.value, 1) * NLAY
         avg_ms = step_ms / NLAY
-        wino = (args.precision == "f32" and os.environ.get("DWS_WN_DIRECT") is None) or args.precision == "bf16x6"
+        wino = (args.precision == "f32" and os.environ.get("DWS_WN_DIRECT") is None) or args.precision in ("bf16x6", "f16x3")
         # `achieved` / `frac` are priced on the flops the kernel EXECUTES (frac <= 1 by construction): the Winograd
         # F(2,3) form does 8 C^2 instead of 12 C^2 flop per position for the convolution.  The direct-convolution
         # algorithmic flops of SURVEY.md 8(d) over the same time are reported beside it as `effective_*`.
@@ -921,12 +925,13 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
         ach = executed / (avg_ms * 1e-3) / 1e12
         eff = flops / (avg_ms * 1e-3) / 1e12
         kname = {"f32": "wn_layer_wino_kernel" if wino else "wn_layer_mfma_kernel", "bf16x3": "wn_layer_bf16x3_kernel",
-                 "bf16x6": "wn_layer_bx6_kernel"}[args.precision]
+                 "bf16x6": "wn_layer_bx6_kernel", "f16x3": "wn_layer_bx6_kernel"}[args.precision]
         traffic, traffic_note = None, None
-        if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and args.precision in ("f32", "bf16x6"):
+        if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 and args.precision in ("f32", "bf16x6", "f16x3"):
             traffic, traffic_note = wavenet_traffic(args.precision, kname, executed)
         result["roofline"] = {
-            "kernel": "%s<%d,%d>" % (kname, cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
+            "kernel": "%s<%s%d,%d>" % (kname, {"bf16x6": "SplitBf16x3,", "f16x3": "SplitF16x2,"}.get(args.precision, ""),
+                                       cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
             "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_note,
             "executed_flops_per_launch": executed,
@@ -990,7 +995,9 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
         #   bf16x6: fp32-EQUIVALENT (exact 3-term split of every operand, six products, fp32 accumulate, Winograd form);
         #           its error against float64 is measured beside the f32 path's in tests/test_bf16x6_gpu.py
         #   bf16x3: 2-term split, ~1e-5 relative: narrower than fp32, reported for comparison only
-        for prec in ("bf16x6", "bf16x3"):
+        #   f16x3:  2-term fp16 split of power-of-two scaled operands, three products, the same kernel and the same float64
+        #           acceptance (tests/test_f16x3_gpu.py): 22 bits per operand, so fp32-CLASS rather than fp32-faithful
+        for prec in ("bf16x6", "f16x3", "bf16x3"):
             net.set_option("precision", prec)
             run(max(args.warmup, 1))
             barrier()
@@ -999,27 +1006,33 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
             barrier()
             ms3 = (time.perf_counter() - t0) / args.steps * 1e3
             leg = {"ms_per_step": ms3, "value": B * L / (T * ms3 * 1e-3), "unit": "audio samples/s", "dtype": DTYPE_NAMES[prec]}
-            if prec == "bf16x6":
+            if prec in ("bf16x6", "f16x3"):
                 NLAY = cfg["model"]["num_res_layers"]
+                nprod = 6 if prec == "bf16x6" else 3
+                kn = "wn_layer_bx6_kernel<%s," % ("SplitBf16x3" if prec == "bf16x6" else "SplitF16x2")
                 eager = lambda k: _lib.check(lib.dws_sampler_steps(net._handle, x.data_ptr(), *ptabs, T, T - 1, k, seed, 0, stream))
                 st = profiled_step_ms(lib, eager, b"wn_layer", 5, NLAY)
                 if st is not None:
                     flops, bytes_ = layer_algorithmic_work(cfg)
-                    executed = wino_executed_work(cfg)      # fp32-equivalent GEMM flops; the MFMA pipe executes 6x that in bf16
+                    executed = wino_executed_work(cfg)      # fp32-equivalent GEMM flops; the MFMA pipe executes nprod x that
                     avg = st / NLAY
-                    peak6 = PEAK_BF16_MFMA_TFLOPS / 6.0
+                    peakn = PEAK_BF16_MFMA_TFLOPS / nprod
                     leg["roofline"] = {
-                        "kernel": "wn_layer_bx6_kernel<%d,%d>" % (cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
-                        "bound": "mfma", "achieved": executed / (avg * 1e-3) / 1e12, "peak": peak6, "unit": "TFLOP/s",
-                        "frac": executed / (avg * 1e-3) / 1e12 / peak6, "avg_launch_ms": avg,
-                        **dict(zip(("traffic", "traffic_source"), wavenet_traffic("bf16x6", "wn_layer_bx6_kernel", executed)
+                        "kernel": "%s%d,%d>" % (kn, cfg["model"]["res_channels"], cfg["model"]["skip_channels"]),
+                        "bound": "mfma", "achieved": executed / (avg * 1e-3) / 1e12, "peak": peakn, "unit": "TFLOP/s",
+                        "frac": executed / (avg * 1e-3) / 1e12 / peakn, "avg_launch_ms": avg,
+                        **dict(zip(("traffic", "traffic_source"), wavenet_traffic(prec, "wn_layer_bx6_kernel", executed)
                                    if args.config == "wnet_h256_d36_T200" and cfg["B"] == 16 else (None, None))),
-                        "peak_note": "2.5 PFLOP/s dense bf16 MFMA / 6 products per fp32-equivalent multiply-add",
-                        "executed_flops_per_launch": executed, "bf16_mfma_flops_per_launch": 6 * executed,
+                        "peak_note": "2.5 PFLOP/s dense 16-bit MFMA / %d products per fp32-equivalent multiply-add" % nprod,
+                        "executed_flops_per_launch": executed, "mfma_flops_per_launch": nprod * executed,
                         "algorithmic_bytes_per_launch": bytes_,
                         "hbm_achieved_GBs": bytes_ / (avg * 1e-3) / 1e9, "hbm_frac": bytes_ / (avg * 1e-3) / 1e9 / PEAK_HBM_GBS}
-                leg["note"] = ("opt-in precision=bf16x6: fp32-equivalent accuracy (error vs a float64 evaluation <= 2x the "
-                               "exact-f32 MFMA path's, tests/test_bf16x6_gpu.py); not the headline value")
+                if prec == "bf16x6":
+                    leg["note"] = ("opt-in precision=bf16x6: fp32-equivalent accuracy (error vs a float64 evaluation <= 2x the "
+                                   "exact-f32 MFMA path's, tests/test_bf16x6_gpu.py); not the headline value")
+                else:
+                    leg["note"] = ("opt-in precision=f16x3: 22-bit operands, fp32 accumulate; accepted by the same float64 "
+                                   "criterion as bf16x6 (tests/test_f16x3_gpu.py); not the headline value")
             else:
                 leg["note"] = ("opt-in precision=bf16x3 (hi/lo bf16 MFMA inputs, fp32 accumulate); max rel err vs reference "
                                "1e-5: narrower than fp32; not the headline value")

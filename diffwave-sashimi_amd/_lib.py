@@ -76,6 +76,7 @@ _SIGS = {
     "dws_mel_spectrogram": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int64, c_f32p, c_f32p, ctypes.c_int32,
                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p, ctypes.c_void_p]),
     "dws_gemm_bf16x6": (ctypes.c_int, [c_f32p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_void_p]),
+    "dws_gemm_f16x3": (ctypes.c_int, [c_f32p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_float] * 2 + [ctypes.c_void_p]),
     "dws_profile_enable": (ctypes.c_int, [ctypes.c_char_p]),
     "dws_profile_query": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     "dws_profile_query_each": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),

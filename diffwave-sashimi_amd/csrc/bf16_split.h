@@ -63,4 +63,84 @@ __device__ __forceinline__ void frag_rank2(float v0, float v1, bool lower_half, 
     out[2] = bx_bf16x8{a2, b2, z, z, z, z, z, z};
 }
 
+// ---- split policies: what the templated GEMM code of wavenet_bx6.hip needs to know about a split ------------------------
+// SplitBf16x3: the exact 3-term bf16 split above (six products): fp32-FAITHFUL, every operand carries its 24 bits.
+struct SplitBf16x3 {
+    typedef bx_bf16x8 v8;
+    typedef bx_bf16x4 v4;
+    static constexpr int NT = 3, NP = 6;           // terms per operand, partial products per term pair
+    static constexpr bool SCALED = false;          // bf16 has fp32's exponent range: no operand scaling
+    static constexpr float SX = 1.f, SG = 1.f;
+    __device__ static constexpr int ia(int t) { return BX6_IA[t]; }
+    __device__ static constexpr int ib(int t) { return BX6_IB[t]; }
+    __device__ static __forceinline__ bx_f32x16 mfma(const v8& a, const v8& b, const bx_f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void split4(const float (&x)[4], v4 (&p)[3]) { split3x4(x, p[0], p[1], p[2]); }
+    __device__ static __forceinline__ void split1(float x, v8 (&out)[3], int i) {
+        __bf16 a, b, c;
+        split3(x, a, b, c);
+        out[0][i] = a; out[1][i] = b; out[2][i] = c;
+    }
+    __device__ static __forceinline__ void rank2(float v0, float v1, bool lower_half, v8 (&out)[3]) { frag_rank2(v0, v1, lower_half, out); }
+    __device__ static __forceinline__ void bits(float x, unsigned short (&b)[3]) {   // the terms as stored by the packers
+        __bf16 p0, p1, p2;
+        split3(x, p0, p1, p2);
+        b[0] = __builtin_bit_cast(unsigned short, p0); b[1] = __builtin_bit_cast(unsigned short, p1); b[2] = __builtin_bit_cast(unsigned short, p2);
+    }
+    __device__ static __forceinline__ v8 bvals(float v0, float v1) {   // B fragment of a correction k-block: exact small values
+        const __bf16 z = (__bf16)0.f;
+        return v8{(__bf16)v0, (__bf16)v1, z, z, z, z, z, z};
+    }
+};
+
+// SplitF16x2 ("f16x3"): x = h + l with h = fp16(x), l = fp16(x - h): 22 significand bits, THREE products (h h, h l, l h; the
+// dropped l l is 2^-22 of |x w|).  Not fp32-faithful element by element -- 2 bits short, and fp16's exponent range needs
+// power-of-two operand scaling so that the low terms stay normal (activations x 2^6, gate x 2^12, each weight matrix by its
+// own power of two; all undone exactly on the fp32 accumulators) -- but in a K >= 256 contraction its representation error
+// is a fraction of the fp32 ACCUMULATION error that both splits and the f32 path share, at half the matrix work of bf16x6.
+// Accepted by the same float64 criterion (tests/test_bf16x6_gpu.py); values beyond 2^9 (activations) overflow fp16.
+typedef _Float16 hx_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hx_f16x4 __attribute__((ext_vector_type(4)));
+struct SplitF16x2 {
+    typedef hx_f16x8 v8;
+    typedef hx_f16x4 v4;
+    static constexpr int NT = 2, NP = 3;
+    static constexpr bool SCALED = true;
+    static constexpr float SX = 64.f, SG = 4096.f;
+    __device__ static constexpr int ia(int t) { return t == 0 ? 1 : 0; }     // (l, h), (h, l), (h, h)
+    __device__ static constexpr int ib(int t) { return t == 1 ? 1 : 0; }
+    __device__ static __forceinline__ bx_f32x16 mfma(const v8& a, const v8& b, const bx_f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void split4(const float (&x)[4], v4 (&p)[2]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 h = (_Float16)x[e];
+            p[0][e] = h;
+            p[1][e] = (_Float16)(x[e] - (float)h);
+        }
+    }
+    __device__ static __forceinline__ void split1(float x, v8 (&out)[2], int i) {
+        const _Float16 h = (_Float16)x;
+        out[0][i] = h;
+        out[1][i] = (_Float16)(x - (float)h);
+    }
+    __device__ static __forceinline__ void bits(float x, unsigned short (&b)[2]) {
+        const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+        b[0] = __builtin_bit_cast(unsigned short, h); b[1] = __builtin_bit_cast(unsigned short, l);
+    }
+    __device__ static __forceinline__ void rank2(float v0, float v1, bool lower_half, v8 (&out)[2]) {
+        const _Float16 z = (_Float16)0.f;
+        out[0] = v8{z, z, z, z, z, z, z, z};
+        out[1] = out[0];
+        split1(lower_half ? v0 : 0.f, out, 0);
+        split1(lower_half ? v1 : 0.f, out, 1);
+    }
+    __device__ static __forceinline__ v8 bvals(float v0, float v1) {
+        const _Float16 z = (_Float16)0.f;
+        return v8{(_Float16)v0, (_Float16)v1, z, z, z, z, z, z};
+    }
+};
+
 }  // namespace dws

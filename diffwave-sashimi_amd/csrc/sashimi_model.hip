@@ -516,11 +516,11 @@ struct SashimiModel : dws_model {
                         DWS_TRY(l->A1_c6.ensure((size_t)FF * H * H * 6));
                         DWS_TRY(l->A2_c6.ensure((size_t)FF * H * H * 6));
                         DWS_TRY(launch_chain16_permute_cols(P(l->prefix + ".layer.output_linear.0.weight"), chain_tmp.f(), 2 * H, H, s));
-                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->Ao_c6.p, 2 * H, H, s));
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->Ao_c6.p, 2 * H, H, WN_SPLIT_BF16X6, nullptr, s));
                         DWS_TRY(launch_chain16_permute_cols(l->W1.f(), chain_tmp.f(), FF * H, H, s));
-                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A1_c6.p, FF * H, H, s));
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A1_c6.p, FF * H, H, WN_SPLIT_BF16X6, nullptr, s));
                         DWS_TRY(launch_chain16_permute_cols(l->W2.f(), chain_tmp.f(), H, FF * H, s));
-                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A2_c6.p, H, FF * H, s));
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A2_c6.p, H, FF * H, WN_SPLIT_BF16X6, nullptr, s));
                     } else if (bf16x6 && s4_tail_wide6_supported(H, FF)) {   // one blob [Wo | W1 | W2], k-block-major fragments
                         DWS_TRY(chain_tmp.ensure((size_t)FF * H * H * 4));
                         DWS_TRY(l->Ao_c6.ensure((size_t)(2 + 2 * FF) * H * H * 6));

@@ -31,6 +31,7 @@ struct WnLayerArgs {
     float* gate_ws;        // generic path scratch [B, C, L]
     float* hsave;          // nullable (training): pre-gate activations H of this layer [B, 2C, L]
     int B, L, dilation, first_layer, last_layer;
+    const float* wscale;   // fp16-split path only: the two power-of-two scales this layer's A1 / A2 were packed with
     unsigned long long* trace;   // nullable (tools only): s_memtime stamps [tile][wave][8] of the Winograd kernel's phases
 };
 
@@ -74,12 +75,17 @@ int launch_wn_layer_bf16x3(int C, int S, const WnLayerArgs& a, hipStream_t s);
 int launch_pack_a_bf16x3(const float* w, void* out, int M, int K, hipStream_t s);
 int launch_wn_bias_tap_bf16(const float* Wd_all, const float* part_t, const float* bias1_all, void* Abt, int NL, int B, int C,
                             hipStream_t s);
-// bf16x6 path (wavenet_bx6.hip): Winograd F(2,3) layer on the bf16 matrix cores, 3-term split, six products
+// split-precision path (wavenet_bx6.hip): Winograd F(2,3) layer on the bf16 / fp16 matrix cores.
+//   WN_SPLIT_BF16X6: 3 bf16 terms per operand, six products (exact split: fp32-faithful)
+//   WN_SPLIT_F16X3:  2 fp16 terms per operand, three products, power-of-two operand scaling (22 bits per operand)
+enum { WN_SPLIT_BF16X6 = 0, WN_SPLIT_F16X3 = 1 };
+inline int wn_split_terms(int split) { return split == WN_SPLIT_F16X3 ? 2 : 3; }
 bool wn_layer_bx6_supported(int C, int S);
-int launch_wn_layer_bx6(int C, int S, const WnLayerArgs& a, hipStream_t s);
-int launch_pack_a1_bx6(const float* w, void* out, int C, hipStream_t s);          // folded [2C][C][3] -> G0..G3 fragments, 3 terms
-int launch_pack_a_bx6(const float* w, void* out, int M, int K, hipStream_t s);    // row-major [M][K] -> fragments, 3 terms
-int launch_gemm_bx6(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
+int launch_wn_layer_bx6(int C, int S, const WnLayerArgs& a, int split, hipStream_t s);
+int launch_weight_scale(const float* w, size_t n, float* out, hipStream_t s);     // *out = power of two bringing max|w| into (1, 2]
+int launch_pack_a1_bx6(const float* w, void* out, int C, int split, const float* scale, hipStream_t s);        // folded [2C][C][3] -> G0..G3 fragments
+int launch_pack_a_bx6(const float* w, void* out, int M, int K, int split, const float* scale, hipStream_t s);  // row-major [M][K] -> fragments
+int launch_gemm_bx6(const float* A, const float* B, float* C, int M, int N, int K, int split, float sa, float sb, hipStream_t s);
 int launch_wn_final(int S, const WnFinalArgs& a, hipStream_t s);
 
 }  // namespace dws

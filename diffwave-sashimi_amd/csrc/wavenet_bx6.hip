@@ -38,9 +38,6 @@ namespace dws {
 
 typedef float bx6_f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bx_bf16x8 bx6_load_frag(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(bx_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
 // The activation streams (x in, x' out, running skip in / out: each element touched once per launch, 1 GB in all) carry the
 // nontemporal policy so that they do not push the weight fragments -- 3.75 MB that every tile re-reads -- out of the
 // 4 MB L2 of an XCD.
@@ -66,9 +63,11 @@ __device__ __forceinline__ float bx6_gate(float t, float s) {   // tanh(t) * sig
 
 // ---- weight packing (commit time) ----------------------------------------------------------------------------------
 // Folded dilated-conv weight [2C][C][3] -> Winograd matrices G0..G3 (the f32 path's formulas and roundings,
-// wavenet_wino.hip: wino_dconv_kernel) -> three bf16 terms in A-fragment order:
-//   out[((((mt * NKB + kb) * 4 + j) * 3 + term) * 64 + lane) * 8 + e] = term of G_j[mt*32 + (lane & 31)][kb*16 + 8*(lane >> 5) + e]
-__global__ void pack_a1_bx6_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int C) {
+// wavenet_wino.hip: wino_dconv_kernel) -> the split's NT terms in A-fragment order:
+//   out[((((mt * NKB + kb) * 4 + j) * NT + term) * 64 + lane) * 8 + e] = term of G_j[mt*32 + (lane & 31)][kb*16 + 8*(lane >> 5) + e]
+// Scaled splits (fp16 terms) multiply by *scale first: a power of two chosen per matrix by weight_scale_kernel.
+template <typename P>
+__global__ void pack_a1_bx6_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int C, const float* __restrict__ scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)2 * C * C * 4) return;
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), j = (int)((i >> 9) & 3);
@@ -83,46 +82,85 @@ __global__ void pack_a1_bx6_kernel(const float* __restrict__ w, unsigned short* 
     else if (j == 1) g = 0.5f * ((w0 + w2) + w1);
     else if (j == 2) g = 0.5f * ((w0 + w2) - w1);
     else g = w2;
-    __bf16 p0, p1, p2;
-    split3(g, p0, p1, p2);
-    const size_t base = ((r * 4 + j) * 3) * 512 + (size_t)lane * 8 + e;
-    out[base] = __builtin_bit_cast(unsigned short, p0);
-    out[base + 512] = __builtin_bit_cast(unsigned short, p1);
-    out[base + 1024] = __builtin_bit_cast(unsigned short, p2);
+    if (P::SCALED) g *= *scale;
+    unsigned short b[P::NT];
+    P::bits(g, b);
+    const size_t base = ((r * 4 + j) * P::NT) * 512 + (size_t)lane * 8 + e;
+#pragma unroll
+    for (int t = 0; t < P::NT; ++t) out[base + t * 512] = b[t];
 }
 
-// Row-major fp32 W[M][K] -> out[(((mt * NKB + kb) * 3 + term) * 64 + lane) * 8 + e]
-__global__ void pack_a_bx6_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int M, int K) {
+// Row-major fp32 W[M][K] -> out[(((mt * NKB + kb) * NT + term) * 64 + lane) * 8 + e]
+template <typename P>
+__global__ void pack_a_bx6_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int M, int K, const float* __restrict__ scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)M * K) return;
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const size_t r = i >> 9;
     const int nkb = K / 16;
     const int kb = (int)(r % nkb), mt = (int)(r / nkb);
-    const float v = w[(size_t)(mt * 32 + (lane & 31)) * K + kb * 16 + 8 * (lane >> 5) + e];
-    __bf16 p0, p1, p2;
-    split3(v, p0, p1, p2);
-    const size_t base = (r * 3) * 512 + (size_t)lane * 8 + e;
-    out[base] = __builtin_bit_cast(unsigned short, p0);
-    out[base + 512] = __builtin_bit_cast(unsigned short, p1);
-    out[base + 1024] = __builtin_bit_cast(unsigned short, p2);
+    float v = w[(size_t)(mt * 32 + (lane & 31)) * K + kb * 16 + 8 * (lane >> 5) + e];
+    if (P::SCALED) v *= *scale;
+    unsigned short b[P::NT];
+    P::bits(v, b);
+    const size_t base = (r * P::NT) * 512 + (size_t)lane * 8 + e;
+#pragma unroll
+    for (int t = 0; t < P::NT; ++t) out[base + t * 512] = b[t];
 }
 
-int launch_pack_a1_bx6(const float* w, void* out, int C, hipStream_t s) {
-    const size_t n = (size_t)2 * C * C * 4;
-    hipLaunchKernelGGL(pack_a1_bx6_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, (unsigned short*)out, C);
+// *out = 2^(1 - ceil(log2 max|w|)): the power of two that brings the largest weight of a matrix into (1, 2]  (one
+// workgroup; commit time).  The Winograd combinations G1, G2 of three taps then stay below 3, every fp16 high term is
+// normal down to 2^-14 and the low terms resolve 2^-25 absolute = 2^-26 of the matrix maximum or better.
+__global__ __launch_bounds__(1024) void weight_scale_kernel(const float* __restrict__ w, size_t n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+        int ex = 0;
+        if (m > 0.f && m < 3.0e38f) {
+            frexpf(m, &ex);                         // m = f * 2^ex, f in [0.5, 1)  ->  m * 2^(1 - ex) in [1, 2)
+            if (ex > 100) ex = 100;
+            if (ex < -100) ex = -100;
+        }
+        *out = ldexpf(1.f, 1 - ex);
+    }
+}
+
+int launch_weight_scale(const float* w, size_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, s, w, n, out);
     return DWS_OK;
 }
 
-int launch_pack_a_bx6(const float* w, void* out, int M, int K, hipStream_t s) {
+int launch_pack_a1_bx6(const float* w, void* out, int C, int split, const float* scale, hipStream_t s) {
+    const size_t n = (size_t)2 * C * C * 4;
+    if (split == WN_SPLIT_F16X3) {
+        DWS_CHECK(scale != nullptr, DWS_ERR_INVALID, "pack_a1: the fp16 split needs the matrix scale");
+        hipLaunchKernelGGL(pack_a1_bx6_kernel<SplitF16x2>, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, (unsigned short*)out, C, scale);
+    } else {
+        hipLaunchKernelGGL(pack_a1_bx6_kernel<SplitBf16x3>, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, (unsigned short*)out, C, scale);
+    }
+    return DWS_OK;
+}
+
+int launch_pack_a_bx6(const float* w, void* out, int M, int K, int split, const float* scale, hipStream_t s) {
     DWS_CHECK(M % 32 == 0 && K % 16 == 0, DWS_ERR_UNSUPPORTED, "pack_a_bx6: M=%d K=%d", M, K);
     const size_t n = (size_t)M * K;
-    hipLaunchKernelGGL(pack_a_bx6_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, (unsigned short*)out, M, K);
+    if (split == WN_SPLIT_F16X3) {
+        DWS_CHECK(scale != nullptr, DWS_ERR_INVALID, "pack_a: the fp16 split needs the matrix scale");
+        hipLaunchKernelGGL(pack_a_bx6_kernel<SplitF16x2>, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, (unsigned short*)out, M, K, scale);
+    } else {
+        hipLaunchKernelGGL(pack_a_bx6_kernel<SplitBf16x3>, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, (unsigned short*)out, M, K, scale);
+    }
     return DWS_OK;
 }
 
 // ---- the layer kernel ----------------------------------------------------------------------------------------------
-template <int C, int S>
+template <int C, int S, int NT>
 struct Bx6Tile {
     static constexpr int WAVES = C / 32;          // one (tanh, sigmoid) tile pair per wave
     static constexpr int NTH = WAVES * 64;
@@ -132,9 +170,9 @@ struct Bx6Tile {
     static constexpr int NKB = C / 16;            // k-blocks of 16 channels
     static constexpr int MS = S / C;              // skip tiles per wave
     static constexpr int RAW_FLOATS = KC * 4 * NP;          // one raw chunk: [row][shift][32] (or [row][128] contiguous)
-    static constexpr int BOP_BYTES = (KC / 8) * 4 * 3 * NP * 16;   // one transformed chunk: [octet][product][term][column] items
+    static constexpr int BOP_BYTES = (KC / 8) * 4 * NT * NP * 16;   // one transformed chunk: [octet][product][term][column] items
     static constexpr int STAGE_FLOATS = 2 * RAW_FLOATS + 2 * BOP_BYTES / 4;
-    static constexpr int GATE_BYTES = (C / 8) * 3 * 64 * 16;       // gate tile: [octet][term][column] items
+    static constexpr int GATE_BYTES = (C / 8) * NT * 64 * 16;       // gate tile: [octet][term][column] items
     static constexpr int MAIN_FLOATS = STAGE_FLOATS > GATE_BYTES / 4 ? STAGE_FLOATS : GATE_BYTES / 4;
     static constexpr int TR_FLOATS = 32 * 64;     // a wave's transpose slot: one row tile x 64 columns
     static constexpr int LDS_FLOATS = MAIN_FLOATS + WAVES * TR_FLOATS;
@@ -143,9 +181,12 @@ struct Bx6Tile {
                   (TITEMS % NTH == 0) && LDS_FLOATS * 4 <= 163840, "channel counts");
 };
 
-template <int C, int S, bool EXTRA>
+template <typename P, int C, int S, bool EXTRA>
 __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel(WnLayerArgs a, int log2d) {
-    using T = Bx6Tile<C, S>;
+    using T = Bx6Tile<C, S, P::NT>;
+    using v8 = typename P::v8;
+    using v4 = typename P::v4;
+    constexpr int NT = P::NT, NPR = P::NP, NA = 2 * P::NT;   // terms, products per term pair, A fragments per GEMM1 step
     constexpr int KC = T::KC, MS = T::MS, WAVES = T::WAVES, NCB = T::NCB, NTH = T::NTH, NKB = T::NKB;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     float* const Xraw = lds;                                            // 2 raw chunks (LDS-DMA target)
@@ -196,6 +237,10 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
 #pragma unroll
         for (int m = 0; m < 1 + MS; ++m) av2[m] = a.bias2[mt2[m] * 32 + l31];
     }
+    // scaled splits (fp16 terms): this layer's two weight matrices were packed times a power of two each (wscale[0], [1]);
+    // inv1 / inv2 undo weight x operand scale on the fp32 accumulators
+    const float ws1 = P::SCALED ? a.wscale[0] : 1.f, ws2 = P::SCALED ? a.wscale[1] : 1.f;
+    const float inv1 = 1.f / (ws1 * P::SX), inv2 = 1.f / (ws2 * P::SG);
 
     // ---- staging of raw x (wavenet_wino.hip: same three forms).  16-byte accesses need every row 16-byte aligned.
     const bool al16 = (L % 4 == 0) && ((((size_t)a.x_in | (size_t)a.x_out | (size_t)a.skip) & 15) == 0);
@@ -277,14 +322,18 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
                     ta[e] = d2 - d1; tb[e] = d1 - d3;
                 }
             }
-            bx_bf16x4 pa[3], pb[3];
-            split3x4(ta, pa[0], pa[1], pa[2]);
-            split3x4(tb, pb[0], pb[1], pb[2]);
-            char* dst = bo + ((((g4 >> 1) * 4 + 2 * jp) * 3) * 32 + l31) * 16 + (g4 & 1) * 8;
+            if (P::SCALED) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                *reinterpret_cast<bx_bf16x4*>(dst + t * 512) = pa[t];
-                *reinterpret_cast<bx_bf16x4*>(dst + (3 + t) * 512) = pb[t];
+                for (int e = 0; e < 4; ++e) { ta[e] *= P::SX; tb[e] *= P::SX; }
+            }
+            v4 pa[NT], pb[NT];
+            P::split4(ta, pa);
+            P::split4(tb, pb);
+            char* dst = bo + ((((g4 >> 1) * 4 + 2 * jp) * NT) * 32 + l31) * 16 + (g4 & 1) * 8;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                *reinterpret_cast<v4*>(dst + t * 512) = pa[t];
+                *reinterpret_cast<v4*>(dst + (NT + t) * 512) = pb[t];
             }
         }
         // The residual x of this wave's 32 output rows passes through the staging buffers exactly once: the wave keeps a
@@ -306,26 +355,27 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
 
     // ---- GEMM1: m_j[2C x 32] = G_j[2C x C] . t_j[C x 32], j = 0..3; this wave: row tiles `wave` and C/32 + wave
     bx_f32x16 acc[2][4];
-    __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A1, 0, 2 * C * 4 * C * 6, 0x00020000);
+    __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A1, 0, 2 * C * 4 * C * 2 * NT, 0x00020000);
     const int lane16 = lane * 16;
-    auto load_a1 = [&](bx_bf16x8 (&dst)[2][3], int kb, int j) {
+    auto load_a1 = [&](v8 (&dst)[2][NT], int kb, int j) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) dst[m][t] = bx6_load_frag(rA1, lane16, (((mt1[m] * NKB + kb) * 4 + j) * 3 + t) * 1024);
+            for (int t = 0; t < NT; ++t)
+                dst[m][t] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rA1, lane16, (((mt1[m] * NKB + kb) * 4 + j) * NT + t) * 1024, 0));
     };
 
     stage_dma(0);
     if (NCB > 1) stage_dma(1);
-    bx_bf16x8 a_cur[2][3], a_nxt[2][3];
+    v8 a_cur[2][NT], a_nxt[2][NT];
     load_a1(a_cur, chunk_of(0) * (KC / 16), 0);
     // chunk 0 has landed (this wave's part; the barrier makes it everyone's): all but the loads issued after it -- chunk 1
-    // and the 6 A fragments.  hipcc does not make a barrier wait for LDS-DMA.
+    // and the NA A fragments.  hipcc does not make a barrier wait for LDS-DMA.
     if (NCB > 1) {
-        if (x4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((RPW / 2 + 6) & 15) | (((RPW / 2 + 6) >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * RPW + 6) & 15) | (((2 * RPW + 6) >> 4) << 14));
+        if (x4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((RPW / 2 + NA) & 15) | (((RPW / 2 + NA) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * RPW + NA) & 15) | (((2 * RPW + NA) >> 4) << 14));
     } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NA);
     }
     __syncthreads();
     stamp(1);
@@ -336,26 +386,25 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         const float v2 = ((unsigned)(p + dil) < (unsigned)L) ? 1.f : 0.f;
         const float v3 = ((unsigned)(p + 2 * dil) < (unsigned)L) ? 1.f : 0.f;
         const float bi[4] = {v0 - v2, v1 + v2, v2 - v1, v1 - v3};
-        const __bf16 z = (__bf16)0.f;
         bx_f32x16 zero;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const __bf16 b0 = (__bf16)(lhi ? 0.f : bi[j]), b1 = (__bf16)((lhi || j != 1) ? 0.f : 1.f);
-            const bx_bf16x8 bf = {b0, b1, z, z, z, z, z, z};
+            // (scaled splits: the indicator operand carries the activation scale, the A rows the weight scale: exact)
+            const v8 bf = P::bvals(lhi ? 0.f : bi[j] * P::SX, (lhi || j != 1) ? 0.f : P::SX);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                bx_bf16x8 af[3];
-                frag_rank2(av1[m][j], j == 1 ? ab1[m] : 0.f, lhi == 0, af);
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf, zero, 0, 0, 0);
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf, acc[m][j], 0, 0, 0);
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf, acc[m][j], 0, 0, 0);
+                v8 af[NT];
+                P::rank2(av1[m][j] * ws1, j == 1 ? ab1[m] * ws1 : 0.f, lhi == 0, af);
+                acc[m][j] = zero;
+#pragma unroll
+                for (int t = NT - 1; t >= 0; --t) acc[m][j] = P::mfma(af[t], bf, acc[m][j]);
             }
         }
     }
     transform(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 6);   // chunk 1 has landed too (younger: only the 6 A fragments)
+    __builtin_amdgcn_s_waitcnt(0x0F70 | NA);   // chunk 1 has landed too (younger: only the NA A fragments)
     __syncthreads();                          // transformed chunk 0 visible, raw chunk 1 complete
 
     constexpr int SPC = (KC / 16) * 4;        // (k-block, product) steps per chunk
@@ -370,31 +419,31 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         int itn = it, jn = j + 1, cbn = cb;
         if (jn == 4) { jn = 0; ++itn; }
         if (itn == KC / 16) { itn = 0; ++cbn; }
-        const char* tb = Bop + (cb & 1) * T::BOP_BYTES + lhi * (4 * 3 * 512) + l31 * 16;
+        const char* tb = Bop + (cb & 1) * T::BOP_BYTES + lhi * (4 * NT * 512) + l31 * 16;
         if (st + 1 < SPC || cb + 1 < NCB) load_a1(a_nxt, chunk_of(cbn) * (KC / 16) + itn, jn);   // (no load left in flight behind the last step)
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole step (12 MFMAs) ahead of its use
-        bx_bf16x8 bq[3];
+        v8 bq[NT];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bq[t] = *reinterpret_cast<const bx_bf16x8*>(tb + ((2 * it * 4 + j) * 3 + t) * 512);
+        for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const v8*>(tb + ((2 * it * 4 + j) * NT + t) * 512);
         if (with_t) transform(cb + 1);
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NPR; ++t)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][BX6_IA[t]], bq[BX6_IB[t]], acc[m][j], 0, 0, 0);
+                acc[m][j] = P::mfma(a_cur[m][P::ia(t)], bq[P::ib(t)], acc[m][j]);
 #ifndef BX6_ABL_NO_INTERLEAVE
         if (with_t) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
+            for (int i = 0; i < 2 * NPR; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x302, BX6_T_PER_MFMA, 0);   // then VALU / DS read / DS write of the transform
+                __builtin_amdgcn_sched_group_barrier(0x302, BX6_T_PER_MFMA * 6 / NPR, 0);   // then VALU / DS read / DS write of the transform
             }
         }
 #endif
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a_cur[m][t] = a_nxt[m][t];
+            for (int t = 0; t < NT; ++t) a_cur[m][t] = a_nxt[m][t];
     };
     auto do_steps_from1 = [&](int cb) {
         if constexpr (SPC == 4) {
@@ -419,8 +468,8 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         do_steps_from1(cb);
         stamp(8 + 2 * cb);
         // transformed chunk cb+1 visible after the barrier; the LDS-DMA of chunk cb+2 must have landed too (hipcc does not
-        // count LDS-DMA among the accesses a barrier waits for): the only younger loads are the 6 A fragments of the next step
-        __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+        // count LDS-DMA among the accesses a barrier waits for): the only younger loads are the NA A fragments of the next step
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NA);
         __syncthreads();
         stamp(9 + 2 * cb);
     }
@@ -477,83 +526,84 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
                     ht = (acc[0][1][r] - acc[0][2][r]) - acc[0][3][r];
                     hs = (acc[1][1][r] - acc[1][2][r]) - acc[1][3][r];
                 }
+                if (P::SCALED) { ht *= inv1; hs *= inv1; }       // undo the operand scales (powers of two: exact)
                 if (EXTRA && melb && pos < L) {
                     ht += melb[(size_t)ch * L + pos];
                     hs += melb[(size_t)(C + ch) * L + pos];
                 }
-                const float g = bx6_gate(ht, hs);
+                const float g = bx6_gate(ht, hs) * P::SG;
                 if (n == 0) g0[e] = g; else g1[e] = g;
             }
         }
-        bx_bf16x4 s0[3], s1[3];
-        split3x4(g0, s0[0], s0[1], s0[2]);
-        split3x4(g1, s1[0], s1[1], s1[2]);
-        char* dst = gt + ((wave * 4 + qd) * 3 * 64) * 16 + lhi * 8;
+        v4 s0[NT], s1[NT];
+        P::split4(g0, s0);
+        P::split4(g1, s1);
+        char* dst = gt + ((wave * 4 + qd) * NT * 64) * 16 + lhi * 8;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            *reinterpret_cast<bx_bf16x4*>(dst + (t * 64 + gcol0) * 16) = s0[t];
-            *reinterpret_cast<bx_bf16x4*>(dst + (t * 64 + gcol1) * 16) = s1[t];
+        for (int t = 0; t < NT; ++t) {
+            *reinterpret_cast<v4*>(dst + (t * 64 + gcol0) * 16) = s0[t];
+            *reinterpret_cast<v4*>(dst + (t * 64 + gcol1) * 16) = s1[t];
         }
     }
     stamp(3);
 
     // ---- GEMM2: [res; skip][(C+S) x 64] = [Wr; Ws][(C+S) x C] . g[C x 64] (+ bias k-block); this wave: res tile `wave`
     // and its skip tiles, both column tiles
-    __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 6, 0x00020000);
-    bx_bf16x8 c_cur[1 + MS][3], c_nxt[1 + MS][3];
-    auto load_a2 = [&](bx_bf16x8 (&dst)[1 + MS][3], int kb) {
+    __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A2, 0, (C + S) * C * 2 * NT, 0x00020000);
+    v8 c_cur[1 + MS][NT], c_nxt[1 + MS][NT];
+    auto load_a2 = [&](v8 (&dst)[1 + MS][NT], int kb) {
 #pragma unroll
         for (int m = 0; m < 1 + MS; ++m)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) dst[m][t] = bx6_load_frag(rA2, lane16, ((mt2[m] * NKB + kb) * 3 + t) * 1024);
+            for (int t = 0; t < NT; ++t)
+                dst[m][t] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rA2, lane16, ((mt2[m] * NKB + kb) * NT + t) * 1024, 0));
     };
     const int rot2 = rot * (KC / 16);          // the same rotation of the k-block order in GEMM2
     auto kblock_of = [&](int kb) { const int k = kb + rot2; return k >= NKB ? k - NKB : k; };
     load_a2(c_cur, kblock_of(0));
     bx_f32x16 acc2[1 + MS][2];
     {
-        const __bf16 z = (__bf16)0.f, one = (__bf16)(lhi ? 0.f : 1.f);
-        const bx_bf16x8 bf = {one, z, z, z, z, z, z, z};
+        const v8 bf = P::bvals(lhi ? 0.f : P::SG, 0.f);      // a row of ones, at the gate operand's scale
         bx_f32x16 zero;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 #pragma unroll
         for (int m = 0; m < 1 + MS; ++m) {
-            bx_bf16x8 af[3];
-            frag_rank2(av2[m], 0.f, lhi == 0, af);
+            v8 af[NT];
+            P::rank2(av2[m] * ws2, 0.f, lhi == 0, af);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf, zero, 0, 0, 0);
-                acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf, acc2[m][n], 0, 0, 0);
-                acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf, acc2[m][n], 0, 0, 0);
+                acc2[m][n] = zero;
+#pragma unroll
+                for (int t = NT - 1; t >= 0; --t) acc2[m][n] = P::mfma(af[t], bf, acc2[m][n]);
             }
         }
     }
     __syncthreads();   // gate tile complete
     stamp(4);
-    const char* gb = gt + lhi * (3 * 64 * 16) + l31 * 16;
+    const char* gb = gt + lhi * (NT * 64 * 16) + l31 * 16;
 #pragma unroll 2
     for (int kb = 0; kb < NKB; ++kb) {
         const int kbn = (kb + 1 < NKB) ? kb + 1 : kb;
         load_a2(c_nxt, kblock_of(kbn));
         __builtin_amdgcn_sched_barrier(0);
-        const char* gk = gb + kblock_of(kb) * (2 * 3 * 64 * 16);
-        bx_bf16x8 bq[2][3];
+        const char* gk = gb + kblock_of(kb) * (2 * NT * 64 * 16);
+        v8 bq[2][NT];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) bq[n][t] = *reinterpret_cast<const bx_bf16x8*>(gk + (t * 64 + n * 32) * 16);
+            for (int t = 0; t < NT; ++t) bq[n][t] = *reinterpret_cast<const v8*>(gk + (t * 64 + n * 32) * 16);
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NPR; ++t)
 #pragma unroll
             for (int m = 0; m < 1 + MS; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c_cur[m][BX6_IA[t]], bq[n][BX6_IB[t]], acc2[m][n], 0, 0, 0);
+                    acc2[m][n] = P::mfma(c_cur[m][P::ia(t)], bq[n][P::ib(t)], acc2[m][n]);
 #pragma unroll
         for (int m = 0; m < 1 + MS; ++m)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) c_cur[m][t] = c_nxt[m][t];
+            for (int t = 0; t < NT; ++t) c_cur[m][t] = c_nxt[m][t];
     }
     stamp(5);
 
@@ -569,7 +619,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) trw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 64 + n * 32 + l31] = acc2[m][n][r];
+                for (int r = 0; r < 16; ++r) trw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 64 + n * 32 + l31] = P::SCALED ? acc2[m][n][r] * inv2 : acc2[m][n][r];
             // one wave, LDS operations of a wave execute in order: only the compiler has to be kept from moving the reads
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int row0 = (m == 0) ? wave * 32 : (wave * MS + (m - 1)) * 32;
@@ -604,7 +654,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
                 for (int r = 0; r < 16; ++r) {
                     const int so = s0 + ((r & 3) + 8 * (r >> 2)) * L4;
                     const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rXall, voffn[n], so, 0));
-                    const float v = (x + acc2[0][n][r]) * rs;
+                    const float v = (x + (P::SCALED ? acc2[0][n][r] * inv2 : acc2[0][n][r])) * rs;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rXo, voffn[n], so, 0);
                 }
             }
@@ -615,7 +665,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
                 for (int r = 0; r < 16; ++r) {
                     const int so = s0 + ((r & 3) + 8 * (r >> 2)) * L4;
                     const float old = first ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rSk, voffn[n], so, 0));
-                    const float v = old + acc2[1 + m][n][r];
+                    const float v = old + (P::SCALED ? acc2[1 + m][n][r] * inv2 : acc2[1 + m][n][r]);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rSk, voffn[n], so, 0);
                 }
             }
@@ -628,10 +678,10 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     }
 }
 
-template <int C, int S>
+template <typename P, int C, int S>
 static int launch_bx6_t(const WnLayerArgs& a, int log2d, hipStream_t s) {
-    ProfileScope ps("wn_layer_bx6", s);
-    using T = Bx6Tile<C, S>;
+    ProfileScope ps(P::NT == 3 ? "wn_layer_bx6" : "wn_layer_f16x3", s);
+    using T = Bx6Tile<C, S, P::NT>;
     const int dil = 1 << log2d;
     const int nblk = (a.L + 2 * dil - 1) / (2 * dil);
     const int ntl = (nblk * dil + 31) / 32;
@@ -639,12 +689,12 @@ static int launch_bx6_t(const WnLayerArgs& a, int log2d, hipStream_t s) {
     static const bool trace = std::getenv("DWS_BX6_TRACE") != nullptr;
     if (trace && !a.melc) {
         wino_trace_launch(ntiles, T::WAVES, a, s, [&](const WnLayerArgs& at) {
-            hipLaunchKernelGGL((wn_layer_bx6_kernel<C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, at, log2d);
-        }, "bx6");
+            hipLaunchKernelGGL((wn_layer_bx6_kernel<P, C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, at, log2d);
+        }, P::NT == 3 ? "bx6" : "f16x3");
         return DWS_OK;
     }
-    if (a.melc) hipLaunchKernelGGL((wn_layer_bx6_kernel<C, S, true>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
-    else hipLaunchKernelGGL((wn_layer_bx6_kernel<C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
+    if (a.melc) hipLaunchKernelGGL((wn_layer_bx6_kernel<P, C, S, true>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
+    else hipLaunchKernelGGL((wn_layer_bx6_kernel<P, C, S, false>), dim3(ntiles), dim3(T::NTH), 0, s, a, log2d);
     return DWS_OK;
 }
 
@@ -652,7 +702,16 @@ bool wn_layer_bx6_supported(int C, int S) {
     return (C == 64 && S == 64) || (C == 128 && S == 128) || (C == 128 && S == 256) || (C == 256 && S == 256);
 }
 
-int launch_wn_layer_bx6(int C, int S, const WnLayerArgs& a, hipStream_t s) {
+template <typename P>
+static int launch_bx6_p(int C, int S, const WnLayerArgs& a, int log2d, hipStream_t s) {
+    if (C == 64 && S == 64) return launch_bx6_t<P, 64, 64>(a, log2d, s);
+    if (C == 128 && S == 128) return launch_bx6_t<P, 128, 128>(a, log2d, s);
+    if (C == 128 && S == 256) return launch_bx6_t<P, 128, 256>(a, log2d, s);
+    if (C == 256 && S == 256) return launch_bx6_t<P, 256, 256>(a, log2d, s);
+    return set_error(DWS_ERR_UNSUPPORTED, "wn_layer_bx6: (C=%d,S=%d) not instantiated", C, S);
+}
+
+int launch_wn_layer_bx6(int C, int S, const WnLayerArgs& a, int split, hipStream_t s) {
     int log2d = 0;
     while ((1 << log2d) < a.dilation) ++log2d;
     DWS_CHECK((1 << log2d) == a.dilation, DWS_ERR_UNSUPPORTED, "wn_layer_bx6: dilation %d is not a power of two", a.dilation);
@@ -660,44 +719,53 @@ int launch_wn_layer_bx6(int C, int S, const WnLayerArgs& a, hipStream_t s) {
     DWS_CHECK((int64_t)(C > S ? C : S) * a.L * 4 < ((int64_t)1 << 31), DWS_ERR_UNSUPPORTED,
               "wn_layer_bx6: %d channels x L=%d exceed a 2 GiB tensor per clip", C > S ? C : S, a.L);
     DWS_CHECK(a.hsave == nullptr, DWS_ERR_UNSUPPORTED, "wn_layer_bx6: the training forward runs with precision=f32");
-    if (C == 64 && S == 64) return launch_bx6_t<64, 64>(a, log2d, s);
-    if (C == 128 && S == 128) return launch_bx6_t<128, 128>(a, log2d, s);
-    if (C == 128 && S == 256) return launch_bx6_t<128, 256>(a, log2d, s);
-    if (C == 256 && S == 256) return launch_bx6_t<256, 256>(a, log2d, s);
-    return set_error(DWS_ERR_UNSUPPORTED, "wn_layer_bx6: (C=%d,S=%d) not instantiated", C, S);
+    if (split == WN_SPLIT_F16X3) {
+        DWS_CHECK(a.wscale != nullptr, DWS_ERR_INVALID, "wn_layer_f16x3: no weight scales");
+        return launch_bx6_p<SplitF16x2>(C, S, a, log2d, s);
+    }
+    return launch_bx6_p<SplitBf16x3>(C, S, a, log2d, s);
 }
 
 // ---- the arithmetic alone, for the GEMM-level accuracy test: C[M][N] = A[M][K] . B[K][N], fp32 in and out, every
-// operand split in registers, one wave per 32 x 32 output tile (tests/test_bf16x6_gpu.py; not a fast GEMM)
+// operand split in registers, one wave per 32 x 32 output tile (tests/test_bf16x6_gpu.py; not a fast GEMM).
+// Scaled splits: A enters times sa, B times sb (powers of two from the caller), the result leaves times 1/(sa sb).
+template <typename P>
 __global__ __launch_bounds__(64) void gemm_bx6_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm,
-                                                      int M, int N, int K) {
+                                                      int M, int N, int K, float sa, float sb) {
+    using v8 = typename P::v8;
     const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
     const int mt = blockIdx.y, nt = blockIdx.x;
     bx_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int kb = 0; kb < K / 16; ++kb) {
-        bx_bf16x8 af[3], bf[3];
+        v8 af[P::NT], bf[P::NT];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = kb * 16 + 8 * lhi + e;
-            __bf16 p0, p1, p2;
-            split3(A[(size_t)(mt * 32 + l31) * K + k], p0, p1, p2);
-            af[0][e] = p0; af[1][e] = p1; af[2][e] = p2;
-            split3(B[(size_t)k * N + nt * 32 + l31], p0, p1, p2);
-            bf[0][e] = p0; bf[1][e] = p1; bf[2][e] = p2;
+            P::split1(A[(size_t)(mt * 32 + l31) * K + k] * sa, af, e);
+            P::split1(B[(size_t)k * N + nt * 32 + l31] * sb, bf, e);
         }
-        mfma6(acc, af, bf);
+#pragma unroll
+        for (int t = 0; t < P::NP; ++t) acc = P::mfma(af[P::ia(t)], bf[P::ib(t)], acc);
     }
+    const float inv = 1.f / (sa * sb);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        Cm[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * N + nt * 32 + l31] = acc[r];
+        Cm[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * N + nt * 32 + l31] = acc[r] * inv;
 }
 
-int launch_gemm_bx6(const float* A, const float* B, float* Cm, int M, int N, int K, hipStream_t s) {
+int launch_gemm_bx6(const float* A, const float* B, float* Cm, int M, int N, int K, int split, float sa, float sb, hipStream_t s) {
     DWS_CHECK(M > 0 && N > 0 && K > 0 && M % 32 == 0 && N % 32 == 0 && K % 16 == 0, DWS_ERR_UNSUPPORTED,
-              "gemm_bf16x6: M=%d N=%d must be multiples of 32, K=%d of 16", M, N, K);
-    hipLaunchKernelGGL(gemm_bx6_kernel, dim3(N / 32, M / 32), dim3(64), 0, s, A, B, Cm, M, N, K);
+              "gemm_bf16x6 / gemm_f16x3: M=%d N=%d must be multiples of 32, K=%d of 16", M, N, K);
+    if (split == WN_SPLIT_F16X3) {
+        int ea = 0, eb = 0;
+        DWS_CHECK(sa > 0.f && sb > 0.f && frexpf(sa, &ea) == 0.5f && frexpf(sb, &eb) == 0.5f, DWS_ERR_INVALID,
+                  "gemm_f16x3: the operand scales must be powers of two (%g, %g)", (double)sa, (double)sb);
+        hipLaunchKernelGGL(gemm_bx6_kernel<SplitF16x2>, dim3(N / 32, M / 32), dim3(64), 0, s, A, B, Cm, M, N, K, sa, sb);
+    } else {
+        hipLaunchKernelGGL(gemm_bx6_kernel<SplitBf16x3>, dim3(N / 32, M / 32), dim3(64), 0, s, A, B, Cm, M, N, K, 1.f, 1.f);
+    }
     return DWS_OK;
 }
 
@@ -706,5 +774,12 @@ int launch_gemm_bx6(const float* A, const float* B, float* Cm, int M, int N, int
 extern "C" int dws_gemm_bf16x6(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, void* stream) {
     DWS_CHECK(A && B && C, DWS_ERR_INVALID, "dws_gemm_bf16x6: null argument");
     DWS_CHECK(M <= (1 << 20) && N <= (1 << 20) && K <= (1 << 20), DWS_ERR_UNSUPPORTED, "dws_gemm_bf16x6: dimension too large");
-    return dws::launch_gemm_bx6(A, B, C, (int)M, (int)N, (int)K, (hipStream_t)stream);
+    return dws::launch_gemm_bx6(A, B, C, (int)M, (int)N, (int)K, dws::WN_SPLIT_BF16X6, 1.f, 1.f, (hipStream_t)stream);
+}
+
+extern "C" int dws_gemm_f16x3(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, float scale_a, float scale_b,
+                              void* stream) {
+    DWS_CHECK(A && B && C, DWS_ERR_INVALID, "dws_gemm_f16x3: null argument");
+    DWS_CHECK(M <= (1 << 20) && N <= (1 << 20) && K <= (1 << 20), DWS_ERR_UNSUPPORTED, "dws_gemm_f16x3: dimension too large");
+    return dws::launch_gemm_bx6(A, B, C, (int)M, (int)N, (int)K, dws::WN_SPLIT_F16X3, scale_a, scale_b, (hipStream_t)stream);
 }

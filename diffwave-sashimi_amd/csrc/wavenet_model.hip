@@ -15,6 +15,8 @@ struct WaveNetModel : dws_model {
     bool cond, mfma_layer, mfma_final;
     bool bf16x3 = false;             // precision option (see include/dws.h)
     bool bf16x6 = false;             // precision option: 3-term split, six products, Winograd form (wavenet_bx6.hip)
+    bool f16x3 = false;              // precision option: 2-term fp16 split, three products, scaled operands (same kernel)
+    DevBuf wscale;                   // f16x3: [NL][2] power-of-two scales of the packed A1 / A2
     bool wino_opt = true;            // conv_algo option: Winograd F(2,3) along the dilation stride (f32 path) or direct
     // the Winograd launcher addresses a clip's [C][L] tensor through one 32-bit buffer descriptor: over-long clips
     // (L >= ~2.1 M samples at C = 256) stay on the direct kernel, which has no such bound.  prepare() marks the model
@@ -22,9 +24,9 @@ struct WaveNetModel : dws_model {
     bool wino_fits(int64_t nL) const {
         return (int64_t)std::max(C, S) * nL * 4 < ((int64_t)1 << 31) && nL + 4 * ((int64_t)1 << (cycle - 1)) < ((int64_t)1 << 28);
     }
-    bool wino() const { return wino_opt && mfma_layer && !bf16x3 && !bf16x6 && wn_layer_wino_supported(C, S) && (L == 0 || wino_fits(L)); }
+    bool wino() const { return wino_opt && mfma_layer && !bf16x3 && !bf16x6 && !f16x3 && wn_layer_wino_supported(C, S) && (L == 0 || wino_fits(L)); }
     // the step-embedding correction rows in the Winograd layout [4][2C] (both Winograd layer kernels read it)
-    bool wino_rows() const { return wino() || bf16x6; }
+    bool wino_rows() const { return wino() || bf16x6 || f16x3; }
 
     // folded / packed weights
     DevBuf Wi;                       // init conv [C][Cin]
@@ -112,17 +114,23 @@ struct WaveNetModel : dws_model {
 
     int set_option(const std::string& key, const std::string& value) override {
         if (key == "precision") {
-            if (value == "f32") { bf16x3 = bf16x6 = false; dirty = true; trained_fwd = false; return DWS_OK; }
+            if (value == "f32") { bf16x3 = bf16x6 = f16x3 = false; dirty = true; trained_fwd = false; return DWS_OK; }
             if (value == "bf16x3") {
                 DWS_CHECK(wn_layer_bf16x3_supported(C, S), DWS_ERR_UNSUPPORTED,
                           "precision=bf16x3 is not built for (res_channels=%d, skip_channels=%d)", C, S);
-                bf16x3 = true; bf16x6 = false; dirty = true; trained_fwd = false;
+                bf16x3 = true; bf16x6 = f16x3 = false; dirty = true; trained_fwd = false;
                 return DWS_OK;
             }
             if (value == "bf16x6") {
                 DWS_CHECK(mfma_layer && wn_layer_bx6_supported(C, S), DWS_ERR_UNSUPPORTED,
                           "precision=bf16x6 is not built for (res_channels=%d, skip_channels=%d)", C, S);
-                bf16x6 = true; bf16x3 = false; dirty = true; trained_fwd = false;
+                bf16x6 = true; bf16x3 = f16x3 = false; dirty = true; trained_fwd = false;
+                return DWS_OK;
+            }
+            if (value == "f16x3") {
+                DWS_CHECK(mfma_layer && wn_layer_bx6_supported(C, S), DWS_ERR_UNSUPPORTED,
+                          "precision=f16x3 is not built for (res_channels=%d, skip_channels=%d)", C, S);
+                f16x3 = true; bf16x3 = bf16x6 = false; dirty = true; trained_fwd = false;
                 return DWS_OK;
             }
         }
@@ -161,11 +169,20 @@ struct WaveNetModel : dws_model {
             DWS_TRY(bias2[n].ensure((size_t)(C + S) * 4));
             stack_params.add(P(p + ".res_conv.bias"), bias2[n].f(), (size_t)C);
             stack_params.add(P(p + ".skip_conv.bias"), bias2[n].f() + C, (size_t)S);
-            if (mfma_layer && bf16x6) {   // 3 bf16 terms per weight, packed straight from the folded weights
-                DWS_TRY(A1[n].ensure((size_t)2 * C * 4 * C * 6));
-                DWS_TRY(A2[n].ensure((size_t)(C + S) * C * 6));
-                DWS_TRY(launch_pack_a1_bx6(Wd(n), A1[n].p, C, s));
-                DWS_TRY(launch_pack_a_bx6(Wrs[n].f(), A2[n].p, C + S, C, s));
+            if (mfma_layer && (bf16x6 || f16x3)) {   // 3 bf16 / 2 fp16 terms per weight, packed straight from the folded weights
+                const int split = f16x3 ? WN_SPLIT_F16X3 : WN_SPLIT_BF16X6;
+                const size_t tb = 2 * (size_t)wn_split_terms(split);
+                float* sc = nullptr;
+                if (f16x3) {
+                    DWS_TRY(wscale.ensure((size_t)NL * 2 * 4));
+                    sc = wscale.f() + 2 * n;
+                    DWS_TRY(launch_weight_scale(Wd(n), (size_t)2 * C * C * 3, sc, s));
+                    DWS_TRY(launch_weight_scale(Wrs[n].f(), (size_t)(C + S) * C, sc + 1, s));
+                }
+                DWS_TRY(A1[n].ensure((size_t)2 * C * 4 * C * tb));
+                DWS_TRY(A2[n].ensure((size_t)(C + S) * C * tb));
+                DWS_TRY(launch_pack_a1_bx6(Wd(n), A1[n].p, C, split, sc, s));
+                DWS_TRY(launch_pack_a_bx6(Wrs[n].f(), A2[n].p, C + S, C, split, f16x3 ? sc + 1 : nullptr, s));
             } else if (mfma_layer) {
                 DWS_TRY(A1[n].ensure((size_t)2 * C * 4 * C * 4));
                 if (wino()) DWS_TRY(launch_wino_dconv(Wd(n), tmp_pack.f(), C, s));
@@ -341,7 +358,7 @@ struct WaveNetModel : dws_model {
 
     int forward_train(const float* audio, const float* steps, float* out, hipStream_t s) override {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
-        DWS_CHECK(!bf16x3 && !bf16x6, DWS_ERR_UNSUPPORTED, "training runs with precision=f32 (no bf16-split backward is built)");
+        DWS_CHECK(!bf16x3 && !bf16x6 && !f16x3, DWS_ERR_UNSUPPORTED, "training runs with precision=f32 (no split-precision backward is built)");
         DWS_CHECK(melBm == 0 || (melBm == B && mfma_bwd), DWS_ERR_UNSUPPORTED,
                   "mel-conditional training needs one mel per clip (got %lld for B=%lld) and the MFMA adjoints (channels %% 32 == 0)",
                   (long long)melBm, (long long)B);
@@ -446,7 +463,8 @@ struct WaveNetModel : dws_model {
             a.dilation = 1 << (n % cycle);
             a.first_layer = (n == 0); a.last_layer = (n == NL - 1);
             if (mfma_layer && bf16x3) DWS_TRY(launch_wn_layer_bf16x3(C, S, a, s));
-            else if (bf16x6) DWS_TRY(launch_wn_layer_bx6(C, S, a, s));
+            else if (bf16x6) DWS_TRY(launch_wn_layer_bx6(C, S, a, WN_SPLIT_BF16X6, s));
+            else if (f16x3) { a.wscale = wscale.f() + 2 * n; DWS_TRY(launch_wn_layer_bx6(C, S, a, WN_SPLIT_F16X3, s)); }
             else if (wino()) DWS_TRY(launch_wn_layer_wino(C, S, a, s));
             else if (mfma_layer) DWS_TRY(launch_wn_layer_mfma(C, S, a, s));
             else DWS_TRY(launch_wn_layer_generic(C, S, a, s));

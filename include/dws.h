@@ -227,6 +227,13 @@ int dws_mel_spectrogram(const float* audio, int64_t B, int64_t T, const float* w
  * accumulated in fp32 -- exactly what the bf16x6 layer kernels execute per k-block.  M, N multiples of 32, K of 16. */
 int dws_gemm_bf16x6(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, void* stream);
 
+/* The arithmetic of precision="f16x3" alone, same shapes: every operand is multiplied by its scale (scale_a / scale_b,
+ * powers of two: the layer kernels use 2^6 for activations, 2^12 for the gate and a per-matrix power of two that brings
+ * the largest weight into (1, 2]), split into two fp16 terms (22 significand bits), three fp16 MFMA products per term
+ * pair accumulated in fp32, the result multiplied by 1 / (scale_a scale_b).  Scaled operands beyond 65504 overflow. */
+int dws_gemm_f16x3(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, float scale_a, float scale_b,
+                   void* stream);
+
 /* Timing of the dominant kernel, measured with HIP events on the stream the
  * kernel was launched on (bench.py roofline leg).  Enables per-launch event
  * recording for kernels whose name contains `substr`; query returns the number

@@ -18,7 +18,7 @@ import json, sqlite3, sys
 w, dst, prec = sys.argv[1], sys.argv[2], sys.argv[3]
 # flops of one MFMA instruction: v_mfma_f32_32x32x2_f32 = 4096; v_mfma_f32_32x32x16_bf16 = 32768, six of them per
 # fp32-equivalent product term (bf16x6) or three (bf16x3)
-per_inst = {"f32": 4096.0, "bf16x6": 32768.0 / 6.0, "bf16x3": 32768.0 / 3.0}[prec]
+per_inst = {"f32": 4096.0, "bf16x6": 32768.0 / 6.0, "bf16x3": 32768.0 / 3.0, "f16x3": 32768.0 / 3.0}[prec]
 def avg(counter):
     c = sqlite3.connect("%s/%s/p_results.db" % (w, counter))
     rows = list(c.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? and "

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--algo", default="winograd")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6", "f16x3"])
     args = ap.parse_args()
     cfg = dict(bench.CONFIGS[args.config])
     if args.batch:
