@@ -96,10 +96,12 @@ struct SplitBf16x3 {
 
 // SplitF16x2 ("f16x3"): x = h + l with h = fp16(x), l = fp16(x - h): 22 significand bits, THREE products (h h, h l, l h; the
 // dropped l l is 2^-22 of |x w|).  Not fp32-faithful element by element -- 2 bits short, and fp16's exponent range needs
-// power-of-two operand scaling so that the low terms stay normal (activations x 2^6, gate x 2^12, each weight matrix by its
+// power-of-two operand scaling so that the low terms stay normal (activations x 2^4, gate x 2^12, each weight matrix by its
 // own power of two; all undone exactly on the fp32 accumulators) -- but in a K >= 256 contraction its representation error
 // is a fraction of the fp32 ACCUMULATION error that both splits and the f32 path share, at half the matrix work of bf16x6.
-// Accepted by the same float64 criterion (tests/test_bf16x6_gpu.py); values beyond 2^9 (activations) overflow fp16.
+// Accepted by the same float64 criterion (tests/test_bf16x6_gpu.py); activations beyond 2^11 overflow fp16 (the Winograd-transformed
+// differences of two of them reach 2^12 x 2^4 = fp16's largest binade); measured with scales 2^2, 2^4 and 2^6: the network-level error is
+// the same to three digits (the fp32 accumulation dominates), so the smallest scale that keeps O(1) low terms normal is used.
 typedef _Float16 hx_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hx_f16x4 __attribute__((ext_vector_type(4)));
 struct SplitF16x2 {
@@ -107,7 +109,10 @@ struct SplitF16x2 {
     typedef hx_f16x4 v4;
     static constexpr int NT = 2, NP = 3;
     static constexpr bool SCALED = true;
-    static constexpr float SX = 64.f, SG = 4096.f;
+#ifndef F16X3_SX
+#define F16X3_SX 16.f
+#endif
+    static constexpr float SX = F16X3_SX, SG = 4096.f;
     __device__ static constexpr int ia(int t) { return t == 0 ? 1 : 0; }     // (l, h), (h, l), (h, h)
     __device__ static constexpr int ib(int t) { return t == 1 ? 1 : 0; }
     __device__ static __forceinline__ bx_f32x16 mfma(const v8& a, const v8& b, const bx_f32x16& c) {

@@ -63,6 +63,8 @@ __device__ __forceinline__ size_t step_row_off(const int* __restrict__ idx, int 
 // instructions instead of ~45 for erff -- the GELU epilogues were VALU-bound, not the MFMAs.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float dws_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// ReLU that propagates NaN like torch.relu (`wavenet.py:149,204`): fmaxf(NaN, 0) would return 0 and hide a range violation
+__device__ __forceinline__ float dws_relu(float x) { return x < 0.f ? 0.f : x; }
 __device__ __forceinline__ float dws_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + dws_exp(-x)); }
 // Phi(x) (standard normal CDF) and ez = exp(-x^2/2)
 __device__ __forceinline__ float dws_norm_cdf(float x, float& ez) {

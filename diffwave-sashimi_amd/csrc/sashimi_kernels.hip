@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void init_conv_ln_kernel(const float* __restri
         float acc = bias[c];
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci) acc = fmaf(W[c * CIN + ci], a[ci], acc);
-        return fmaxf(acc, 0.f);
+        return dws_relu(acc);
     };
     float sum = 0.f;
     for (int c = 0; c < D; ++c) sum += chan(c);
@@ -339,7 +339,7 @@ __global__ void pw_generic_kernel(PwArgs a) {
     if (EPI == 0) {
         float v = dot(o);
         if (a.act == 1) v = gelu_erf(v);
-        else if (a.act == 2) v = fmaxf(v, 0.f);
+        else if (a.act == 2) v = dws_relu(v);
         a.out[((size_t)b * a.O + o) * L + l] = v;
     } else if (EPI == 1) {
         const int Hh = a.O / 2;

@@ -82,7 +82,7 @@ enum { WN_SPLIT_BF16X6 = 0, WN_SPLIT_F16X3 = 1 };
 inline int wn_split_terms(int split) { return split == WN_SPLIT_F16X3 ? 2 : 3; }
 bool wn_layer_bx6_supported(int C, int S);
 int launch_wn_layer_bx6(int C, int S, const WnLayerArgs& a, int split, hipStream_t s);
-int launch_weight_scale(const float* w, size_t n, float* out, hipStream_t s);     // *out = power of two bringing max|w| into (1, 2]
+int launch_weight_scale(const float* w, size_t n, const float* bias, int nb, const float* bias_b, int nb_b, float* out, hipStream_t s);   // power of two bringing max(|w|, |bias|/1024) into [1, 2)
 int launch_pack_a1_bx6(const float* w, void* out, int C, int split, const float* scale, hipStream_t s);        // folded [2C][C][3] -> G0..G3 fragments
 int launch_pack_a_bx6(const float* w, void* out, int M, int K, int split, const float* scale, hipStream_t s);  // row-major [M][K] -> fragments
 int launch_gemm_bx6(const float* A, const float* B, float* C, int M, int N, int K, int split, float sa, float sb, hipStream_t s);

@@ -32,6 +32,13 @@
 
 namespace dws {
 
+#ifndef BX6_PF3
+#define BX6_PF3 1   // A-fragment prefetch distance in (k-block, product) steps: 3-term split (12 MFMAs per step)
+#endif
+#ifndef BX6_PF2
+#define BX6_PF2 2   // 2-term split (6 MFMAs per step)
+#endif
+#define BX6_PF(NT) ((NT) == 2 ? BX6_PF2 : BX6_PF3)
 #ifndef BX6_T_PER_MFMA
 #define BX6_T_PER_MFMA 7   // transform instructions dealt out behind each MFMA of a chunk's first step
 #endif
@@ -108,13 +115,20 @@ __global__ void pack_a_bx6_kernel(const float* __restrict__ w, unsigned short* _
     for (int t = 0; t < P::NT; ++t) out[base + t * 512] = b[t];
 }
 
-// *out = 2^(1 - ceil(log2 max|w|)): the power of two that brings the largest weight of a matrix into (1, 2]  (one
-// workgroup; commit time).  The Winograd combinations G1, G2 of three taps then stay below 3, every fp16 high term is
-// normal down to 2^-14 and the low terms resolve 2^-25 absolute = 2^-26 of the matrix maximum or better.
-__global__ __launch_bounds__(1024) void weight_scale_kernel(const float* __restrict__ w, size_t n, float* __restrict__ out) {
+// *out = the power of two that brings m = max(max|w|, max|bias| / 1024) into [1, 2)  (one workgroup; commit time).  The
+// Winograd combinations G1, G2 of three taps then stay below 3, every fp16 high term is normal down to 2^-14 and the low terms
+// resolve 2^-25 absolute = 2^-26 of the matrix maximum or better.  The bias rows ride in the same accumulators (correction
+// k-block), so they enter the maximum far enough down that a bias 1000 x the weights neither overflows fp16 (< 2^11 scaled)
+// nor costs the weights precision in the usual case.
+__global__ __launch_bounds__(1024) void weight_scale_kernel(const float* __restrict__ w, size_t n, const float* __restrict__ bias, int nb,
+                                                            const float* __restrict__ bias_b, int nb_b, float* __restrict__ out) {
     __shared__ float red[16];
     float m = 0.f;
     for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+    if (bias)
+        for (int i = threadIdx.x; i < nb; i += 1024) m = fmaxf(m, fabsf(bias[i]) * (1.f / 1024.f));
+    if (bias_b)
+        for (int i = threadIdx.x; i < nb_b; i += 1024) m = fmaxf(m, fabsf(bias_b[i]) * (1.f / 1024.f));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -131,8 +145,8 @@ __global__ __launch_bounds__(1024) void weight_scale_kernel(const float* __restr
     }
 }
 
-int launch_weight_scale(const float* w, size_t n, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, s, w, n, out);
+int launch_weight_scale(const float* w, size_t n, const float* bias, int nb, const float* bias_b, int nb_b, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, s, w, n, bias, nb, bias_b, nb_b, out);
     return DWS_OK;
 }
 
@@ -367,15 +381,21 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
 
     stage_dma(0);
     if (NCB > 1) stage_dma(1);
-    v8 a_cur[2][NT], a_nxt[2][NT];
-    load_a1(a_cur, chunk_of(0) * (KC / 16), 0);
+    // A fragments run PF (k-block, product) steps ahead of their use, in a ring of four register sets indexed by the
+    // step number (compile time: the steps of a chunk are a multiple of four).  One step is 2 NPR MFMAs = 32 NPR matrix-pipe
+    // cycles per wave: six products cover an L2 round trip with one step, three products need two.
+    constexpr int PF = BX6_PF(NT);
+    v8 a_ring[4][2][NT];
+#pragma unroll
+    for (int s0 = 0; s0 < PF; ++s0) load_a1(a_ring[s0], chunk_of(0) * (KC / 16) + (s0 >> 2), s0 & 3);
+    constexpr int NAF = PF * NA;              // A fragment loads in flight behind anything older
     // chunk 0 has landed (this wave's part; the barrier makes it everyone's): all but the loads issued after it -- chunk 1
-    // and the NA A fragments.  hipcc does not make a barrier wait for LDS-DMA.
+    // and the NAF A fragments.  hipcc does not make a barrier wait for LDS-DMA.
     if (NCB > 1) {
-        if (x4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((RPW / 2 + NA) & 15) | (((RPW / 2 + NA) >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * RPW + NA) & 15) | (((2 * RPW + NA) >> 4) << 14));
+        if (x4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((RPW / 2 + NAF) & 15) | (((RPW / 2 + NAF) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * RPW + NAF) & 15) | (((2 * RPW + NAF) >> 4) << 14));
     } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70 | NA);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NAF);
     }
     __syncthreads();
     stamp(1);
@@ -404,7 +424,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         }
     }
     transform(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | NA);   // chunk 1 has landed too (younger: only the NA A fragments)
+    __builtin_amdgcn_s_waitcnt(0x0F70 | NAF);  // chunk 1 has landed too (younger: only the NAF A fragments)
     __syncthreads();                          // transformed chunk 0 visible, raw chunk 1 complete
 
     constexpr int SPC = (KC / 16) * 4;        // (k-block, product) steps per chunk
@@ -416,12 +436,11 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         constexpr int st = decltype(ST)::value;
         constexpr bool with_t = decltype(WITH_T)::value;
         constexpr int it = st >> 2, j = st & 3;
-        int itn = it, jn = j + 1, cbn = cb;
-        if (jn == 4) { jn = 0; ++itn; }
-        if (itn == KC / 16) { itn = 0; ++cbn; }
+        constexpr int sn = (st + PF) % SPC, itn = sn >> 2, jn = sn & 3;
+        const int cbn = cb + (st + PF) / SPC;
         const char* tb = Bop + (cb & 1) * T::BOP_BYTES + lhi * (4 * NT * 512) + l31 * 16;
-        if (st + 1 < SPC || cb + 1 < NCB) load_a1(a_nxt, chunk_of(cbn) * (KC / 16) + itn, jn);   // (no load left in flight behind the last step)
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole step (12 MFMAs) ahead of its use
+        if (cbn < NCB) load_a1(a_ring[(st + PF) & 3], chunk_of(cbn) * (KC / 16) + itn, jn);   // (no load left in flight behind the last step)
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PF whole steps ahead of its use
         v8 bq[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const v8*>(tb + ((2 * it * 4 + j) * NT + t) * 512);
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         for (int t = 0; t < NPR; ++t)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                acc[m][j] = P::mfma(a_cur[m][P::ia(t)], bq[P::ib(t)], acc[m][j]);
+                acc[m][j] = P::mfma(a_ring[st & 3][m][P::ia(t)], bq[P::ib(t)], acc[m][j]);
 #ifndef BX6_ABL_NO_INTERLEAVE
         if (with_t) {
 #pragma unroll
@@ -440,10 +459,6 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
             }
         }
 #endif
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) a_cur[m][t] = a_nxt[m][t];
     };
     auto do_steps_from1 = [&](int cb) {
         if constexpr (SPC == 4) {
@@ -460,7 +475,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
             do_step(cb, std::integral_constant<int, 7>{}, std::false_type{});
         }
     };
-    static_assert(SPC == 4 || SPC == 8, "steps per chunk");
+    static_assert((SPC == 4 || SPC == 8) && PF >= 1 && PF <= 3, "steps per chunk, prefetch distance");
     for (int cb = 0; cb < NCB; ++cb) {
         if (cb + 2 < NCB) stage_dma(cb + 2);       // into the raw buffer chunk cb occupied (transformed an iteration ago)
         if (cb + 1 < NCB) do_step(cb, std::integral_constant<int, 0>{}, std::true_type{});
@@ -468,8 +483,8 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         do_steps_from1(cb);
         stamp(8 + 2 * cb);
         // transformed chunk cb+1 visible after the barrier; the LDS-DMA of chunk cb+2 must have landed too (hipcc does not
-        // count LDS-DMA among the accesses a barrier waits for): the only younger loads are the NA A fragments of the next step
-        __builtin_amdgcn_s_waitcnt(0x0F70 | NA);
+        // count LDS-DMA among the accesses a barrier waits for): the only younger loads are the NAF A fragments of the next steps
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NAF);
         __syncthreads();
         stamp(9 + 2 * cb);
     }

@@ -189,7 +189,7 @@ __global__ void init_conv_kernel(const float* __restrict__ audio, const float* _
     for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
         float acc = bc;
         for (int ci = 0; ci < Cin; ++ci) acc = fmaf(W[c * Cin + ci], audio[((size_t)b * Cin + ci) * L + l], acc);
-        x[((size_t)b * C + c) * L + l] = fmaxf(acc, 0.f);
+        x[((size_t)b * C + c) * L + l] = dws_relu(acc);
     }
 }
 
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void wn_final_mfma_kernel(WnFinalArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const float y = fmaxf(acc[m][n][r] + a.bf[row], 0.f);
+                    const float y = dws_relu(acc[m][n][r] + a.bf[row]);
                     part = fmaf(a.Wz[oc * S + row], y, part);
                     if (oc == 0 && a.tap) {
                         const int pos = l0 + (wn * NT + n) * 32 + l31;
@@ -790,7 +790,7 @@ __global__ void wn_final_generic_kernel(WnFinalArgs a, int S) {
             for (int r = 0; r < S; ++r) {
                 float acc = 0.f;
                 for (int k = 0; k < S; ++k) acc = fmaf(a.Wf[(size_t)r * S + k], sk[(size_t)k * L + l] * a.scale, acc);
-                const float y = fmaxf(acc + a.bf[r], 0.f);
+                const float y = dws_relu(acc + a.bf[r]);
                 if (oc == 0 && a.tap) a.tap[((size_t)b * S + r) * L + l] = y;
                 o = fmaf(a.Wz[oc * S + r], y, o);
             }

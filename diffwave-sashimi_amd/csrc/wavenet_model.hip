@@ -176,8 +176,10 @@ struct WaveNetModel : dws_model {
                 if (f16x3) {
                     DWS_TRY(wscale.ensure((size_t)NL * 2 * 4));
                     sc = wscale.f() + 2 * n;
-                    DWS_TRY(launch_weight_scale(Wd(n), (size_t)2 * C * C * 3, sc, s));
-                    DWS_TRY(launch_weight_scale(Wrs[n].f(), (size_t)(C + S) * C, sc + 1, s));
+                    // (the raw parameter buffers: the stacked copies b1_all / bias2 are filled later in this commit)
+                    DWS_TRY(launch_weight_scale(Wd(n), (size_t)2 * C * C * 3, P(p + ".dilated_conv_layer.conv.bias"), 2 * C, nullptr, 0, sc, s));
+                    DWS_TRY(launch_weight_scale(Wrs[n].f(), (size_t)(C + S) * C, P(p + ".res_conv.bias"), C, P(p + ".skip_conv.bias"), S,
+                                                sc + 1, s));
                 }
                 DWS_TRY(A1[n].ensure((size_t)2 * C * 4 * C * tb));
                 DWS_TRY(A2[n].ensure((size_t)(C + S) * C * tb));

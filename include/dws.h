@@ -228,7 +228,7 @@ int dws_mel_spectrogram(const float* audio, int64_t B, int64_t T, const float* w
 int dws_gemm_bf16x6(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, void* stream);
 
 /* The arithmetic of precision="f16x3" alone, same shapes: every operand is multiplied by its scale (scale_a / scale_b,
- * powers of two: the layer kernels use 2^6 for activations, 2^12 for the gate and a per-matrix power of two that brings
+ * powers of two: the layer kernels use 2^4 for activations, 2^12 for the gate and a per-matrix power of two that brings
  * the largest weight into (1, 2]), split into two fp16 terms (22 significand bits), three fp16 MFMA products per term
  * pair accumulated in fp32, the result multiplied by 1 / (scale_a scale_b).  Scaled operands beyond 65504 overflow. */
 int dws_gemm_f16x3(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, float scale_a, float scale_b,

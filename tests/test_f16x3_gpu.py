@@ -1,5 +1,5 @@
 """precision="f16x3": the WaveNet layer kernel of `csrc/wavenet_bx6.hip` instantiated with the 2-term fp16 split
-(`csrc/bf16_split.h`: SplitF16x2): operands multiplied by a power of two (activations 2^6, gate 2^12, every weight matrix
+(`csrc/bf16_split.h`: SplitF16x2): operands multiplied by a power of two (activations 2^4, gate 2^12, every weight matrix
 by the power of two that brings its largest element into (1, 2]), split as h = fp16(x), l = fp16(x - h), three fp16 MFMA
 products (h h, h l, l h) accumulated in fp32, the scales undone exactly on the accumulators.  22 bits per operand: NOT
 fp32-faithful element by element, so the acceptance is the measured one of tests/test_bf16x6_gpu.py and nothing weaker:
@@ -9,7 +9,7 @@ fp32-faithful element by element, so the acceptance is the measured one of tests
   * network level (`models/wavenet.py:82-121,149-165,202-210`): error against the FLOAT64 oracle <= 2 x the exact-f32
     MFMA path's on wn_c128, wn_h128_d30 and wn_h256_d36, max-rel and rms, eps and pre_final;
   * what the split does not cover is stated and tested: scaled operands beyond fp16's range overflow (activations beyond
-    2^9 = 512; the reference's activations are O(1): x' = (x + res) sqrt(.5) of unit-variance audio).
+    2^11 = 2048; the reference's activations are O(1): x' = (x + res) sqrt(.5) of unit-variance audio).
 """
 import numpy as np
 import pytest
@@ -180,10 +180,32 @@ def test_f16x3_follows_a_weight_update(gpu):
         for k, v in net.named_parameters():
             if k.endswith("res_conv.weight_g") or k.endswith("dilated_conv_layer.conv.weight_g"):
                 v.mul_(0.03125 if "res_conv" in k else 3.0)
+            if k.endswith("residual_blocks.1.dilated_conv_layer.conv.bias") or k.endswith("residual_blocks.2.skip_conv.bias"):
+                v.fill_(40.0)        # a bias a thousand times the weights: enters the matrix scale, must not overflow fp16
         a = net((audio.to(gpu), steps.to(gpu)))
         net.set_option("precision", "f32")
         b = net((audio.to(gpu), steps.to(gpu)))
     assert rel_err(a, b) < 1e-5, rel_err(a, b)
+
+
+def test_f16x3_range_is_what_the_header_says(gpu):
+    """Activations of a few hundred (64 x unit-variance audio) are inside the fp16 range of the scaled split and match the
+    f32 path as before; far beyond 2^11 the scaled high terms overflow to infinity and the output is NOT finite -- a range
+    violation cannot pass as a plausible finite result."""
+    cfg, B, L, wseed, iseed, _ = cases.WAVENET_CASES["wn_c64"]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    audio, steps = cases.wavenet_inputs(B, L, 1, iseed)
+    with torch.no_grad():
+        out = {}
+        for prec in ("f32", "f16x3"):
+            net.set_option("precision", prec)
+            out[prec] = net(((64.0 * audio).to(gpu), steps.to(gpu))).cpu()
+            if prec == "f32":
+                xl = net.read_tap("x", (B, cfg["res_channels"], L)).abs().max().item()
+                print(f"max |x| leaving the last layer at 64 x audio: {xl:.1f}")
+        assert torch.isfinite(out["f16x3"]).all() and rel_err(out["f16x3"], out["f32"]) < 1e-5
+        big = net(((3e5 * audio).to(gpu), steps.to(gpu))).cpu()
+        assert not torch.isfinite(big).all()
 
 
 def test_f16x3_sampler_graph_equals_the_per_step_loop(gpu):
