@@ -705,9 +705,17 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
             a6.precision, a6.no_roofline, a6.steps = "bf16x6", True, max(steps // 2, 10)
             r6 = sample_bench(a6, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False, full=False)
             out[name]["extra_bf16x6"] = {"ms_per_step": r6["ms_per_step"], "value": r6["value"], "unit": r6["unit"],
-                                         "dtype": "f32, register-chained tails (H <= 64) f32-equivalent on bf16 MFMA "
+                                         "dtype": "f32, register-chained tails (H <= 128) f32-equivalent on bf16 MFMA "
                                                   "(3-term split, 6 products, fp32 accumulate)",
                                          "note": "opt-in precision=bf16x6; not the leg's value"}
+            # and with the 2-term fp16 split of scaled operands (three products; the same kernels and float64 criterion)
+            a3 = copy.copy(a6)
+            a3.precision = "f16x3"
+            r3 = sample_bench(a3, dict(CONFIGS[name]), world, rank, dev, ddist, red_dev, extras=False, full=False)
+            out[name]["extra_f16x3"] = {"ms_per_step": r3["ms_per_step"], "value": r3["value"], "unit": r3["unit"],
+                                        "dtype": "f32, register-chained tails (H <= 128) on fp16 MFMA (2-term split of "
+                                                 "power-of-two scaled operands, 3 products, fp32 accumulate)",
+                                        "note": "opt-in precision=f16x3; not the leg's value"}
         except Exception as e:      # noqa: BLE001 -- reported, not swallowed
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()

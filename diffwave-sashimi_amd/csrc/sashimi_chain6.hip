@@ -15,6 +15,11 @@
 // registers: no LDS round trip, no shuffle, no barrier between the stages, as before.
 //
 // Weights: 6 H^2 x 6 bytes (three bf16 terms) in LDS in A-fragment order -- 36 KB at H = 32, 144 KB at H = 64.
+//
+// precision = "f16x3": the same kernels instantiated with the 2-term fp16 split (bf16_split.h: SplitF16x2; three products,
+// 4 bytes per weight): every GEMM's B operand (g, y, u: the register-resident activations) is multiplied by 2^4 before its
+// split, every weight matrix by its own power of two (S4TailArgs::wscale_c6, weight_scale_kernel), the bias k-block carries
+// both scales, and the accumulators are multiplied back by the exact inverse before GLU / GELU / LayerNorm see them.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -23,6 +28,7 @@
 #include "bf16_split.h"
 #include "sashimi.h"
 #include "sashimi_mfma.h"
+#include "wavenet.h"
 
 namespace dws {
 
@@ -44,13 +50,13 @@ int launch_chain16_permute_cols(const float* w, float* out, int M, int K, hipStr
     return DWS_OK;
 }
 
-template <int H, int FFE>
+template <int H, int FFE, int NT>
 struct Chain6Cfg {
     static constexpr int TH = H / 32, TO = 2 * H / 32, TF = FFE * H / 32;
     static constexpr int WAVES = (H >= 64) ? 8 : 4;
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int KBH = H / 16, KBF = FFE * H / 16;                 // k-blocks of an H / ff H contraction
-    static constexpr int WO_BYTES = 2 * H * H * 6, W1_BYTES = FFE * H * H * 6, W2_BYTES = FFE * H * H * 6;
+    static constexpr int WO_BYTES = 2 * H * H * 2 * NT, W1_BYTES = FFE * H * H * 2 * NT, W2_BYTES = FFE * H * H * 2 * NT;
     static constexpr int W_BYTES = WO_BYTES + W1_BYTES + W2_BYTES;
     static constexpr int B_FLOATS = 2 * H + FFE * H + H;                    // bo | b1 | b2
     static constexpr int LDS_BYTES = W_BYTES + B_FLOATS * 4;
@@ -59,51 +65,55 @@ struct Chain6Cfg {
 
 __device__ __forceinline__ float c6_xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
 
-// eight fp32 values of an accumulator-layout tile (register half hb) -> the three bf16x8 B fragments of one k-block
-__device__ __forceinline__ void c6_bfrag(const bx_f32x16& v, int hb, bx_bf16x8 (&out)[3]) {
+// eight fp32 values of an accumulator-layout tile (register half hb) -> the NT B fragments of one k-block
+template <typename P>
+__device__ __forceinline__ void c6_bfrag(const bx_f32x16& v, int hb, typename P::v8 (&out)[P::NT]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        __bf16 p0, p1, p2;
-        split3(v[8 * hb + i], p0, p1, p2);
-        out[0][i] = p0; out[1][i] = p1; out[2][i] = p2;
+    for (int i = 0; i < 8; ++i) P::split1(P::SCALED ? v[8 * hb + i] * P::SX : v[8 * hb + i], out, i);
+}
+
+// bias k-block of a GEMM: acc[m] = (bias column x weight scale, NT terms) . (a row of ones x operand scale)
+template <typename P, int MT, typename ACC>
+__device__ __forceinline__ void c6_bias_block(ACC& acc, const float* __restrict__ bias, float ws, int l31, int lhi) {
+    using v8 = typename P::v8;
+    const v8 bf = P::bvals(lhi ? 0.f : P::SX, 0.f);
+    bx_f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        v8 af[P::NT];
+        P::rank2(P::SCALED ? bias[m * 32 + l31] * ws : bias[m * 32 + l31], 0.f, lhi == 0, af);
+        acc[m] = zero;
+#pragma unroll
+        for (int t = P::NT - 1; t >= 0; --t) acc[m] = P::mfma(af[t], bf, acc[m]);
     }
 }
 
-// acc[m] (+)= W[m] . B for all MT row tiles and NKB k-blocks; fragments of W at w + ((m NKB + kb) 3 + term) 1024 + lane 16;
+// acc[m] = W[m] . B + bias for all MT row tiles and NKB k-blocks; fragments of W at w + ((m NKB + kb) NT + term) 1024 + lane 16;
 // src[t] are the accumulator-layout tiles whose registers are the B operand (k-block kb <- tile kb >> 1, half kb & 1).
-// bias: acc starts from a rank-1 k-block (A = bias column in three terms, B = a row of ones).
-template <int MT, int NKB, int NS>
-__device__ __forceinline__ void c6_gemm(bx_f32x16 (&acc)[MT], const char* __restrict__ w, const float* __restrict__ bias,
+// bias: acc starts from a rank-1 k-block (A = bias column in NT terms, B = a row of ones).  ws: the power of two the weights
+// were packed with (scaled splits); the accumulators leave multiplied by 1 / (ws SX).
+template <typename P, int MT, int NKB, int NS>
+__device__ __forceinline__ void c6_gemm(bx_f32x16 (&acc)[MT], const char* __restrict__ w, const float* __restrict__ bias, float ws,
                                         const bx_f32x16 (&src)[NS], int lane, int l31, int lhi) {
+    using v8 = typename P::v8;
+    constexpr int NT = P::NT, NPR = P::NP;
     static_assert(NKB == 2 * NS, "two k-blocks per source tile");
     constexpr int MU = (MT % 2 == 0) ? 2 : 1, NU = MT / MU;      // row tiles per unit: two accumulators alternate in the MFMA stream
     const char* wl = w + lane * 16;
-    {
-        const __bf16 z = (__bf16)0.f, one = (__bf16)(lhi ? 0.f : 1.f);
-        const bx_bf16x8 bf = {one, z, z, z, z, z, z, z};
-        bx_f32x16 zero;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            bx_bf16x8 af[3];
-            frag_rank2(bias[m * 32 + l31], 0.f, lhi == 0, af);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf, zero, 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf, acc[m], 0, 0, 0);
-        }
-    }
-    bx_bf16x8 a_cur[MU][3], a_nxt[MU][3];
-    auto load_a = [&](bx_bf16x8 (&dst)[MU][3], int kb, int u) {
+    c6_bias_block<P, MT>(acc, bias, ws, l31, lhi);
+    v8 a_cur[MU][NT], a_nxt[MU][NT];
+    auto load_a = [&](v8 (&dst)[MU][NT], int kb, int u) {
 #pragma unroll
         for (int mm = 0; mm < MU; ++mm)
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                dst[mm][t] = *reinterpret_cast<const bx_bf16x8*>(wl + (((u * MU + mm) * NKB + kb) * 3 + t) * 1024);
+            for (int t = 0; t < NT; ++t)
+                dst[mm][t] = *reinterpret_cast<const v8*>(wl + (((u * MU + mm) * NKB + kb) * NT + t) * 1024);
     };
     load_a(a_cur, 0, 0);
-    bx_bf16x8 bq[3], bn[3];
-    c6_bfrag(src[0], 0, bq);
+    v8 bq[NT], bn[NT];
+    c6_bfrag<P>(src[0], 0, bq);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
@@ -113,40 +123,47 @@ __device__ __forceinline__ void c6_gemm(bx_f32x16 (&acc)[MT], const char* __rest
             if (kbn < NKB) load_a(a_nxt, kbn, un);
             __builtin_amdgcn_sched_barrier(0);   // the fragment reads stay a whole unit ahead of their MFMAs
             // the split of the NEXT k-block's operand rides in this unit's MFMA stream (the MFMAs do not depend on it)
-            if (last_u && kb + 1 < NKB) c6_bfrag(src[(kb + 1) >> 1], (kb + 1) & 1, bn);
+            if (last_u && kb + 1 < NKB) c6_bfrag<P>(src[(kb + 1) >> 1], (kb + 1) & 1, bn);
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < NPR; ++t)
 #pragma unroll
                 for (int mm = 0; mm < MU; ++mm)
-                    acc[u * MU + mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mm][BX6_IA[t]], bq[BX6_IB[t]], acc[u * MU + mm], 0, 0, 0);
+                    acc[u * MU + mm] = P::mfma(a_cur[mm][P::ia(t)], bq[P::ib(t)], acc[u * MU + mm]);
 #ifndef C6_NO_INTERLEAVE
             if (last_u && kb + 1 < NKB) {
 #pragma unroll
-                for (int i = 0; i < 6 * MU; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 48 / (6 * MU), 0);   // a share of the 44 split instructions
+                for (int i = 0; i < NPR * MU; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 48 / (NPR * MU), 0);   // a share of the ~44 split instructions
                 }
             }
 #endif
 #pragma unroll
             for (int mm = 0; mm < MU; ++mm)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) a_cur[mm][t] = a_nxt[mm][t];
+                for (int t = 0; t < NT; ++t) a_cur[mm][t] = a_nxt[mm][t];
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bq[t] = bn[t];
+        for (int t = 0; t < NT; ++t) bq[t] = bn[t];
+    }
+    if (P::SCALED) {
+        const float inv = 1.f / (ws * P::SX);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] *= inv;
     }
 }
 
-template <int H, int FFE, bool YNEXT>
+template <typename P, int H, int FFE, bool YNEXT>
 __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain6_kernel(S4TailArgs a) {
-    using T = Chain6Cfg<H, FFE>;
+    using T = Chain6Cfg<H, FFE, P::NT>;
     constexpr int TH = T::TH, TO = T::TO, TF = T::TF;
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char lds6[];
-    char* const wo = lds6;                                   // [TO][KBH][3][64] 16-byte fragments
-    char* const w1 = wo + T::WO_BYTES;                       // [TF][KBH][3][64]
-    char* const w2 = w1 + T::W1_BYTES;                       // [TH][KBF][3][64]
+    char* const wo = lds6;                                   // [TO][KBH][NT][64] 16-byte fragments
+    char* const w1 = wo + T::WO_BYTES;                       // [TF][KBH][NT][64]
+    char* const w2 = w1 + T::W1_BYTES;                       // [TH][KBF][NT][64]
     float* const bo = reinterpret_cast<float*>(w2 + T::W2_BYTES);   // [2H]
     float* const b1 = bo + 2 * H;                            // [FFE*H]
     float* const b2 = b1 + FFE * H;                          // [H]
@@ -174,6 +191,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain6_kerne
     const float n1_m = YNEXT ? a.n1_m[0] : 0.f, n1_s = YNEXT ? a.n1_s[0] : 0.f;
     const bool has_mel = a.mel != nullptr, has_add = a.addend != nullptr;
     const float one = lhi ? 0.f : 1.f;
+    const float wso = P::SCALED ? a.wscale_c6[0] : 1.f, ws1 = P::SCALED ? a.wscale_c6[1] : 1.f, ws2 = P::SCALED ? a.wscale_c6[2] : 1.f;
     const int ntl = (L + 31) / 32, ntiles = a.B * ntl;
     const float invH = 1.f / (float)H;
 
@@ -214,7 +232,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain6_kerne
         C6_STAMP(1)
         // ---- GEMM-o: o[2H x 32] = Wo g + bo
         bx_f32x16 ao[TO];
-        c6_gemm<TO, T::KBH, TH>(ao, wo, bo, g, lane, l31, lhi);
+        c6_gemm<P, TO, T::KBH, TH>(ao, wo, bo, wso, g, lane, l31, lhi);
         C6_STAMP(2)
         // ---- GLU + residual: x1 = x (+ mel) + o_a * sigmoid(o_b); LN2 down the channel column
         float s1 = 0.f;
@@ -243,7 +261,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain6_kerne
         C6_STAMP(3)
         // ---- GEMM-1: u[ff H x 32] = GELU(W1 y + b1)
         bx_f32x16 u[TF];
-        c6_gemm<TF, T::KBH, TH>(u, w1, b1, y, lane, l31, lhi);
+        c6_gemm<P, TF, T::KBH, TH>(u, w1, b1, ws1, y, lane, l31, lhi);
         C6_STAMP(4)
 #ifndef C6_AD_LATE
         // the U-Net skip of this tile: requested now, needed after GEMM-2
@@ -264,7 +282,7 @@ __global__ __launch_bounds__((H >= 64 ? 512 : 256), 2) void s4_tail_chain6_kerne
         C6_STAMP(5)
         // ---- GEMM-2: f[H x 32] = W2 u + b2;  out = x1 + f (+ skip)
         bx_f32x16 f[TH];
-        c6_gemm<TH, T::KBF, TF>(f, w2, b2, u, lane, l31, lhi);
+        c6_gemm<P, TH, T::KBF, TF>(f, w2, b2, ws2, u, lane, l31, lhi);
         C6_STAMP(6)
 #ifdef C6_AD_LATE
         // the U-Net skip of this tile
@@ -337,46 +355,54 @@ bool s4_tail_chain6_supported(int H, int ff) { return ff == 2 && (H == 32 || H =
 // One workgroup barrier per chunk (48 MFMAs per wave) both publishes the chunk that has landed and frees the slot that
 // was consumed before it; the stream does not stop at tile boundaries (the next tile's first chunks arrive under GEMM-2).
 // Fragment order in memory: k-block major, [k-block][row tile][term][lane] (pack_a_bx6_kmajor).
-__global__ void pack_a_bx6_kmajor_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int M, int K) {
+template <typename P>
+__global__ void pack_a_bx6_kmajor_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int M, int K, const float* __restrict__ scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)M * K) return;
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const size_t r = i >> 9;                       // kb * MT + mt
     const int MT = M / 32;
     const int mt = (int)(r % MT), kb = (int)(r / MT);
-    const float v = w[(size_t)(mt * 32 + (lane & 31)) * K + kb * 16 + 8 * (lane >> 5) + e];
-    __bf16 p0, p1, p2;
-    split3(v, p0, p1, p2);
-    const size_t base = (r * 3) * 512 + (size_t)lane * 8 + e;
-    out[base] = __builtin_bit_cast(unsigned short, p0);
-    out[base + 512] = __builtin_bit_cast(unsigned short, p1);
-    out[base + 1024] = __builtin_bit_cast(unsigned short, p2);
+    float v = w[(size_t)(mt * 32 + (lane & 31)) * K + kb * 16 + 8 * (lane >> 5) + e];
+    if (P::SCALED) v *= *scale;
+    unsigned short b[P::NT];
+    P::bits(v, b);
+    const size_t base = (r * P::NT) * 512 + (size_t)lane * 8 + e;
+#pragma unroll
+    for (int t = 0; t < P::NT; ++t) out[base + t * 512] = b[t];
 }
 
-int launch_pack_a_bx6_kmajor(const float* w, void* out, int M, int K, hipStream_t s) {
+int launch_pack_a_bx6_kmajor(const float* w, void* out, int M, int K, int split, const float* scale, hipStream_t s) {
     DWS_CHECK(M % 32 == 0 && K % 16 == 0, DWS_ERR_UNSUPPORTED, "pack_a_bx6_kmajor: M=%d K=%d", M, K);
-    hipLaunchKernelGGL(pack_a_bx6_kmajor_kernel, dim3(ceil_div((int64_t)M * K, 256)), dim3(256), 0, s, w, (unsigned short*)out, M, K);
+    if (split == WN_SPLIT_F16X3) {
+        DWS_CHECK(scale != nullptr, DWS_ERR_INVALID, "pack_a_kmajor: the fp16 split needs the matrix scale");
+        hipLaunchKernelGGL(pack_a_bx6_kmajor_kernel<SplitF16x2>, dim3(ceil_div((int64_t)M * K, 256)), dim3(256), 0, s, w, (unsigned short*)out, M, K, scale);
+    } else {
+        hipLaunchKernelGGL(pack_a_bx6_kmajor_kernel<SplitBf16x3>, dim3(ceil_div((int64_t)M * K, 256)), dim3(256), 0, s, w, (unsigned short*)out, M, K, scale);
+    }
     return DWS_OK;
 }
 
-template <int H, int FFE>
+template <int H, int FFE, int NT>
 struct Wide6Cfg {
     static constexpr int TH = H / 32, TO = 2 * H / 32, TF = FFE * H / 32;
     static constexpr int WAVES = 4, THREADS = 256;
     static constexpr int KBH = H / 16, KBF = FFE * H / 16;
-    static constexpr int CHUNK = TO * 3 * 1024;                            // bytes: one k-block of the 2H-row GEMMs
+    static constexpr int CHUNK = TO * NT * 1024;                           // bytes: one k-block of the 2H-row GEMMs
     static constexpr int KPC2 = TO / TH;                                   // k-blocks of GEMM-2 per chunk
     static constexpr int NCH = KBH + KBH + KBF / KPC2;                     // chunks per tile
-    static constexpr int NSLOT = 5, AHEAD = NSLOT - 1;                     // ring slots; chunks requested ahead of use
+    static constexpr int NSLOT = (NT == 3) ? 5 : 7, AHEAD = NSLOT - 1;     // ring slots; chunks requested ahead of use
     static constexpr int DPW = CHUNK / 1024 / WAVES;                       // LDS-DMA instructions per wave and chunk
     static constexpr int B_FLOATS = 2 * H + FFE * H + H;
     static constexpr int LDS_BYTES = NSLOT * CHUNK + B_FLOATS * 4;
     static_assert(TO == TF && TO % TH == 0 && KBF % KPC2 == 0 && (CHUNK / 1024) % WAVES == 0 && LDS_BYTES <= 163840, "shape");
 };
 
-template <int H, int FFE, bool YNEXT>
+template <typename P, int H, int FFE, bool YNEXT>
 __global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
-    using T = Wide6Cfg<H, FFE>;
+    using T = Wide6Cfg<H, FFE, P::NT>;
+    using v8 = typename P::v8;
+    constexpr int NT = P::NT, NPR = P::NP;
     constexpr int TH = T::TH, TO = T::TO, TF = T::TF;
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char ldsw[];
@@ -424,34 +450,20 @@ __global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
         return p;
     };
     // acc[m] = W[m] . B + bias over NKB k-blocks whose fragments arrive KPC k-blocks per chunk, [k-block][row tile][term]
-    auto gemm = [&](auto& acc, auto MT_, auto NKB_, auto KPC_, const float* bias, const auto& src) {
+    auto gemm = [&](auto& acc, auto MT_, auto NKB_, auto KPC_, const float* bias, float ws, const auto& src) {
         constexpr int MT = decltype(MT_)::value, NKB = decltype(NKB_)::value, KPC = decltype(KPC_)::value;
         constexpr int NU = MT / 2;
-        {
-            const __bf16 z = (__bf16)0.f, one = (__bf16)(lhi ? 0.f : 1.f);
-            const bx_bf16x8 bf = {one, z, z, z, z, z, z, z};
-            bx_f32x16 zero;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                bx_bf16x8 af[3];
-                frag_rank2(bias[m * 32 + l31], 0.f, lhi == 0, af);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf, zero, 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf, acc[m], 0, 0, 0);
-            }
-        }
-        bx_bf16x8 bq[3], bn[3];
-        c6_bfrag(src[0], 0, bq);
+        c6_bias_block<P, MT>(acc, bias, ws, l31, lhi);
+        v8 bq[NT], bn[NT];
+        c6_bfrag<P>(src[0], 0, bq);
 #pragma unroll
         for (int ch = 0; ch < NKB / KPC; ++ch) {
             const char* wl = next_chunk();
-            bx_bf16x8 a_cur[2][3], a_nxt[2][3];
+            v8 a_cur[2][NT], a_nxt[2][NT];
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) a_cur[mm][t] = *reinterpret_cast<const bx_bf16x8*>(wl + (mm * 3 + t) * 1024);
+                for (int t = 0; t < NT; ++t) a_cur[mm][t] = *reinterpret_cast<const v8*>(wl + (mm * NT + t) * 1024);
 #pragma unroll
             for (int kl = 0; kl < KPC; ++kl) {
                 const int kb = ch * KPC + kl;
@@ -463,31 +475,38 @@ __global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
 #pragma unroll
                         for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                            for (int t = 0; t < 3; ++t)
-                                a_nxt[mm][t] = *reinterpret_cast<const bx_bf16x8*>(wl + (((kln * MT) + un * 2 + mm) * 3 + t) * 1024);
+                            for (int t = 0; t < NT; ++t)
+                                a_nxt[mm][t] = *reinterpret_cast<const v8*>(wl + (((kln * MT) + un * 2 + mm) * NT + t) * 1024);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (last_u && kb + 1 < NKB) c6_bfrag(src[(kb + 1) >> 1], (kb + 1) & 1, bn);
+                    if (last_u && kb + 1 < NKB) c6_bfrag<P>(src[(kb + 1) >> 1], (kb + 1) & 1, bn);
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
+                    for (int t = 0; t < NPR; ++t)
 #pragma unroll
                         for (int mm = 0; mm < 2; ++mm)
-                            acc[u * 2 + mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mm][BX6_IA[t]], bq[BX6_IB[t]], acc[u * 2 + mm], 0, 0, 0);
+                            acc[u * 2 + mm] = P::mfma(a_cur[mm][P::ia(t)], bq[P::ib(t)], acc[u * 2 + mm]);
                     if (last_u && kb + 1 < NKB) {
 #pragma unroll
-                        for (int i = 0; i < 12; ++i) {
+                        for (int i = 0; i < 2 * NPR; ++i) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 48 / (2 * NPR), 0);
                         }
                     }
 #pragma unroll
                     for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                        for (int t = 0; t < 3; ++t) a_cur[mm][t] = a_nxt[mm][t];
+                        for (int t = 0; t < NT; ++t) a_cur[mm][t] = a_nxt[mm][t];
                 }
 #pragma unroll
-                for (int t = 0; t < 3; ++t) bq[t] = bn[t];
+                for (int t = 0; t < NT; ++t) bq[t] = bn[t];
             }
+        }
+        if (P::SCALED) {
+            const float inv = 1.f / (ws * P::SX);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] *= inv;
         }
     };
 
@@ -496,6 +515,7 @@ __global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
     const bool has_mel = a.mel != nullptr, has_add = a.addend != nullptr;
     const float one = lhi ? 0.f : 1.f;
     const float invH = 1.f / (float)H;
+    const float wso = P::SCALED ? a.wscale_c6[0] : 1.f, ws1 = P::SCALED ? a.wscale_c6[1] : 1.f, ws2 = P::SCALED ? a.wscale_c6[2] : 1.f;
 #define W6_SOFF(t, r) ((32 * (t) + ((r) & 3) + 8 * ((r) >> 2)) * L4)
     for (int wt = blockIdx.x; wt < ntiles; wt += gridDim.x) {
         const int b = __builtin_amdgcn_readfirstlane(wt / ntl);
@@ -524,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
         }
         // ---- GEMM-o, GLU + residual, LN2
         bx_f32x16 ao[TO];
-        gemm(ao, std::integral_constant<int, TO>{}, std::integral_constant<int, T::KBH>{}, std::integral_constant<int, 1>{}, bo, g);
+        gemm(ao, std::integral_constant<int, TO>{}, std::integral_constant<int, T::KBH>{}, std::integral_constant<int, 1>{}, bo, wso, g);
         float s1 = 0.f;
 #pragma unroll
         for (int t = 0; t < TH; ++t)
@@ -550,7 +570,7 @@ __global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
             for (int r = 0; r < 16; ++r) y[t][r] = alpha * (x1[t][r] + ln_m);
         // ---- GEMM-1, GELU
         bx_f32x16 u[TF];
-        gemm(u, std::integral_constant<int, TF>{}, std::integral_constant<int, T::KBH>{}, std::integral_constant<int, 1>{}, b1, y);
+        gemm(u, std::integral_constant<int, TF>{}, std::integral_constant<int, T::KBH>{}, std::integral_constant<int, 1>{}, b1, ws1, y);
         bx_f32x16 ad[TH];
         if (has_add) {
             __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.addend + (size_t)b * H * L), 0, H * L4, 0x00020000);
@@ -566,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
             for (int r = 0; r < 16; ++r) u[m][r] = dws_gelu(u[m][r]);
         // ---- GEMM-2, output
         bx_f32x16 f[TH];
-        gemm(f, std::integral_constant<int, TH>{}, std::integral_constant<int, T::KBF>{}, std::integral_constant<int, T::KPC2>{}, b2, u);
+        gemm(f, std::integral_constant<int, TH>{}, std::integral_constant<int, T::KBF>{}, std::integral_constant<int, T::KPC2>{}, b2, ws2, u);
         float so = 0.f;
 #pragma unroll
         for (int t = 0; t < TH; ++t)
@@ -611,26 +631,33 @@ __global__ __launch_bounds__(256, 1) void s4_tail_wide6_kernel(S4TailArgs a) {
 
 bool s4_tail_wide6_supported(int H, int ff) { return ff == 2 && H == 128; }
 
-int launch_s4_tail_wide6(int H, const S4TailArgs& a, hipStream_t s) {
-    DWS_CHECK(H == 128 && a.Ao_c6, DWS_ERR_STATE, "s4_tail_wide6: H=%d / weights not packed", H);
-    using T = Wide6Cfg<128, 2>;
-    ProfileScope ps("s4_tail_mfma_wide6", s);
+template <typename P>
+static int launch_wide6_p(const S4TailArgs& a, hipStream_t s) {
+    using T = Wide6Cfg<128, 2, P::NT>;
+    ProfileScope ps(P::NT == 3 ? "s4_tail_mfma_wide6" : "s4_tail_mfma_wide_f16x3", s);
     static int ncu = 0;
     if (ncu == 0) {
-        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_wide6_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_wide6_kernel<128, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_wide6_kernel<P, 128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_wide6_kernel<P, 128, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
         int dev = 0;
         DWS_HIP(hipGetDevice(&dev));
         DWS_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const int ntiles = a.B * ceil_div(a.L, 128);
     const int grid = std::min(ncu, ntiles);
-    if (a.ynext) hipLaunchKernelGGL((s4_tail_wide6_kernel<128, 2, true>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((s4_tail_wide6_kernel<128, 2, false>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, a);
+    if (a.ynext) hipLaunchKernelGGL((s4_tail_wide6_kernel<P, 128, 2, true>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((s4_tail_wide6_kernel<P, 128, 2, false>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, a);
     return DWS_OK;
 }
 
-
+int launch_s4_tail_wide6(int H, const S4TailArgs& a, hipStream_t s) {
+    DWS_CHECK(H == 128 && a.Ao_c6, DWS_ERR_STATE, "s4_tail_wide6: H=%d / weights not packed", H);
+    if (a.split_c6 == WN_SPLIT_F16X3) {
+        DWS_CHECK(a.wscale_c6 != nullptr, DWS_ERR_STATE, "s4_tail_wide6: no weight scales for the fp16 split");
+        return launch_wide6_p<SplitF16x2>(a, s);
+    }
+    return launch_wide6_p<SplitBf16x3>(a, s);
+}
 
 template <typename F>
 static void chain6_trace_launch(int H, int nwg, int waves, S4TailArgs a, hipStream_t s, F launch) {
@@ -662,19 +689,19 @@ static void chain6_trace_launch(int H, int nwg, int waves, S4TailArgs a, hipStre
     fprintf(stderr, " tile %.0f\n", life / cnt);
 }
 
-template <int H>
+template <typename P, int H>
 static int launch_chain6_t(const S4TailArgs& a, hipStream_t s) {
-    using T = Chain6Cfg<H, 2>;
-    ProfileScope ps("s4_tail_mfma_chain6", s);
+    using T = Chain6Cfg<H, 2, P::NT>;
+    ProfileScope ps(P::NT == 3 ? "s4_tail_mfma_chain6" : "s4_tail_mfma_chain_f16x3", s);
     const size_t lds = (size_t)T::LDS_BYTES;
     static int slots = 0;
     if (slots == 0) {
-        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain6_kernel<H, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain6_kernel<H, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain6_kernel<P, H, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain6_kernel<P, H, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0, ncu = 0, per_cu = 0;
         DWS_HIP(hipGetDevice(&dev));
         DWS_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        DWS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s4_tail_chain6_kernel<H, 2, true>, T::THREADS, lds));
+        DWS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s4_tail_chain6_kernel<P, H, 2, true>, T::THREADS, lds));
         DWS_CHECK(ncu > 0 && per_cu > 0, DWS_ERR_HIP, "s4_tail_chain6: occupancy query returned %d x %d", ncu, per_cu);
         slots = ncu * per_cu;
     }
@@ -683,19 +710,25 @@ static int launch_chain6_t(const S4TailArgs& a, hipStream_t s) {
     static const bool trace = std::getenv("DWS_CHAIN_TRACE") != nullptr;
     if (trace && a.ynext) {
         chain6_trace_launch(H, grid, T::WAVES, a, s, [&](const S4TailArgs& at) {
-            hipLaunchKernelGGL((s4_tail_chain6_kernel<H, 2, true>), dim3(grid), dim3(T::THREADS), lds, s, at);
+            hipLaunchKernelGGL((s4_tail_chain6_kernel<P, H, 2, true>), dim3(grid), dim3(T::THREADS), lds, s, at);
         });
         return DWS_OK;
     }
-    if (a.ynext) hipLaunchKernelGGL((s4_tail_chain6_kernel<H, 2, true>), dim3(grid), dim3(T::THREADS), lds, s, a);
-    else hipLaunchKernelGGL((s4_tail_chain6_kernel<H, 2, false>), dim3(grid), dim3(T::THREADS), lds, s, a);
+    if (a.ynext) hipLaunchKernelGGL((s4_tail_chain6_kernel<P, H, 2, true>), dim3(grid), dim3(T::THREADS), lds, s, a);
+    else hipLaunchKernelGGL((s4_tail_chain6_kernel<P, H, 2, false>), dim3(grid), dim3(T::THREADS), lds, s, a);
     return DWS_OK;
 }
 
 int launch_s4_tail_chain6(int H, const S4TailArgs& a, hipStream_t s) {
     DWS_CHECK(a.Ao_c6 && a.A1_c6 && a.A2_c6, DWS_ERR_STATE, "s4_tail_chain6: the split chain-ordered weights were not packed");
-    if (H == 32) return launch_chain6_t<32>(a, s);
-    if (H == 64) return launch_chain6_t<64>(a, s);
+    if (a.split_c6 == WN_SPLIT_F16X3) {
+        DWS_CHECK(a.wscale_c6 != nullptr, DWS_ERR_STATE, "s4_tail_chain6: no weight scales for the fp16 split");
+        if (H == 32) return launch_chain6_t<SplitF16x2, 32>(a, s);
+        if (H == 64) return launch_chain6_t<SplitF16x2, 64>(a, s);
+    } else {
+        if (H == 32) return launch_chain6_t<SplitBf16x3, 32>(a, s);
+        if (H == 64) return launch_chain6_t<SplitBf16x3, 64>(a, s);
+    }
     return set_error(DWS_ERR_UNSUPPORTED, "s4_tail_chain6: H=%d not instantiated", H);
 }
 

@@ -39,6 +39,8 @@ struct S4TailArgs {
     const void* Ao_c6;
     const void* A1_c6;
     const void* A2_c6;
+    int split_c6;                // WN_SPLIT_BF16X6 | WN_SPLIT_F16X3 (wavenet.h): which split the three blobs above hold
+    const float* wscale_c6;      // f16x3: the power of two each of Wo, W1, W2 was packed with [3]
     unsigned long long* trace;   // nullable (tools only, DWS_TAIL_TRACE=1): s_memtime stamps [workgroup][wave][16] of the
                                  // LDS-tile kernel's phases
 };
@@ -72,7 +74,7 @@ int launch_chain16_permute_cols(const float* w, float* out, int M, int K, hipStr
 // [Wo | W1 | W2] of k-block-major fragments (pack_a_bx6_kmajor)
 bool s4_tail_wide6_supported(int H, int ff);
 int launch_s4_tail_wide6(int H, const S4TailArgs& a, hipStream_t s);
-int launch_pack_a_bx6_kmajor(const float* w, void* out, int M, int K, hipStream_t s);
+int launch_pack_a_bx6_kmajor(const float* w, void* out, int M, int K, int split, const float* scale, hipStream_t s);
 int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s);
 bool pw_mfma_supported(int mode, int K, int M, int p);
 bool pw_mfma_ln_supported(int M);

@@ -110,7 +110,8 @@ struct SLayer {
     DevBuf W1, W2, Wp;    // folded ff / pool weights
     DevBuf Ao, A1, A2, rs1, Ap;  // MFMA-packed copies (+ row sums of W1 for the folded LayerNorm)
     DevBuf Ao_c, A1_c, A2_c;     // H <= 64: the same weights with chain-ordered columns (sashimi_chain.hip)
-    DevBuf Ao_c6, A1_c6, A2_c6;  // precision = bf16x6: 3-term bf16 fragments in the 16-wide chain order (sashimi_chain6.hip)
+    DevBuf Ao_c6, A1_c6, A2_c6;  // precision = bf16x6 / f16x3: split fragments in the 16-wide chain order (sashimi_chain6.hip)
+    DevBuf wscale_c6;            // f16x3: the three matrices' power-of-two scales
     bool mfma = false, mfma2 = false;
     DevBuf Kf;            // rocFFT path: [H][L+1] complex spectrum of the two-sided kernel (n = 2L)
     DevBuf kfa, kfb, kfs; // fused path: pair-ordered spectrum at the power-of-two size (fftconv.h)
@@ -181,14 +182,18 @@ struct SashimiModel : dws_model {
     CondTrainWs cws;
     DevBuf gW0f, gW1f, gWcf;
 
-    bool bf16x6 = false;      // precision option: the H <= 64 tails on the bf16 matrix cores, 3-term split (sashimi_chain6.hip)
+    // precision option: the H <= 128 tails on the 16-bit matrix cores (sashimi_chain6.hip): bf16x6 = 3-term bf16 split, six
+    // products; f16x3 = 2-term fp16 split of scaled operands, three products
+    bool bf16x6 = false, f16x3 = false;
+    bool split_tails() const { return bf16x6 || f16x3; }
     int set_option(const std::string& key, const std::string& value) override {
         if (key == "precision") {
-            if (value == "f32" || value == "bf16x6") {
-                if ((value == "bf16x6") != bf16x6) { bf16x6 = !bf16x6; dirty = true; drop_graph(); trained_fwd = false; }
+            if (value == "f32" || value == "bf16x6" || value == "f16x3") {
+                const bool b6 = value == "bf16x6", f3 = value == "f16x3";
+                if (b6 != bf16x6 || f3 != f16x3) { bf16x6 = b6; f16x3 = f3; dirty = true; drop_graph(); trained_fwd = false; }
                 return DWS_OK;
             }
-            return set_error(DWS_ERR_UNSUPPORTED, "sashimi: precision=%s is not built (f32 | bf16x6)", value.c_str());
+            return set_error(DWS_ERR_UNSUPPORTED, "sashimi: precision=%s is not built (f32 | bf16x6 | f16x3)", value.c_str());
         }
         return dws_model::set_option(key, value);
     }
@@ -510,28 +515,39 @@ struct SashimiModel : dws_model {
                         DWS_TRY(launch_chain_permute_cols(l->W2.f(), chain_tmp.f(), H, FF * H, s));
                         DWS_TRY(launch_pack_a_frag(chain_tmp.f(), l->A2_c.f(), H, FF * H, s));
                     }
-                    if (bf16x6 && s4_tail_chain6_supported(H, FF)) {
+                    const int split = f16x3 ? WN_SPLIT_F16X3 : WN_SPLIT_BF16X6;
+                    const size_t wb = 2 * (size_t)wn_split_terms(split);            // bytes per packed weight
+                    float* sc = nullptr;
+                    if (f16x3 && (s4_tail_chain6_supported(H, FF) || s4_tail_wide6_supported(H, FF))) {
+                        DWS_TRY(l->wscale_c6.ensure(3 * 4));
+                        sc = l->wscale_c6.f();
+                        DWS_TRY(launch_weight_scale(P(l->prefix + ".layer.output_linear.0.weight"), (size_t)2 * H * H,
+                                                    P(l->prefix + ".layer.output_linear.0.bias"), 2 * H, nullptr, 0, sc, s));
+                        DWS_TRY(launch_weight_scale(l->W1.f(), (size_t)FF * H * H, P(l->prefix + ".ff.ff.0.conv.bias"), FF * H, nullptr, 0, sc + 1, s));
+                        DWS_TRY(launch_weight_scale(l->W2.f(), (size_t)FF * H * H, P(l->prefix + ".ff.ff.2.conv.bias"), H, nullptr, 0, sc + 2, s));
+                    }
+                    if (split_tails() && s4_tail_chain6_supported(H, FF)) {
                         DWS_TRY(chain_tmp.ensure((size_t)FF * H * H * 4));
-                        DWS_TRY(l->Ao_c6.ensure((size_t)2 * H * H * 6));
-                        DWS_TRY(l->A1_c6.ensure((size_t)FF * H * H * 6));
-                        DWS_TRY(l->A2_c6.ensure((size_t)FF * H * H * 6));
+                        DWS_TRY(l->Ao_c6.ensure((size_t)2 * H * H * wb));
+                        DWS_TRY(l->A1_c6.ensure((size_t)FF * H * H * wb));
+                        DWS_TRY(l->A2_c6.ensure((size_t)FF * H * H * wb));
                         DWS_TRY(launch_chain16_permute_cols(P(l->prefix + ".layer.output_linear.0.weight"), chain_tmp.f(), 2 * H, H, s));
-                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->Ao_c6.p, 2 * H, H, WN_SPLIT_BF16X6, nullptr, s));
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->Ao_c6.p, 2 * H, H, split, sc, s));
                         DWS_TRY(launch_chain16_permute_cols(l->W1.f(), chain_tmp.f(), FF * H, H, s));
-                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A1_c6.p, FF * H, H, WN_SPLIT_BF16X6, nullptr, s));
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A1_c6.p, FF * H, H, split, sc ? sc + 1 : nullptr, s));
                         DWS_TRY(launch_chain16_permute_cols(l->W2.f(), chain_tmp.f(), H, FF * H, s));
-                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A2_c6.p, H, FF * H, WN_SPLIT_BF16X6, nullptr, s));
-                    } else if (bf16x6 && s4_tail_wide6_supported(H, FF)) {   // one blob [Wo | W1 | W2], k-block-major fragments
+                        DWS_TRY(launch_pack_a_bx6(chain_tmp.f(), l->A2_c6.p, H, FF * H, split, sc ? sc + 2 : nullptr, s));
+                    } else if (split_tails() && s4_tail_wide6_supported(H, FF)) {   // one blob [Wo | W1 | W2], k-block-major fragments
                         DWS_TRY(chain_tmp.ensure((size_t)FF * H * H * 4));
-                        DWS_TRY(l->Ao_c6.ensure((size_t)(2 + 2 * FF) * H * H * 6));
+                        DWS_TRY(l->Ao_c6.ensure((size_t)(2 + 2 * FF) * H * H * wb));
                         l->A1_c6.release(); l->A2_c6.release();
                         char* blob = static_cast<char*>(l->Ao_c6.p);
                         DWS_TRY(launch_chain16_permute_cols(P(l->prefix + ".layer.output_linear.0.weight"), chain_tmp.f(), 2 * H, H, s));
-                        DWS_TRY(launch_pack_a_bx6_kmajor(chain_tmp.f(), blob, 2 * H, H, s));
+                        DWS_TRY(launch_pack_a_bx6_kmajor(chain_tmp.f(), blob, 2 * H, H, split, sc, s));
                         DWS_TRY(launch_chain16_permute_cols(l->W1.f(), chain_tmp.f(), FF * H, H, s));
-                        DWS_TRY(launch_pack_a_bx6_kmajor(chain_tmp.f(), blob + (size_t)2 * H * H * 6, FF * H, H, s));
+                        DWS_TRY(launch_pack_a_bx6_kmajor(chain_tmp.f(), blob + (size_t)2 * H * H * wb, FF * H, H, split, sc ? sc + 1 : nullptr, s));
                         DWS_TRY(launch_chain16_permute_cols(l->W2.f(), chain_tmp.f(), H, FF * H, s));
-                        DWS_TRY(launch_pack_a_bx6_kmajor(chain_tmp.f(), blob + (size_t)(2 + FF) * H * H * 6, H, FF * H, s));
+                        DWS_TRY(launch_pack_a_bx6_kmajor(chain_tmp.f(), blob + (size_t)(2 + FF) * H * H * wb, H, FF * H, split, sc ? sc + 2 : nullptr, s));
                     } else {
                         l->Ao_c6.release(); l->A1_c6.release(); l->A2_c6.release();
                     }
@@ -774,7 +790,11 @@ struct SashimiModel : dws_model {
             t.A2 = l->A2.f(); t.b2 = P(p + ".ff.ff.2.conv.bias");
             t.addend = addend; t.out = l->out.f(); t.B = nB; t.L = Ls;
             t.Ao_c = l->Ao_c.f(); t.A1_c = l->A1_c.f(); t.A2_c = l->A2_c.f();
-            if (bf16x6) { t.Ao_c6 = l->Ao_c6.p; t.A1_c6 = l->A1_c6.p; t.A2_c6 = l->A2_c6.p; }
+            if (split_tails()) {
+                t.Ao_c6 = l->Ao_c6.p; t.A1_c6 = l->A1_c6.p; t.A2_c6 = l->A2_c6.p;
+                t.split_c6 = f16x3 ? WN_SPLIT_F16X3 : WN_SPLIT_BF16X6;
+                t.wscale_c6 = f16x3 ? l->wscale_c6.f() : nullptr;
+            }
             if (next) {     // next block: feeds_next(l, next) holds, the stage's y buffer is free once this block's convolution ran
                 t.ynext = next->y;
                 t.n1_m = next->m; t.n1_s = next->s;

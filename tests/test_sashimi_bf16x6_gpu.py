@@ -1,8 +1,10 @@
-"""precision="bf16x6" for the SaShiMi backbone: the register-chained S4 tails (H <= 128: `s4.py:1435` output_linear + GLU,
+"""precision="bf16x6" and "f16x3" for the SaShiMi backbone: the register-chained S4 tails (H <= 128: `s4.py:1435` output_linear + GLU,
 `sashimi.py:60-75` FF, `sashimi.py:177-184`) on the bf16 matrix cores with the 3-term split of `csrc/bf16_split.h`
 (`csrc/sashimi_chain6.hip`: H = 32, 64 with the weights resident in LDS, H = 128 one wave per SIMD with the weights
 streamed through an LDS ring).  Same acceptance as the WaveNet layer (tests/test_bf16x6_gpu.py): measured against a
-FLOAT64 evaluation of the oracle graph, the split path's error must stay within 2x the exact-f32 MFMA path's."""
+FLOAT64 evaluation of the oracle graph, the split path's error must stay within 2x the exact-f32 MFMA path's.
+"f16x3" runs the same kernels with the 2-term fp16 split (`csrc/bf16_split.h`: SplitF16x2; activations x 2^4, every weight
+matrix by its own power of two, three products) under the same criterion."""
 import pytest
 import torch
 
@@ -20,8 +22,12 @@ def _f64(net, cfg, audio, steps, mel=None):
                                    return_pre_final=True)
 
 
+SPLITS = ["bf16x6", "f16x3"]
+
+
+@pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("name", ["ss_d64_short", "ss_d128_short", "ss_unet_d64"])
-def test_sashimi_bf16x6_error_against_float64_is_that_of_the_f32_path(gpu, name):
+def test_sashimi_bf16x6_error_against_float64_is_that_of_the_f32_path(gpu, name, split):
     cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES[name]
     L = cfg["L"]
     net = cases.build_ours(cfg, wseed).to(gpu)
@@ -29,10 +35,10 @@ def test_sashimi_bf16x6_error_against_float64_is_that_of_the_f32_path(gpu, name)
     ref, ref_pre = _f64(net, cfg, audio, steps)
     out = {}
     with torch.no_grad():
-        for prec in ("f32", "bf16x6"):
+        for prec in ("f32", split):
             net.set_option("precision", prec)
             eps = net((audio.to(gpu), steps.to(gpu)))
-            out[prec] = (eps.cpu(), net.read_tap("pre_final", (B, cfg["d_model"], L)).cpu())
+            out["f32" if prec == "f32" else "bf16x6"] = (eps.cpu(), net.read_tap("pre_final", (B, cfg["d_model"], L)).cpu())
         net.set_option("precision", "f32")
         again = net((audio.to(gpu), steps.to(gpu))).cpu()
     assert torch.equal(again, out["f32"][0])                 # switching back restores the f32 path bit for bit
@@ -40,9 +46,9 @@ def test_sashimi_bf16x6_error_against_float64_is_that_of_the_f32_path(gpu, name)
     e = {p: (rel_err(out[p][0], ref), rel_err(out[p][1], ref_pre)) for p in out}
     rms = {p: float(((out[p][1].double() - ref_pre) ** 2).mean().sqrt() / (ref_pre ** 2).mean().sqrt()) for p in out}
     direct = rel_err(out["bf16x6"][1], out["f32"][1])
-    print(f"{name}: max-rel error vs float64 (eps, pre_final) f32-MFMA {e['f32'][0]:.3e} {e['f32'][1]:.3e} | bf16x6 "
-          f"{e['bf16x6'][0]:.3e} {e['bf16x6'][1]:.3e}; rms-rel pre_final f32 {rms['f32']:.3e} bf16x6 {rms['bf16x6']:.3e}; "
-          f"bf16x6 vs f32 path directly {direct:.3e}")
+    print(f"{name}: max-rel error vs float64 (eps, pre_final) f32-MFMA {e['f32'][0]:.3e} {e['f32'][1]:.3e} | {split} "
+          f"{e['bf16x6'][0]:.3e} {e['bf16x6'][1]:.3e}; rms-rel pre_final f32 {rms['f32']:.3e} {split} {rms['bf16x6']:.3e}; "
+          f"{split} vs f32 path directly {direct:.3e}")
     for k in (0, 1):
         assert e["bf16x6"][k] <= 2.0 * e["f32"][k], (name, k, e)
     assert rms["bf16x6"] <= 2.0 * rms["f32"], (name, rms)
@@ -51,13 +57,14 @@ def test_sashimi_bf16x6_error_against_float64_is_that_of_the_f32_path(gpu, name)
     assert rel_err(out["bf16x6"][0], g[f"{name}/eps"]) < max(1.5 * rel_err(out["f32"][0], g[f"{name}/eps"]), REL_TOL / 100)
 
 
-def test_sashimi_bf16x6_conditional_d32_matches_reference(gpu):
+@pytest.mark.parametrize("split", SPLITS)
+def test_sashimi_bf16x6_conditional_d32_matches_reference(gpu, split):
     """H = 32 and 64 chained tails with the mel term in the residual (`sashimi.py:160-175`), BASELINE config 4's widths."""
     name = "ss_cond_d32"
     cfg, B, Tmel, wseed, iseed, _ = cases.SASHIMI_COND_CASES[name]
     g = load_golden("sashimi_cond")
     net = cases.build_ours(cfg, wseed).to(gpu)
-    net.set_option("precision", "bf16x6")
+    net.set_option("precision", split)
     audio, steps = cases.wavenet_inputs(B, cfg["L"], 1, iseed)
     with torch.no_grad():
         for Bm in (1, B):
@@ -69,12 +76,13 @@ def test_sashimi_bf16x6_conditional_d32_matches_reference(gpu):
             assert err < REL_TOL / 100, f"{name} Bm={Bm}: {err:.3e}"
 
 
-def test_sashimi_bf16x6_sampler_graph_equals_the_per_step_loop(gpu):
+@pytest.mark.parametrize("split", SPLITS)
+def test_sashimi_bf16x6_sampler_graph_equals_the_per_step_loop(gpu, split):
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
     cfg, B, wseed, iseed, _ = cases.SASHIMI_CASES["ss_d64_short"]
     L = cfg["L"]
     net = cases.build_ours(cfg, wseed).to(gpu)
-    net.set_option("precision", "bf16x6")
+    net.set_option("precision", split)
     T = 5
     dh = calc_diffusion_hyperparams(T, 1e-4, 0.05)
     gen = torch.Generator().manual_seed(5)
@@ -93,4 +101,5 @@ def test_sashimi_rejects_unknown_precision(gpu):
     with pytest.raises(NotImplementedError):
         net.set_option("precision", "bf16x3")
     net.set_option("precision", "bf16x6")      # accepted: no tail of this tiny model is on the chain kernel, nothing changes
+    net.set_option("precision", "f16x3")
     net.set_option("precision", "f32")
