@@ -437,6 +437,9 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
     # (SaShiMi unet_d128_n6) is quoted at 256 global on 8 GPUs = 32 per GPU
     B, L = (args.batch or (4 if cfg["model"]["_name_"] == "wavenet" else 32)), cfg["L"]
     net = build_model(cfg, dev).train()
+    tprec = getattr(args, "precision", "f32")
+    if tprec != "f32":       # SaShiMi: bf16x6 = the pointwise GEMMs and weight gradients of the step on the bf16 matrix cores
+        net.set_option("precision", tprec)
     if world > 1:
         net = apply_gradient_allreduce(net)
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)     # `train.py:91`
@@ -545,7 +548,7 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
             "metric": "training audio samples/sec (train.py-style DP step: fwd + bwd + grad all-reduce + Adam)",
             "value": ddist.aggregate_throughput(B * L, world, ms * 1e-3), "unit": "audio samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic U(-0.3,0.3) audio",
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAMES[tprec], "data": "synthetic U(-0.3,0.3) audio",
             "config": {"workload": args.config + " training", "batch_per_gpu": B, "L": L,
                        "parallelism": "dp%d, bucketed asynchronous RCCL all-reduce of the gradients" % world},
             "per_rank_ms_per_step": per_rank_ms, "process_group": ddist.group_info(),
@@ -743,6 +746,24 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
         r = train_bench(a, dict(CONFIGS[a.config]), world, rank, dev, ddist, red_dev, emit=False)
         out[key] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
                                       "final_loss", "dp") if k in r}
+        # the same step with its pointwise GEMMs and weight gradients on the bf16 matrix cores (exact 3-term split, six
+        # products: tapconv_mfma_kernel<.., SPLIT>, wgrad_dma4_kernel<1>; gradients against float64 within 2x the f32 path's,
+        # tests/test_sashimi_training_gpu.py).  Opt-in, not the leg's value.
+        a6 = copy.copy(a)
+        a6.precision = "bf16x6"
+        prev = os.environ.get("DWS_BENCH_NO_DP_OVERHEAD")
+        os.environ["DWS_BENCH_NO_DP_OVERHEAD"] = "1"          # (the DP-overhead measurement belongs to the f32 leg above)
+        try:
+            r6 = train_bench(a6, dict(CONFIGS[a.config]), world, rank, dev, ddist, red_dev, emit=False)
+        finally:
+            if prev is None:
+                del os.environ["DWS_BENCH_NO_DP_OVERHEAD"]
+            else:
+                os.environ["DWS_BENCH_NO_DP_OVERHEAD"] = prev
+        if r6:
+            out[key]["extra_bf16x6"] = {"ms_per_step": r6["ms_per_step"], "value": r6["value"], "unit": r6["unit"],
+                                        "dtype": r6["dtype"], "final_loss": r6["final_loss"],
+                                        "note": "opt-in precision=bf16x6; not the leg's value"}
         if not args.no_cpu_baseline:
             if args.cpu_train_baseline:
                 out[key]["cpu_baseline"] = cpu_train_baseline(dict(CONFIGS[a.config]))

@@ -1068,6 +1068,7 @@ struct SashimiModel : dws_model {
         q.out = out; q.bias = bias; q.res = res; q.addend = addend; q.aux = aux; q.out2 = out2;
         q.addin = (epi == 0) ? aux : nullptr; q.addscale = 1.f;
         q.B = (int)B; q.L = Lx;
+        q.split = bf16x6 ? 1 : 0;      // precision = bf16x6: the pointwise GEMMs of the training step on the bf16 matrix cores
         return launch_tapconv_mfma(q, s);
     }
 
@@ -1082,6 +1083,7 @@ struct SashimiModel : dws_model {
             DWS_TRY(bpart.ensure((size_t)w.nsplit * O * 4));
             w.bias_part = bpart.f(); w.dbias = db; w.bias_scale = 1.f;
         }
+        w.split = bf16x6 ? 1 : 0;
         return launch_wgrad_mfma(w, 1, 1.f, dW, s);
     }
 

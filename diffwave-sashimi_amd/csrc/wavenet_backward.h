@@ -38,6 +38,7 @@ struct TapConvArgs {
     const float* H; float* dH; float* g;
     const float* bias; const float* res; const float* addend; const float* aux; float* out2;
     int B, L;
+    int split;                   // 1: precision = bf16x6 (3-term bf16 split, six products) where an instance exists (T = 1, L % 4 == 0)
 };
 bool tapconv_mfma_supported(int M, int K0, int K1, int T);
 bool tapconv_glu_supported(int M, int K, int L);   // epilogue 6 (GLU + residual fused into the 2H x H GEMM)
@@ -60,6 +61,7 @@ struct WgradArgs {
     float* bias_part;            // optional [nsplit][O] scratch: also produce dbias[o] = bias_scale * sum_{b,l} dY[b,o,l]
     float* dbias; float bias_scale;
     int xL;                      // row stride of X in floats (0 = L)
+    int split;                   // 1: precision = bf16x6 in the 16-byte single-tap kernel (wgrad_dma4)
 };
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T);
 int launch_wgrad_mfma(const WgradArgs& a, int T, float scale, float* dW, hipStream_t s);

@@ -16,6 +16,7 @@
 //   scratch buffer and are summed in a fixed order by wgrad_reduce_kernel (deterministic, no atomics).
 #include <cstdlib>
 
+#include "bf16_split.h"
 #include "wavenet_backward.h"
 
 // (Nontemporal cache policy on the streamed operands -- tapconv input DMA, its output stores, the wgrad DMA -- was
@@ -42,15 +43,25 @@ __device__ __forceinline__ float gelu_grad_b(float x) { return dws_gelu_grad(x);
 //   6  GLU + residual (`s4.py:1435`, `sashimi.py:177`), M = 2H, MT = 2: a wave owns the 32-row tiles q and q + H/32
 //      (the two GLU halves of the same channels): out = o = acc + bias [B,2H,L] and
 //      out2 = x1 = res + o_a sigmoid(o_b) (+ aux)  [B,H,L]
-template <int MT, int T, int EPI>
+//
+// SPLIT (precision = "bf16x6" in training; T = 1, 16-byte staging only): the same GEMM on the bf16 matrix cores with every
+// operand as an exact 3-term bf16 split and six partial products (bf16_split.h).  The staged fp32 chunk is split ONCE by
+// the workgroup (one 16-byte B item of eight k values per thread and chunk, three terms) into a second LDS buffer while
+// the previous chunk's MFMAs run; the A fragments stay the fp32 ones of pack_a_frag (the weights change every step) and
+// are split by the wave that owns the rows.  Slot e = 4 g + j of a 16-wide k-block is k = 16 kb + 8 g + 2 j + lhi -- the
+// order the fp32 fragments of k-groups 2 kb, 2 kb + 1 already hold per lane; the B items are built in the same order.
+template <int MT, int T, int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void tapconv_mfma_kernel(TapConvArgs a) {
     constexpr int P = 64, NT = 2, KC = 32;
     constexpr int ROWS = T * KC, RPW = ROWS / 4;
+    static_assert(!SPLIT || (T == 1 && EPI != 1), "split instances: pointwise GEMMs");
+    constexpr int BOP_FLOATS = SPLIT ? (KC / 16) * 2 * 3 * P * 4 : 0;     // one split chunk: [k-block][k half][term][column] 16-byte items
     // T = 3: measured faster with 2 workgroups per CU than with 3 (456 -> 384 us on the C = 256 adjoint), so the
     // allocation is padded past a third of the 160 KB LDS
     constexpr int LDS_PAD = (T == 3) ? 2304 : 0;
     constexpr int EPI_FLOATS = (EPI == 1) ? 0 : 4 * 32 * P;   // one 32-row transposition tile per wave (float4 epilogue)
-    constexpr int LDS_FLOATS = (2 * ROWS * P + LDS_PAD) > EPI_FLOATS ? (2 * ROWS * P + LDS_PAD) : EPI_FLOATS;
+    constexpr int MAIN_FLOATS = 2 * ROWS * P + LDS_PAD + 2 * BOP_FLOATS;
+    constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,6 +126,74 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // has to land within a k-group -- was built for T = 1 and measured: -13 % on the K = 2H GEMMs (8+ chunks), but +5..8 %
     // on the K = H ones (4 chunks: the longer prologue shows); choosing per launch by the chunk count kept both gains apart
     // but the larger kernel slowed its other path by 4 %: a wash over a training step either way.  Not kept.)
+    if constexpr (SPLIT) {
+        char* const bop = reinterpret_cast<char*>(lds + 2 * ROWS * P);
+        // this thread's B item of a chunk: k-block wave >> 1, k half wave & 1 (wave-uniform), column lane
+        auto transform = [&](int cb) {
+            const float* xs = lds + (cb & 1) * (ROWS * P) + ((wave >> 1) * 16 + (wave & 1)) * P + lane;
+            bx_bf16x8 it[3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) SplitBf16x3::split1(xs[(8 * (e >> 2) + 2 * (e & 3)) * P], it, e);
+            char* dst = bop + (cb & 1) * (BOP_FLOATS * 4) + ((wave * 3) * P + lane) * 16;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<bx_bf16x8*>(dst + t * (P * 16)) = it[t];
+        };
+        constexpr int NAF = MT * 2;                    // fp32 A fragments (k-groups) per k-block of 16
+        f32x4 a_cur[MT][2], a_nxt[MT][2];
+        const int nkb = ncb * (KC / 16);
+        auto load_a = [&](f32x4 (&dst)[MT][2], int kb) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) dst[m][g] = buf_load4(rA, lane16, (mt[m] * a.nkg_total + 2 * kb + g) * 1024);
+        };
+        stage_dma(0, 0);
+        if (ncb > 1) stage_dma(1, 1);
+        load_a(a_cur, 0);
+        // chunk 0 has landed: all but the loads issued after it (chunk 1: KC / 16 per wave, and the A fragments)
+        if (ncb > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (KC / 16 + NAF));
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | NAF);
+        __syncthreads();
+        transform(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NAF);      // chunk 1 too
+        __syncthreads();
+        for (int cb = 0; cb < ncb; ++cb) {
+            if (cb + 2 < ncb) stage_dma(cb + 2, cb & 1);   // raw buffer of chunk cb: split an iteration ago
+            const char* bb = bop + (cb & 1) * (BOP_FLOATS * 4) + (lhi * 3 * P + l31) * 16;
+#pragma unroll
+            for (int kl = 0; kl < KC / 16; ++kl) {
+                const int kb = cb * (KC / 16) + kl;
+                load_a(a_nxt, kb + 1 < nkb ? kb + 1 : kb);
+                __builtin_amdgcn_sched_barrier(0);
+                bx_bf16x8 bq[NT][3];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        bq[n][t] = *reinterpret_cast<const bx_bf16x8*>(bb + ((kl * 2 * 3 + t) * P + n * 32) * 16);
+                bx_bf16x8 af[MT][3];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) SplitBf16x3::split1(a_cur[m][e >> 2][e & 3], af[m], e);
+                if (kl == 0 && cb + 1 < ncb) transform(cb + 1);   // rides in this k-block's MFMA stream
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][BX6_IA[t]], bq[n][BX6_IB[t]], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) a_cur[m][g] = a_nxt[m][g];
+            }
+            // chunk cb + 2 has landed (younger: only the NAF fragments of the next k-block); split chunk cb + 1 visible
+            __builtin_amdgcn_s_waitcnt(0x0F70 | NAF);
+            __syncthreads();
+        }
+    } else {
     stage_dma(0, 0);
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
@@ -149,6 +228,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // the LDS-DMA of chunk cb+1 (the only younger loads: the next k-group's A fragments)
         __syncthreads();
+    }
     }
 
 
@@ -323,9 +403,27 @@ bool tapconv_glu_supported(int M, int K, int L) {
     return tapconv_mfma_supported(M, K, 0, 1) && M % 256 == 0 && (L & 3) == 0;
 }
 
+// split instances: T = 1, not the gate adjoint, and the 16-byte staging form (the kernel's x4 condition)
+static bool tapconv_split_ok(const TapConvArgs& a) {
+    return a.split == 1 && a.T == 1 && a.epi != 1 && a.L % 4 == 0 && ((((size_t)a.src0) | ((size_t)a.src1)) % 16 == 0);
+}
+
 template <int T, int EPI>
 static int launch_tc(const TapConvArgs& a, hipStream_t s) {
     const int nt = a.B * ceil_div(a.L, 64);
+    if constexpr (T == 1 && EPI != 1) {
+        if (tapconv_split_ok(a)) {
+            if constexpr (EPI == 6) {
+                hipLaunchKernelGGL((tapconv_mfma_kernel<2, T, EPI, 1>), dim3(nt, a.M / 256), dim3(256), 0, s, a);
+            } else {
+                if (a.M % 256 == 0)
+                    hipLaunchKernelGGL((tapconv_mfma_kernel<2, T, EPI, 1>), dim3(nt, ceil_div(a.M, 256)), dim3(256), 0, s, a);
+                else
+                    hipLaunchKernelGGL((tapconv_mfma_kernel<1, T, EPI, 1>), dim3(nt, ceil_div(a.M, 128)), dim3(256), 0, s, a);
+            }
+            return DWS_OK;
+        }
+    }
     if constexpr (EPI == 6) {
         hipLaunchKernelGGL((tapconv_mfma_kernel<2, T, EPI>), dim3(nt, a.M / 256), dim3(256), 0, s, a);
     } else {
@@ -338,7 +436,7 @@ static int launch_tc(const TapConvArgs& a, hipStream_t s) {
 }
 
 int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s) {
-    ProfileScope ps("tapconv_mfma", s);
+    ProfileScope ps(tapconv_split_ok(a) ? "tapconv_bx6" : "tapconv_mfma", s);
     DWS_CHECK(tapconv_mfma_supported(a.M, a.K0, a.K1, a.T), DWS_ERR_UNSUPPORTED, "tapconv_mfma: M=%d K=%d+%d T=%d", a.M,
               a.K0, a.K1, a.T);
     if (a.T == 3) {
@@ -590,6 +688,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
 //  * a lane reads one ds_read_b128 per operand and FOUR k-steps: the contraction index of MFMA e of block j is position
 //    8 j + 4 lhi + e for both operands (any pairing of positions with k is as good as any other).  The sixteen lanes a
 //    ds_read_b128 services together sit in sixteen different rows, i.e. sixteen different rotations: conflict-free.
+// SPLIT (precision = "bf16x6"): both operands as exact 3-term bf16 splits, six products per 16 positions on
+// v_mfma_f32_32x32x16_bf16; a lane supplies eight consecutive positions of its row (two rotated quads) and splits them in
+// registers.  (The waves of a workgroup that share a row tile each split it again: 132 VALU instructions per 12 MFMAs and
+// wave, a little above the matrix time -- still half the exact-f32 MFMA's, which occupies the same VALU.)
+template <int SPLIT>
 __global__ __launch_bounds__(512, 1) void wgrad_dma4_kernel(WgradArgs a) {
     constexpr int PC = 64, TILE = 128 * PC;
     extern __shared__ __attribute__((aligned(16))) float wlds[];   // [2 buffers][dY tile | X tile]
@@ -656,6 +759,38 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma4_kernel(WgradArgs a) {
         // operands of block j + 1 are read while block j's eight MFMAs run (the sched_barriers pin that order): left to
         // itself hipcc reads one operand, waits for it (lgkmcnt(0)) and issues four MFMAs on ONE accumulator, eight registers
         // of operands in all -- every group of four MFMAs then starts with an exposed LDS round trip
+        if constexpr (SPLIT) {
+            f32x4 q0[2], q1[2], qb[2], n0[2], n1[2], nb[2];
+            auto rd16 = [&](int jb, f32x4 (&x0)[2], f32x4 (&x1)[2], f32x4 (&y)[2]) {     // positions 16 jb + 8 lhi + 0..7
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int qa = (4 * jb + 2 * lhi + h + rowA) & 15, qq = (4 * jb + 2 * lhi + h + rowB) & 15;
+                    x0[h] = *reinterpret_cast<const f32x4*>(sdy + rowA * PC + 4 * qa);
+                    x1[h] = *reinterpret_cast<const f32x4*>(sdy + (rowA + 32) * PC + 4 * qa);
+                    y[h] = *reinterpret_cast<const f32x4*>(sx + rowB * PC + 4 * qq);
+                }
+            };
+            rd16(0, q0, q1, qb);
+#pragma unroll
+            for (int jb = 0; jb < PC / 16; ++jb) {
+                if (jb + 1 < PC / 16) rd16(jb + 1, n0, n1, nb);
+                __builtin_amdgcn_sched_barrier(0);
+                bx_bf16x8 f0[3], f1[3], fb[3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    SplitBf16x3::split1(q0[e >> 2][e & 3], f0, e);
+                    SplitBf16x3::split1(q1[e >> 2][e & 3], f1, e);
+                    SplitBf16x3::split1(qb[e >> 2][e & 3], fb, e);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[BX6_IA[t]], fb[BX6_IB[t]], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[BX6_IA[t]], fb[BX6_IB[t]], acc[1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { q0[h] = n0[h]; q1[h] = n1[h]; qb[h] = nb[h]; }
+            }
+        } else {
         f32x4 a0, a1, bv, a0n, a1n, bvn;
         auto rd = [&](int j, f32x4& x0, f32x4& x1, f32x4& y) {
             const int qa = (2 * j + lhi + rowA) & 15, qb = (2 * j + lhi + rowB) & 15;
@@ -675,6 +810,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma4_kernel(WgradArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             a0 = a0n; a1 = a1n; bv = bvn;
+        }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk ch+1 has landed (hipcc does not make a barrier wait for LDS-DMA)
         __syncthreads();                      // ... for every wave, and buffer `buf` is free again
@@ -760,7 +896,7 @@ int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
 }
 
 int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipStream_t s) {
-    ProfileScope ps("wgrad_mfma", s);
+    ProfileScope ps(a_in.split == 1 ? "wgrad_bx6" : "wgrad_mfma", s);
     DWS_CHECK((size_t)a_in.B * std::max(a_in.O, a_in.C) * std::max(a_in.L, a_in.xL) * 4 < ((size_t)1 << 31), DWS_ERR_UNSUPPORTED,
               "wgrad_mfma: operand larger than 2 GiB (B=%d rows=%d L=%d)", a_in.B, std::max(a_in.O, a_in.C), a_in.L);
     WgradArgs a = a_in;
@@ -772,10 +908,12 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
         constexpr int lds = 2 * 2 * 128 * 64 * 4;
         static bool attr4 = false;
         if (!attr4) {
-            DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr4 = true;
         }
-        hipLaunchKernelGGL(wgrad_dma4_kernel, grid, dim3(512), lds, s, a);
+        if (a.split == 1) hipLaunchKernelGGL(wgrad_dma4_kernel<1>, grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL(wgrad_dma4_kernel<0>, grid, dim3(512), lds, s, a);
     } else if (T == 1 && !a.xact && !a.addc && !no_dma) {
         constexpr int lds = 2 * 2 * 128 * 66 * 4;
         static bool attr = false;

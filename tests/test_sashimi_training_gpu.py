@@ -22,7 +22,7 @@ TRAIN_CASES = {
 }
 
 
-def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None, start=0, tries=3):
+def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None, start=0, tries=3, precision="f32", also=()):
     """Engine gradients, the oracle's fp32 autograd and its FLOAT64 autograd (the rounding-noise yardstick of
     tests/gradcheck.py) on the same weights, audio, steps and noise."""
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
@@ -37,10 +37,18 @@ def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None, start=0, trie
     audio, gseed, loss_of, truth, kink, tried = gradcheck.smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed, start=start, tries=tries)
     print(f"inputs: try {tried} (audio seed {aseed + 1000 * tried}), largest kink noise {max(kink.values()):.1e}")
     net = net.to(gpu).train()
-    loss = training_loss(net, nn.MSELoss(), audio.to(gpu), dh, mel_spec=None if mel is None else mel.to(gpu),
-                         generator=torch.Generator().manual_seed(gseed))
-    loss.backward()
-    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+
+    def engine_grads(prec):
+        net.set_option("precision", prec)
+        net.zero_grad(set_to_none=True)
+        loss = training_loss(net, nn.MSELoss(), audio.to(gpu), dh, mel_spec=None if mel is None else mel.to(gpu),
+                             generator=torch.Generator().manual_seed(gseed))
+        loss.backward()
+        return loss, {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+
+    others = {p: engine_grads(p)[1] for p in also}     # the same weights / inputs under other precisions (see the callers)
+    loss, got = engine_grads(precision)
+    net.extra_grads = others
     loss32, o32 = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
     o32 = {k: o32[k] for k in got}
     truth = {k: truth[k] for k in got}
@@ -64,6 +72,32 @@ def test_sashimi_parameter_gradients_match_autograd(gpu, name):
     e64 = gradcheck.errors(got, truth)
     k64 = max(e64, key=e64.get)
     print(f"{name}: worst parameter-gradient rel err vs oracle fp32 {worst:.3e} ({worst_k}); vs float64 {e64[k64]:.3e} ({k64})")
+
+
+def test_sashimi_bf16x6_training_gradients_are_those_of_the_f32_path(gpu):
+    """precision="bf16x6" in training: the pointwise GEMMs of forward_train / backward (`tapconv_mfma_kernel<.., SPLIT>`) and
+    the weight gradients (`wgrad_dma4_kernel<1>`) on the bf16 matrix cores with the exact 3-term split.  BASELINE config 5's
+    channel counts (H = 128 / 256 / 512).  Same rule as the f32 path (tests/gradcheck.py); and against FLOAT64: the worst tensor
+    is no further than 2 x the f32 path's worst, the median tensor within 1.5 x, and a single tensor exceeds 2 x its f32 error
+    only inside 30 % of its 1e-3 bound (the cancelling sums -- log_dt, LayerNorm scalars -- land anywhere inside their
+    rounding noise under ANY change of summation order: 1.8e-4 against 2.5e-5 on one log_dt, 4.1e-4 against 7.1e-4 on the
+    worst one)."""
+    from tests import gradcheck
+    cfg, B = TRAIN_CASES["d128"]
+    net, got, o32, truth, loss, ref_loss, kink = _engine_and_oracle(cfg, B, gpu, 15, 19, 23, start=0, tries=1, precision="bf16x6",
+                                                                    also=("f32",))
+    assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    worst, worst_k = gradcheck.compare(got, o32, truth, label="d128 bf16x6", kink=kink)
+    f32 = net.extra_grads["f32"]
+    e6, e32 = gradcheck.errors(got, truth), gradcheck.errors(f32, truth)
+    assert any(not torch.equal(got[k], f32[k]) for k in got)          # the split kernels really ran
+    bad = {k: (e6[k], e32[k]) for k in e6 if e6[k] > max(2.0 * e32[k], 0.3 * gradcheck.TOL)}
+    k6, k32 = max(e6, key=e6.get), max(e32, key=e32.get)
+    med = sorted(e6[k] / max(e32[k], 1e-12) for k in e6)[len(e6) // 2]
+    print(f"d128: worst gradient error vs float64: bf16x6 {e6[k6]:.3e} ({k6}) | f32 {e32[k32]:.3e} ({k32}); "
+          f"median ratio bf16x6/f32 {med:.2f}")
+    assert not bad, bad
+    assert e6[k6] <= 2.0 * e32[k32] and med <= 1.5
 
 
 def test_sashimi_training_step_reduces_the_loss(gpu):
