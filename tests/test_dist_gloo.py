@@ -168,4 +168,5 @@ def test_gradients_written_into_the_bucket_views_are_adopted_without_a_copy(tmp_
         assert p.returncode == 0, e[-3000:]
         d = json.loads(o.strip().splitlines()[-1])
         assert d["buckets"] >= 2 and d["inside"] and d["ok"] == [True, True, True], d
-        assert all(st == {"in_place": 3, "copied": 0} for st in d["stats"]), d
+        # ("kept": retained gradients of non-leaf tensors stashed over the exchange -- none in this worker)
+        assert all(st == {"in_place": 3, "copied": 0, "kept": 0} for st in d["stats"]), d

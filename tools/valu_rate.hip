@@ -37,6 +37,14 @@ __global__ __launch_bounds__(1024) void probe(float* out, unsigned long long* cy
             if (KIND == 10) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[i]) : "v"(pd), "v"(p[(i + 5) % UNROLL]));
             if (KIND == 11) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(p[(i + 3) % UNROLL]), "v"(p[(i + 7) % UNROLL]));
             if (KIND == 12) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 3) % UNROLL]), "v"(a[(i + 7) % UNROLL]));
+            if (KIND == 14) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 15) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 16) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (KIND == 17) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 18) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a[i]));
+            if (KIND == 19) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == 20) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 21) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(a[i]));
             if (KIND == 13) {   // 7 packed + 1 rcp, the Cauchy backward's mix
                 if (i % 8 == 7) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
                 else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(p[(i + 3) % UNROLL]), "v"(p[(i + 7) % UNROLL]));
@@ -105,5 +113,13 @@ int main() {
     run<6>("v_rcp_f32");
     run<8>("v_mov_b32");
     run<13>("7 v_pk_fma_f32 + 1 v_rcp_f32");
+    run<14>("v_cvt_pk_bf16_f32");
+    run<15>("v_cvt_pk_f16_f32");
+    run<16>("v_perm_b32");
+    run<17>("v_and_b32");
+    run<18>("v_cvt_f32_f16");
+    run<19>("v_cvt_f16_f32");
+    run<20>("v_sub_f32");
+    run<21>("v_lshlrev_b32");
     return 0;
 }
