@@ -133,7 +133,12 @@ int dws_model_update_params(dws_model* m, int32_t count, const char* const* name
  *               = "bf16x6" WaveNet residual layers on the bf16 matrix cores at fp32-EQUIVALENT accuracy: every GEMM
  *                          operand as an exact 3-term bf16 split (24 significand bits), the six partial products above
  *                          2^-26 accumulated in fp32, Winograd F(2,3) form (the f32 path's algorithm and roundings).
- *                          Inference only.  Error against a float64 evaluation: that of the f32 path.
+ *                          WaveNet: inference only.  SaShiMi: the S4 block tails (H <= 128) in sampling; in training the
+ *                          pointwise GEMMs and weight gradients of the step.  Error against a float64 evaluation: that
+ *                          of the f32 path.
+ *               = "f16x3"  the same kernels with a 2-term fp16 split of power-of-two scaled operands (22 significand
+ *                          bits per operand, three products: half the matrix work of bf16x6).  Inference only.  Accepted
+ *                          by the same float64 criterion; activations beyond 2^11 overflow fp16 and yield NaN.
  *   "conv_algo" = "winograd" (default) WaveNet residual layers (precision f32) with the dilated 3-tap convolution in
  *                          Winograd F(2,3) form along the dilation stride: 8 C^2 instead of 12 C^2 flop per position,
  *                          one extra fp32 rounding in the weights and in the inputs (same 1e-6 class error); the

@@ -50,6 +50,10 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline(gpu):
     x6 = d["extra_bf16x6"]
     assert x6["dtype"].startswith("f32-equivalent") and x6["ms_per_step"] > 0 and d["dtype"] == "f32"
     assert abs(x6["roofline"]["peak"] - 2500.0 / 6) < 1e-6 and 0 < x6["roofline"]["frac"] < 1
+    # the 2-term fp16 split leg (precision=f16x3): three products, priced against 2.5 PFLOP/s / 3; never `value` either
+    x3 = d["extra_f16x3"]
+    assert x3["dtype"].startswith("f32-class") and abs(x3["roofline"]["peak"] - 2500.0 / 3) < 1e-6 and 0 < x3["roofline"]["frac"] < 1
+    assert x3["ms_per_step"] < x6["ms_per_step"] < d["ms_per_step"]
     # the whole host beside the best single process: N pinned B = 1 workers
     wh = cb["whole_host"]
     assert "error" not in wh and wh["workers"] >= 1 and wh["cores"] == wh["workers"] * wh["threads_per_worker"] and wh["value"] > 0
@@ -102,6 +106,11 @@ def test_default_headline_line_carries_the_other_baseline_configs(gpu):
     assert abs(c3["value"] - 16 * 16000 / (200 * c3["ms_per_step"] * 1e-3)) < 1e-6 * c3["value"]
     tr = ex["unet_d128_n6_T200 --mode train"]
     assert tr["config"]["batch_per_gpu"] == 32 and "whole_step_frac" in tr["roofline"]
+    # opt-in split legs ride beside the f32 legs, never in their place
+    for name in ("unet_d64_n6_T200", "unet_d32_n6_T50_cond"):
+        assert ex[name]["extra_bf16x6"]["ms_per_step"] > 0 and ex[name]["extra_f16x3"]["ms_per_step"] > 0
+    t6 = tr["extra_bf16x6"]
+    assert t6["dtype"].startswith("f32-equivalent") and t6["ms_per_step"] > 0 and abs(t6["final_loss"] - tr["final_loss"]) < 1e-3
 
 
 @pytest.mark.parametrize("mode", ["sample", "train"])
