@@ -690,8 +690,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
 //    ds_read_b128 services together sit in sixteen different rows, i.e. sixteen different rotations: conflict-free.
 // SPLIT (precision = "bf16x6"): both operands as exact 3-term bf16 splits, six products per 16 positions on
 // v_mfma_f32_32x32x16_bf16; a lane supplies eight consecutive positions of its row (two rotated quads) and splits them in
-// registers.  (The waves of a workgroup that share a row tile each split it again: 132 VALU instructions per 12 MFMAs and
-// wave, a little above the matrix time -- still half the exact-f32 MFMA's, which occupies the same VALU.)
+// registers.  (The waves of a workgroup that share a row tile each split it again: ~165 VALU instructions per 12 MFMAs and
+// wave.  Splitting block j + 1 under block j's MFMAs with sched_group_barrier was built and measured: 270 us against 254 us
+// per launch -- the kernel now moves 1.07 GB per launch at 4.2 TB/s (the X tile is read by both 128-row halves of a 2H
+// output): it is bound by those bytes, no longer by an execution pipe.)
 template <int SPLIT>
 __global__ __launch_bounds__(512, 1) void wgrad_dma4_kernel(WgradArgs a) {
     constexpr int PC = 64, TILE = 128 * PC;
