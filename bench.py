@@ -1000,9 +1000,12 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
                         traffic_fc = ff_.get("hbm_bytes_per_launch", 0) * nblocks if ff_.get("dispatches") else None
                         traffic_note = os.path.basename(tfile)
                     break
+            # the split precisions run every tail GEMM (H = 32 ... 512) on the 16-bit matrix cores: priced against that rate
+            # over the products per fp32-equivalent multiply-add (six / three), like the WaveNet split legs
+            tpeak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3.0}[args.precision]
             result["roofline"] = {
-                "kernel": "s4_tail_mfma_kernel<H,...> (all %d block launches of a step)" % nblocks, "bound": "mfma",
-                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "kernel": "s4_tail kernels (all %d block launches of a step; precision %s)" % (nblocks, args.precision), "bound": "mfma",
+                "achieved": ach, "peak": tpeak, "unit": "TFLOP/s", "frac": ach / tpeak,
                 "traffic": traffic, "traffic_source": traffic_note, "ms_per_step_in_kernel": step_ms, "launches_timed": nprof * nblocks,
                 "algorithmic_flops_per_step": flops, "algorithmic_bytes_per_step": bytes_,
                 "hbm_achieved_GBs": bytes_ / (step_ms * 1e-3) / 1e9,

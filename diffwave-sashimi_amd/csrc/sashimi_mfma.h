@@ -39,7 +39,8 @@ struct S4TailArgs {
     const void* Ao_c6;
     const void* A1_c6;
     const void* A2_c6;
-    int split_c6;                // WN_SPLIT_BF16X6 | WN_SPLIT_F16X3 (wavenet.h): which split the three blobs above hold
+    int split_on;                // precision = bf16x6 / f16x3 requested (H >= 256 runs the LDS-tile kernel's split instances on Ao / A1 / A2)
+    int split_c6;                // WN_SPLIT_BF16X6 | WN_SPLIT_F16X3 (wavenet.h): which split
     const float* wscale_c6;      // f16x3: the power of two each of Wo, W1, W2 was packed with [3]
     unsigned long long* trace;   // nullable (tools only, DWS_TAIL_TRACE=1): s_memtime stamps [workgroup][wave][16] of the
                                  // LDS-tile kernel's phases

@@ -19,6 +19,8 @@
 
 #include "sashimi.h"
 #include "sashimi_mfma.h"
+#include "bf16_split.h"
+#include "wavenet.h"
 
 namespace dws {
 
@@ -90,6 +92,95 @@ __device__ __forceinline__ void gemm_slab(f32x16 (&acc)[MT][NT], const float4* _
 #undef DWS_TAIL_GROUP4
 }
 
+// The same slab on the 16-bit matrix cores (precision = "bf16x6" / "f16x3", H >= 256: bf16_split.h): a k-block of 16 is
+// two fp32 k-groups of the SAME packed A (slot e = 4 g + j of the block is k = 16 kb + 8 g + 2 j + lhi, the order the two
+// float4 fragments already hold per lane), split by the wave that owns the rows; the B operand is read from the fp32 tile
+// in that order (eight ds_read_b32 per column tile) and split in registers -- every wave of the workgroup splits the
+// columns it multiplies.  Scaled splits: B enters times SX, A times ws; the caller multiplies the accumulators back.
+template <typename SP, int MT, int NT, int P>
+__device__ __forceinline__ void gemm_slab_split(f32x16 (&acc)[MT][NT], const float4* __restrict__ A, int nkg_total, int kg0,
+                                                int nkg, const int (&mt)[MT], const float* __restrict__ bt, int wn, int lane,
+                                                float ws) {
+    using v8 = typename SP::v8;
+    constexpr int TN = SP::NT, NPR = SP::NP, D = 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int nkb = nkg / 2;            // nkg is a multiple of 4
+    float4 buf[D][MT][2];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) buf[d][m][g] = A[((size_t)mt[m] * nkg_total + kg0 + 2 * d + g) * 64 + lane];
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; kb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float4 cur[MT][2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { cur[m][0] = buf[d][m][0]; cur[m][1] = buf[d][m][1]; }
+            const int kn = min(kb + d + D, nkb - 1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) buf[d][m][g] = A[((size_t)mt[m] * nkg_total + kg0 + 2 * kn + g) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+            const float* bk = bt + ((kb + d) * 16 + lhi) * P + wn * NT * 32 + l31;
+            v8 bq[NT][TN], af[MT][TN];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = bk[(8 * (e >> 2) + 2 * (e & 3)) * P + n * 32];
+                    SP::split1(SP::SCALED ? v * SP::SX : v, bq[n], e);
+                }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = f4_get(cur[m][e >> 2], e & 3);
+                    SP::split1(SP::SCALED ? v * ws : v, af[m], e);
+                }
+#pragma unroll
+            for (int t = 0; t < NPR; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = SP::mfma(af[m][SP::ia(t)], bq[n][SP::ib(t)], acc[m][n]);
+        }
+    }
+}
+
+// which slab a kernel instance runs: SP = void -> the exact-f32 one
+template <typename SP, int MT, int NT, int P, bool KGU>
+struct SlabRun {
+    static constexpr bool SCALED = SP::SCALED;
+    static constexpr float SX = SP::SX;
+    __device__ static __forceinline__ void run(f32x16 (&acc)[MT][NT], const float4* __restrict__ A, int nkg_total, int kg0, int nkg,
+                                               const int (&mt)[MT], const float* __restrict__ bt, int wn, int lane, float ws) {
+        gemm_slab_split<SP, MT, NT, P>(acc, A, nkg_total, kg0, nkg, mt, bt, wn, lane, ws);
+    }
+};
+template <int MT, int NT, int P, bool KGU>
+struct SlabRun<void, MT, NT, P, KGU> {
+    static constexpr bool SCALED = false;
+    static constexpr float SX = 1.f;
+    __device__ static __forceinline__ void run(f32x16 (&acc)[MT][NT], const float4* __restrict__ A, int nkg_total, int kg0, int nkg,
+                                               const int (&mt)[MT], const float* __restrict__ bt, int wn, int lane, float) {
+        gemm_slab<MT, NT, P, KGU>(acc, A, nkg_total, kg0, nkg, mt, bt, wn, lane);
+    }
+};
+
+template <int MT, int NT>
+__device__ __forceinline__ void acc_scale(f32x16 (&acc)[MT][NT], float f) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] *= f;
+}
+
 // TransposedLN statistics of an [H][P] tile in LDS, down each column (population std, no eps; `sashimi.py:17-20`):
 // the tile is centred in place, colmean[col] = mean, colalpha[col] = s / std.  THREADS = P * PARTS; ends with a barrier.
 template <int H, int P, int PARTS>
@@ -132,8 +223,15 @@ __device__ __forceinline__ void column_stats(float* __restrict__ tile, float* __
 // a row-major float4 pass over the tile in LDS.  In the accumulator layout (a lane owns single positions of 16 rows)
 // the same traffic takes four times the VMEM instructions, and their issue was the larger part of the kernel's
 // non-MFMA time.
-template <int H, int WM, int WN, int NT, int FFE, bool VEC, int OCC, bool KGU>
+// SP: void = exact-f32 MFMA; SplitBf16x3 / SplitF16x2 = the GEMMs on the 16-bit matrix cores (gemm_slab_split).
+template <int H, int WM, int WN, int NT, int FFE, bool VEC, int OCC, bool KGU, typename SP = void>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailArgs a) {
+    using SR = SlabRun<SP, TailCfg<H, WM, WN, NT, FFE>::MT, NT, TailCfg<H, WM, WN, NT, FFE>::P, KGU>;
+    constexpr bool SCALED = SR::SCALED;
+    auto slab = [&](auto& acc, const float4* A, int nkg_total, int kg0, int nkg, const auto& mts, const float* bt, int wn_, int lane_,
+                    float ws) { SR::run(acc, A, nkg_total, kg0, nkg, mts, bt, wn_, lane_, ws); };
+    const float sx = SR::SX;
+    const float wso = SCALED ? a.wscale_c6[0] : 1.f, ws1 = SCALED ? a.wscale_c6[1] : 1.f, ws2 = SCALED ? a.wscale_c6[2] : 1.f;
     using T = TailCfg<H, WM, WN, NT, FFE>;
     constexpr int P = T::P, MT = T::MT, THREADS = T::THREADS, PARTS = T::PARTS;
     // row-major float4 view of an [H][P] tile: F4_ROW float4 per row, ROWS_PASS rows per pass of the workgroup
@@ -242,8 +340,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc_a[m][n][r] = 0.f; acc_b[m][n][r] = 0.f; }
-        gemm_slab<MT, NT, P, KGU>(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane);
-        gemm_slab<MT, NT, P, KGU>(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane);
+        slab(acc_a, Ao, H / 8, 0, H / 8, mt_a, tile, wn, lane, wso);
+        slab(acc_b, Ao, H / 8, 0, H / 8, mt_b, tile, wn, lane, wso);
+        if constexpr (SCALED) {
+            acc_scale(acc_a, 1.f / (wso * sx));
+            acc_scale(acc_b, 1.f / (wso * sx));
+        }
         stamp(2);    // GEMM-o
         __syncthreads();  // every wave is done reading g
         stamp(3);    // barrier
@@ -314,7 +416,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         int mt_q[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) mt_q[m] = q * (H / 32) + mt_h[m];
-        gemm_slab<MT, NT, P, KGU>(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane);
+        slab(acc1, A1, H / 8, 0, H / 8, mt_q, tile, wn, lane, ws1);
+        if constexpr (SCALED) acc_scale(acc1, 1.f / (ws1 * sx));
         stamp(7 + 3 * (q & 1));     // GEMM-1 chunk q  (stamps 7..12 hold the first two chunks)
         if (q > 0) __syncthreads();  // previous chunk of u fully consumed by GEMM-2
 #pragma unroll
@@ -340,9 +443,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void s4_tail_mfma_kernel(S4TailA
         }
         __syncthreads();
         stamp(8 + 3 * (q & 1));     // GELU epilogue + barrier(s)
-        gemm_slab<MT, NT, P, KGU>(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane);
+        slab(acc2, A2, FFE * H / 8, q * (H / 8), H / 8, mt_h, ut, wn, lane, ws2);
         stamp(9 + 3 * (q & 1));     // GEMM-2 partial
     }
+    if constexpr (SCALED) acc_scale(acc2, 1.f / (ws2 * sx));
 
     // ---- out = x1 + f (+ addend);  x1 = centred tile + mean
     if constexpr (VEC) {
@@ -516,6 +620,23 @@ static void tail_trace_launch(int H, int nwg, int waves, S4TailArgs a, hipStream
     fprintf(stderr, " wave life %.0f, workgroup span %.0f\n", span / nw, wgspan / nwg);
 }
 
+// the split instances (H >= 256): the 16-byte tile I/O form only; SP = SplitBf16x3 | SplitF16x2
+template <int H, int WM, int WN, int NT, int OCC, typename SP>
+static int launch_tail_split_t(const S4TailArgs& a, hipStream_t s) {
+    using T = TailCfg<H, WM, WN, NT, 2>;
+    ProfileScope ps(SP::NT == 3 ? "s4_tail_mfma_tile6" : "s4_tail_mfma_tile_f16x3", s);
+    const int ntl = ceil_div(a.L, T::P);
+    const size_t lds = (size_t)T::LDS_FLOATS * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, false, SP>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, false, SP>), dim3(a.B * ntl), dim3(T::THREADS), lds, s, a);
+    return DWS_OK;
+}
+
 template <int H, int WM, int WN, int NT, int OCC, bool KGU>
 static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     using T = TailCfg<H, WM, WN, NT, 2>;
@@ -568,6 +689,16 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
         switch (H) {
             case 32: return launch_tail_t<32, 1, 4, 1, 2, true>(a, s);
             case 64: return launch_tail_t<64, 2, 2, 2, 2, true>(a, s);
+        }
+    }
+    // precision = bf16x6 / f16x3 at H >= 256: the LDS-tile kernel with its GEMMs on the 16-bit matrix cores
+    if (alt == 0 && a.split_on && (a.L & 3) == 0 && getenv("DWS_TAIL_NO_VEC") == nullptr && getenv("DWS_TAIL_NO_SPLIT_TILE") == nullptr) {
+        if (a.split_c6 == WN_SPLIT_F16X3 && a.wscale_c6) {
+            if (H == 256) return launch_tail_split_t<256, 8, 1, 2, 1, SplitF16x2>(a, s);
+            if (H == 512) return launch_tail_split_t<512, 16, 1, 1, 1, SplitF16x2>(a, s);
+        } else if (a.split_c6 == WN_SPLIT_BF16X6) {
+            if (H == 256) return launch_tail_split_t<256, 8, 1, 2, 1, SplitBf16x3>(a, s);
+            if (H == 512) return launch_tail_split_t<512, 16, 1, 1, 1, SplitBf16x3>(a, s);
         }
     }
     switch (H) {

@@ -518,7 +518,7 @@ struct SashimiModel : dws_model {
                     const int split = f16x3 ? WN_SPLIT_F16X3 : WN_SPLIT_BF16X6;
                     const size_t wb = 2 * (size_t)wn_split_terms(split);            // bytes per packed weight
                     float* sc = nullptr;
-                    if (f16x3 && (s4_tail_chain6_supported(H, FF) || s4_tail_wide6_supported(H, FF))) {
+                    if (f16x3) {     // (H >= 256: the LDS-tile kernel's split instances scale the fp32 fragments in registers)
                         DWS_TRY(l->wscale_c6.ensure(3 * 4));
                         sc = l->wscale_c6.f();
                         DWS_TRY(launch_weight_scale(P(l->prefix + ".layer.output_linear.0.weight"), (size_t)2 * H * H,
@@ -791,6 +791,7 @@ struct SashimiModel : dws_model {
             t.addend = addend; t.out = l->out.f(); t.B = nB; t.L = Ls;
             t.Ao_c = l->Ao_c.f(); t.A1_c = l->A1_c.f(); t.A2_c = l->A2_c.f();
             if (split_tails()) {
+                t.split_on = 1;
                 t.Ao_c6 = l->Ao_c6.p; t.A1_c6 = l->A1_c6.p; t.A2_c6 = l->A2_c6.p;
                 t.split_c6 = f16x3 ? WN_SPLIT_F16X3 : WN_SPLIT_BF16X6;
                 t.wscale_c6 = f16x3 ? l->wscale_c6.f() : nullptr;

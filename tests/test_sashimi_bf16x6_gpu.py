@@ -3,6 +3,8 @@
 (`csrc/sashimi_chain6.hip`: H = 32, 64 with the weights resident in LDS, H = 128 one wave per SIMD with the weights
 streamed through an LDS ring).  Same acceptance as the WaveNet layer (tests/test_bf16x6_gpu.py): measured against a
 FLOAT64 evaluation of the oracle graph, the split path's error must stay within 2x the exact-f32 MFMA path's.
+H >= 256 (the bottom stages of ss_unet_d64 / ss_d128_short) runs the LDS-tile kernel `s4_tail_mfma_kernel<..., SP>` with its
+three GEMMs on the same split arithmetic (`csrc/sashimi_mfma.hip`: gemm_slab_split).
 "f16x3" runs the same kernels with the 2-term fp16 split (`csrc/bf16_split.h`: SplitF16x2; activations x 2^4, every weight
 matrix by its own power of two, three products) under the same criterion."""
 import pytest
