@@ -1146,6 +1146,8 @@ struct SashimiModel : dws_model {
 
     int forward_train(const float* audio, const float* steps, float* out, hipStream_t s) override {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "forward before prepare");
+        DWS_CHECK(!f16x3, DWS_ERR_UNSUPPORTED,
+                  "training runs with precision=f32 or bf16x6 (gradients span too many binades for the fixed scales of the fp16 split)");
         keep_cauchy = true;
         if (dirty) DWS_TRY(commit(s));
         DWS_TRY(train_supported());

@@ -100,6 +100,18 @@ def test_sashimi_bf16x6_training_gradients_are_those_of_the_f32_path(gpu):
     assert e6[k6] <= 2.0 * e32[k32] and med <= 1.5
 
 
+def test_sashimi_training_rejects_the_fp16_split(gpu):
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    from diffwave_sashimi_amd.training import training_loss
+    cfg, B = TRAIN_CASES["d32"]
+    net = cases.build_ours(cfg, 16).to(gpu).train()
+    net.set_option("precision", "f16x3")
+    dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
+    audio = (torch.randn(B, 1, cfg["L"], generator=torch.Generator().manual_seed(1)) * 0.3).to(gpu)
+    with pytest.raises(NotImplementedError):
+        training_loss(net, nn.MSELoss(), audio, dh, generator=torch.Generator().manual_seed(3))
+
+
 def test_sashimi_training_step_reduces_the_loss(gpu):
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
     from diffwave_sashimi_amd.training import training_loss
