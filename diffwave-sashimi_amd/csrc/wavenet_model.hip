@@ -410,6 +410,12 @@ struct WaveNetModel : dws_model {
         if (dirty) DWS_TRY(commit(s));
         if (tab_T == T && tab_version == commit_version) return DWS_OK;
         drop_graph();   // a captured step holds pointers into the old table
+        {   // the table grows with T x layers x channels (0.06 GB at T = 200, C = 256; 0.3-0.6 GB at T = 1000): bounded, so that
+            // a wrong T fails with a message instead of an allocation of whatever size it implies
+            const size_t bytes = (size_t)T * ((size_t)NL * C + (mfma_layer ? (size_t)NL * abt_row() : 0) + Ein + Emid + Eout + 1) * 4;
+            DWS_CHECK(T > 0 && bytes <= ((size_t)4 << 30), DWS_ERR_UNSUPPORTED,
+                      "sampler step table: T=%d needs %.2f GB (limit 4 GB): sample with fewer steps or per-step forwards", T, bytes / 1e9);
+        }
         DWS_TRY(tab_steps.ensure((size_t)T * 4));
         DWS_TRY(tab_emb.ensure((size_t)T * Ein * 4));
         DWS_TRY(tab_h1.ensure((size_t)T * Emid * 4));

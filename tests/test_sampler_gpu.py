@@ -65,6 +65,20 @@ def test_philox_noise_is_standard_normal(gpu):
     assert abs(float((x[:, :, 1:] * x[:, :, :-1]).mean())) < 0.01  # lag-1 correlation
 
 
+def test_step_table_size_is_bounded(gpu):
+    """The WaveNet step table is T x (layers x channels + correction rows) floats: a T whose table would pass 4 GB is refused
+    with DWS_ERR_UNSUPPORTED before anything is allocated (four million steps of a 64-channel network here)."""
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
+    cfg, B, L, wseed, _, _ = cases.WAVENET_CASES["wn_c64"]
+    net = cases.build_ours(cfg, wseed).to(gpu)
+    T = 4_000_000
+    dh = calc_diffusion_hyperparams(T, 1e-4, 0.05)
+    with pytest.raises(NotImplementedError, match="step table"):
+        sampling(net, (1, 1, 64), dh, seed=1)
+    dh = calc_diffusion_hyperparams(4, 1e-4, 0.05)
+    assert torch.isfinite(sampling(net, (1, 1, 64), dh, seed=1)).all()      # the model is usable afterwards
+
+
 @pytest.mark.parametrize("backbone", ["wavenet", "sashimi"])
 def test_step_table_sampler_equals_the_per_step_loop(gpu, backbone):
     """The sampler evaluates the step-only part of the network (embedding, MLP, every layer's fc_t, the layer kernels'
