@@ -376,7 +376,11 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
+#ifdef BX6_ABL_A_HOT     // timing ablation only (wrong results): every step re-reads the same fragments -> they come from the CU's L1
+                dst[m][t] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rA1, lane16, ((mt1[m] * NKB * 4) * NT + t) * 1024 + 0 * (kb + j), 0));
+#else
                 dst[m][t] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rA1, lane16, (((mt1[m] * NKB + kb) * 4 + j) * NT + t) * 1024, 0));
+#endif
     };
 
     stage_dma(0);
