@@ -293,11 +293,11 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) % NCB));
 #endif
     auto chunk_of = [&](int cb) { const int c = cb + rot; return c >= NCB ? c - NCB : c; };
-    auto stage_dma = [&](int cbi) {
+    constexpr int NPIECE = RPW / 2;                // staging requests (row pairs) per wave and chunk
+    auto stage_piece = [&](int cbi, int i) {
         float* xs = Xraw + (cbi & 1) * T::RAW_FLOATS;
         const int cb = chunk_of(cbi);
-#pragma unroll
-        for (int i = 0; i < RPW / 2; ++i) {
+        {
             const int cc = 2 * (wave + WAVES * i);
             if (x4) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rXall, xs + cc * 128, 16, voffA, (cb * KC + cc) * L * 4, 0, BX6_NT);
@@ -310,6 +310,10 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
                 }
             }
         }
+    };
+    auto stage_dma = [&](int cbi) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) stage_piece(cbi, i);
     };
 
     // ---- transform pass: raw chunk c1 -> t_j = Winograd input transform, three bf16 terms each, in B-fragment order.
@@ -443,12 +447,25 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         constexpr int sn = (st + PF) % SPC, itn = sn >> 2, jn = sn & 3;
         const int cbn = cb + (st + PF) / SPC;
         const char* tb = Bop + (cb & 1) * T::BOP_BYTES + lhi * (4 * NT * 512) + l31 * 16;
+#if !defined(BX6_ABL_NO_STAGE) && !defined(BX6_STAGE_AT_TOP)
+        // the staging requests of chunk cb + 2 are dealt out over the first SPC - PF steps (one or two per step) instead of
+        // standing together behind the chunk barrier, where both waves of a SIMD issue them into an empty matrix pipe; none
+        // in the last PF steps, so that the chunk-end wait (all but the youngest NAF loads) still covers them
+        if (cb + 2 < NCB) {
+            constexpr int NS = (SPC - PF) < 1 ? 1 : (SPC - PF);
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i)
+                if (i * NS / NPIECE == st) stage_piece(cb + 2, i);
+        }
+#endif
         if (cbn < NCB) load_a1(a_ring[(st + PF) & 3], chunk_of(cbn) * (KC / 16) + itn, jn);   // (no load left in flight behind the last step)
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PF whole steps ahead of its use
         v8 bq[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const v8*>(tb + ((2 * it * 4 + j) * NT + t) * 512);
+#ifndef BX6_ABL_NO_TRANSFORM
         if (with_t) transform(cb + 1);
+#endif
 #pragma unroll
         for (int t = 0; t < NPR; ++t)
 #pragma unroll
@@ -481,15 +498,21 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     };
     static_assert((SPC == 4 || SPC == 8) && PF >= 1 && PF <= 3, "steps per chunk, prefetch distance");
     for (int cb = 0; cb < NCB; ++cb) {
+#if !defined(BX6_ABL_NO_STAGE) && defined(BX6_STAGE_AT_TOP)
         if (cb + 2 < NCB) stage_dma(cb + 2);       // into the raw buffer chunk cb occupied (transformed an iteration ago)
+#endif
         if (cb + 1 < NCB) do_step(cb, std::integral_constant<int, 0>{}, std::true_type{});
         else do_step(cb, std::integral_constant<int, 0>{}, std::false_type{});
         do_steps_from1(cb);
         stamp(8 + 2 * cb);
         // transformed chunk cb+1 visible after the barrier; the LDS-DMA of chunk cb+2 must have landed too (hipcc does not
         // count LDS-DMA among the accesses a barrier waits for): the only younger loads are the NAF A fragments of the next steps
+#ifndef BX6_ABL_NO_DMA_WAIT     // (timing ablations, wrong results: no wait for the staged chunk / no chunk barrier / no staging)
         __builtin_amdgcn_s_waitcnt(0x0F70 | NAF);
+#endif
+#ifndef BX6_ABL_NO_BARRIER
         __syncthreads();
+#endif
         stamp(9 + 2 * cb);
     }
     stamp(2);
