@@ -286,7 +286,8 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     }
     // The K loop visits the channel chunks in an order ROTATED by the tile number: workgroups that run in lockstep on the
     // CUs of an XCD then ask the L2 for different parts of the weight matrices at any moment (every tile streams all of
-    // A1 / A2, 3.75 MB at C = 256, and that stream -- not the MFMAs -- bounds GEMM1)
+    // A1 / A2, 3.75 MB at C = 256; worth 3 k of 77 k GEMM1 cycles.  The stream is NOT what bounds GEMM1: with the fragments
+    // served from L1 (BX6_ABL_A_HOT) GEMM1 moves by 2-3 %, profiles/r05_split_layer_ablations.txt)
 #ifdef BX6_ABL_NO_ROT
     const int rot = 0;
 #else
@@ -447,10 +448,10 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
         constexpr int sn = (st + PF) % SPC, itn = sn >> 2, jn = sn & 3;
         const int cbn = cb + (st + PF) / SPC;
         const char* tb = Bop + (cb & 1) * T::BOP_BYTES + lhi * (4 * NT * 512) + l31 * 16;
-#if !defined(BX6_ABL_NO_STAGE) && !defined(BX6_STAGE_AT_TOP)
-        // the staging requests of chunk cb + 2 are dealt out over the first SPC - PF steps (one or two per step) instead of
-        // standing together behind the chunk barrier, where both waves of a SIMD issue them into an empty matrix pipe; none
-        // in the last PF steps, so that the chunk-end wait (all but the youngest NAF loads) still covers them
+#if !defined(BX6_ABL_NO_STAGE) && defined(BX6_STAGE_SPREAD)
+        // (measured and NOT the default: the staging requests of chunk cb + 2 dealt out over the first SPC - PF steps instead
+        // of standing together behind the chunk barrier -- GEMM1 50.4 k -> 54.5 k cycles (f16x3), 76.0 k -> 83.0 k (bf16x6):
+        // an LDS-DMA request in the MFMA stream holds the wave's issue longer than it costs next to the barrier)
         if (cb + 2 < NCB) {
             constexpr int NS = (SPC - PF) < 1 ? 1 : (SPC - PF);
 #pragma unroll
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     };
     static_assert((SPC == 4 || SPC == 8) && PF >= 1 && PF <= 3, "steps per chunk, prefetch distance");
     for (int cb = 0; cb < NCB; ++cb) {
-#if !defined(BX6_ABL_NO_STAGE) && defined(BX6_STAGE_AT_TOP)
+#if !defined(BX6_ABL_NO_STAGE) && !defined(BX6_STAGE_SPREAD)
         if (cb + 2 < NCB) stage_dma(cb + 2);       // into the raw buffer chunk cb occupied (transformed an iteration ago)
 #endif
         if (cb + 1 < NCB) do_step(cb, std::integral_constant<int, 0>{}, std::true_type{});
