@@ -186,9 +186,10 @@ def smooth_ckpt(path, min_ckpt, max_ckpt):
 @torch.no_grad()
 def generate(rank, diffusion_cfg, model_cfg, dataset_cfg, ckpt_iter="max", n_samples=1, name=None, batch_size=None,
              ckpt_smooth=None, mel_path=None, mel_name=None, dataloader=None, exp_root="exp", seed=None,
-             written=None):
+             written=None, precision=None):
     """``generate.py:58-200``.  ``ckpt_iter`` may additionally be ``"init"``: seeded random weights
-    (no checkpoint), for smoke runs without trained weights."""
+    (no checkpoint), for smoke runs without trained weights.  ``precision`` (not in the reference; CLI:
+    ``+engine.precision=bf16x6|f16x3``): the engine's opt-in matrix arithmetic, see ``include/dws.h``."""
     from .models import construct_model
     from .sampling import calc_diffusion_hyperparams, sampling
     from scipy.io.wavfile import write as wavwrite
@@ -200,6 +201,8 @@ def generate(rank, diffusion_cfg, model_cfg, dataset_cfg, ckpt_iter="max", n_sam
     dh = calc_diffusion_hyperparams(**diffusion_cfg, fast=True)
     model_kwargs = {k: v for k, v in model_cfg.items()}
     net = construct_model(model_kwargs).cuda().eval()
+    if precision not in (None, "f32"):
+        net.set_option("precision", precision)     # NotImplementedError where the engine has no such kernels for this model
 
     ckpt_path = os.path.join(exp_root, local_path, "checkpoint")
     if ckpt_iter == "init":
@@ -262,6 +265,7 @@ def generate(rank, diffusion_cfg, model_cfg, dataset_cfg, ckpt_iter="max", n_sam
 
 def _worker(rank, cfg, exp_root):
     gen = dict(cfg.get("generate", {}))
+    gen.setdefault("precision", (cfg.get("engine") or {}).get("precision"))
     generate(rank, dict(cfg["diffusion"]), dict(cfg["model"]), dict(cfg["dataset"]), exp_root=exp_root, **gen)
 
 

@@ -135,7 +135,7 @@ def dataloader(dataset_cfg, batch_size, num_gpus, unconditional=True, rank=0, nu
 
 
 def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, ckpt_iter, n_iters, iters_per_ckpt,
-          iters_per_logging, learning_rate, batch_size_per_gpu, name=None, exp_root="exp", num_workers=4):
+          iters_per_logging, learning_rate, batch_size_per_gpu, name=None, exp_root="exp", num_workers=4, precision=None):
     """``train.py:49-196``."""
     from .distributed_util import apply_gradient_allreduce, reduce_tensor
     from .models import construct_model
@@ -151,6 +151,8 @@ def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, c
         raise RuntimeError("the dataset holds fewer clips than one batch")
     print("Data loaded")
     net = construct_model(dict(model_cfg)).cuda().train()
+    if precision not in (None, "f32"):      # `+engine.precision=bf16x6`: SaShiMi's GEMMs and weight gradients on the bf16 matrix cores
+        net.set_option("precision", precision)
     print(f"{type(net).__name__} parameters: {sum(p.numel() for p in net.parameters()) / 1e6:.6f}M")   # `utils.py:76-88`
     if num_gpus > 1:
         net = apply_gradient_allreduce(net)
@@ -242,6 +244,7 @@ def distributed_train(rank, num_gpus, group_name, cfg, exp_root="exp"):
         init_distributed(rank, num_gpus, group_name, dist_cfg.get("dist_backend", "nccl"),
                          dist_cfg.get("dist_url", "tcp://127.0.0.1:54321"))
     tr = dict(cfg["train"])
+    tr.setdefault("precision", (cfg.get("engine") or {}).get("precision"))
     train(rank, num_gpus, dict(cfg["diffusion"]), dict(cfg["model"]), dict(cfg["dataset"]), dict(cfg.get("generate") or {}),
           exp_root=exp_root, **tr)
 

@@ -148,6 +148,9 @@ def test_generate_end_to_end_from_a_checkpoint(tmp_path, gpu):
     assert torch.equal(audio, again)                                               # seeded -> reproducible
     with pytest.raises(Exception, match="No valid model found"):
         generate(0, diff, dict(cfg), ds, ckpt_iter=3000, n_samples=2, exp_root=root)
+    # the engine's opt-in arithmetic (`+engine.precision=f16x3` on the command line): another trajectory, the same audio to 1e-4
+    split = generate(1, diff, dict(cfg), ds, ckpt_iter=2000, n_samples=4, batch_size=2, exp_root=root, seed=11, precision="f16x3")
+    assert not torch.equal(split, audio) and float((split - audio).abs().max() / audio.abs().max()) < 1e-4
 
 
 @pytest.mark.gpu
