@@ -98,6 +98,23 @@ def test_sashimi_bf16x6_sampler_graph_equals_the_per_step_loop(gpu, split):
     assert rel_err(a, c) < 1e-4
 
 
+@pytest.mark.parametrize("split", SPLITS)
+def test_sashimi_split_with_stage_lengths_that_are_not_multiples_of_four(gpu, split):
+    """L = 1040 -> stages of 1040 / 260 / 65 positions: the H = 256 stage (65 positions) takes the per-lane tile I/O form, for
+    which no split instance exists (it runs the f32 one), the chain kernels run ragged last tiles; against the CPU oracle."""
+    cfg = cases.ss_cfg(d_model=64, n_layers=1, L=1040)
+    net = cases.build_ours(cfg, 171).to(gpu)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    audio, steps = cases.wavenet_inputs(2, 1040, 1, 172)
+    with torch.no_grad():
+        ref = oss.sashimi_forward(sd, cfg, audio, steps)
+        net.set_option("precision", split)
+        got = net((audio.to(gpu), steps.to(gpu)))
+        net.set_option("precision", "f32")
+        f32 = net((audio.to(gpu), steps.to(gpu)))
+    assert rel_err(got, ref) < REL_TOL / 10 and rel_err(got, f32) < 5e-6 and not torch.equal(got, f32)
+
+
 def test_sashimi_rejects_unknown_precision(gpu):
     net = cases.build_ours(cases.SASHIMI_CASES["ss_tiny"][0], 1).to(gpu)
     with pytest.raises(NotImplementedError):
