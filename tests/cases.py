@@ -119,3 +119,14 @@ def summarize(t, stride=16, edge=256):
     return dict(first=t.detach().flatten()[:edge].clone(), last=t.detach().flatten()[-edge:].clone(),
                 strided=t.detach().flatten()[::stride].clone(),
                 sum=f.sum().reshape(1), sumsq=(f * f).sum().reshape(1), absmax=f.abs().max().reshape(1))
+
+
+# Results of expensive CPU-oracle evaluations shared between test modules of one pytest session (the float64 forward of a
+# seeded case is the yardstick of several precision tests): key -> value, computed once.
+_SESSION_CACHE = {}
+
+
+def cached(key, make):
+    if key not in _SESSION_CACHE:
+        _SESSION_CACHE[key] = make()
+    return _SESSION_CACHE[key]

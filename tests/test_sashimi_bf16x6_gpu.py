@@ -34,7 +34,7 @@ def test_sashimi_bf16x6_error_against_float64_is_that_of_the_f32_path(gpu, name,
     L = cfg["L"]
     net = cases.build_ours(cfg, wseed).to(gpu)
     audio, steps = cases.wavenet_inputs(B, L, cfg["in_channels"], iseed)
-    ref, ref_pre = _f64(net, cfg, audio, steps)
+    ref, ref_pre = cases.cached(("sashimi_f64", name), lambda: _f64(net, cfg, audio, steps))     # once for both splits
     out = {}
     with torch.no_grad():
         for prec in ("f32", split):

@@ -34,7 +34,10 @@ def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None, start=0, trie
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
     # inputs away from every ReLU kink (tests/gradcheck.py: smooth_case), so that the plain 1e-3 bound applies
-    audio, gseed, loss_of, truth, kink, tried = gradcheck.smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed, start=start, tries=tries)
+    # (the oracle side of a seeded case -- input search, float64 and fp32 autograd -- is shared by the tests that use it)
+    okey = None if mel is not None else ("sashimi_train_oracle", repr(sorted(cfg.items())), B, wseed, aseed, gseed, start, tries)
+    make = lambda: gradcheck.smooth_case(cfg, sd, dh, B, L, mel, aseed, gseed, start=start, tries=tries)
+    audio, gseed, loss_of, truth, kink, tried = make() if okey is None else cases.cached(okey, make)
     print(f"inputs: try {tried} (audio seed {aseed + 1000 * tried}), largest kink noise {max(kink.values()):.1e}")
     net = net.to(gpu).train()
 
@@ -49,7 +52,8 @@ def _engine_and_oracle(cfg, B, gpu, wseed, aseed, gseed, mel=None, start=0, trie
     others = {p: engine_grads(p)[1] for p in also}     # the same weights / inputs under other precisions (see the callers)
     loss, got = engine_grads(precision)
     net.extra_grads = others
-    loss32, o32 = gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
+    make32 = lambda: gradcheck.oracle_grads(cfg, sd, loss_of, torch.float32)
+    loss32, o32 = make32() if okey is None else cases.cached(okey + ("fp32",), make32)
     o32 = {k: o32[k] for k in got}
     truth = {k: truth[k] for k in got}
     for k, gk in got.items():
