@@ -291,7 +291,10 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
 #ifdef BX6_ABL_NO_ROT
     const int rot = 0;
 #else
-    const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) % NCB));
+    // Keyed by the tile's number INSIDE its clip (consecutive workgroups of an XCD run consecutive tiles: xcd_remap), never by
+    // the batch index: the summation order of a position must not depend on where its clip sits in the batch
+    // (tests/test_full_size_gpu.py: equal clips give equal bits, a clip alone == the clip inside a batch of 16).
+    const int rot = __builtin_amdgcn_readfirstlane((int)((unsigned)(q0 >> 5) % NCB));
 #endif
     auto chunk_of = [&](int cb) { const int c = cb + rot; return c >= NCB ? c - NCB : c; };
     constexpr int NPIECE = RPW / 2;                // staging requests (row pairs) per wave and chunk

@@ -104,6 +104,10 @@ class EngineModule(nn.Module):
     def set_option(self, key, value):
         """Engine option, e.g. ``set_option("precision", "bf16x3")`` (see dws_model_set_option)."""
         _lib.check(_lib.load().dws_model_set_option(self._ensure_handle(), key.encode(), str(value).encode()))
+        # an option marks the engine dirty: its next commit re-packs the weights and DROPS the installed conditioner
+        # terms, so the cached mel must be handed over again even if it is the very same tensor object
+        self._mel_key = None
+        self._mel_ref = None
         return self
 
     def invalidate(self):

@@ -46,18 +46,25 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline(gpu):
     fl = d["full_loop"]
     assert fl["T"] == 200 and fl["finite"] and abs(fl["ms_per_step"] - fl["ms"] / 200) < 1e-9
     assert 0.9 < fl["ratio_to_timed_ms_per_step"] < 1.15, fl
-    # the fp32-equivalent split leg (precision=bf16x6): its own dtype string and roofline against 2.5 PFLOP/s / 6; never `value`
-    x6 = d["extra_bf16x6"]
-    assert x6["dtype"].startswith("f32-equivalent") and x6["ms_per_step"] > 0 and d["dtype"] == "f32"
-    assert abs(x6["roofline"]["peak"] - 2500.0 / 6) < 1e-6 and 0 < x6["roofline"]["frac"] < 1
-    # the 2-term fp16 split leg (precision=f16x3): three products, priced against 2.5 PFLOP/s / 3; never `value` either
-    x3 = d["extra_f16x3"]
-    assert x3["dtype"].startswith("f32-class") and abs(x3["roofline"]["peak"] - 2500.0 / 3) < 1e-6 and 0 < x3["roofline"]["frac"] < 1
-    assert x3["ms_per_step"] < x6["ms_per_step"] < d["ms_per_step"]
-    # the whole host beside the best single process: N pinned B = 1 workers
+    # the headline arithmetic is the fp32-equivalent split (precision=bf16x6): its own dtype string, roofline against
+    # 2.5 PFLOP/s / 6; the exact-f32 leg rides beside it with its own roofline against the fp32 MFMA rate, never as `value`
+    assert d["dtype"].startswith("f32-equivalent") and d["state_finite"]
+    assert abs(rf["peak"] - 2500.0 / 6) < 1e-6 and rf["kernel"].startswith("wn_layer_bx6_kernel<SplitBf16x3")
+    x32 = d["extra_f32_exact"]
+    assert x32["dtype"] == "f32" and x32["state_finite"] and abs(x32["roofline"]["peak"] - 157.3) < 1e-6
+    assert 0 < x32["roofline"]["frac"] < 1 and x32["roofline"]["kernel"].startswith("wn_layer_wino_kernel")
+    assert d["ms_per_step"] < x32["ms_per_step"]
+    assert "extra_f16x3" not in d and "extra_bf16x3" not in d          # the narrower splits are not advertised in the line
+    # the whole host beside the best single process: N pinned B = 1 workers, sized to the container's
+    # CPU quota; GPU/CPU is computed from the better of the two
     wh = cb["whole_host"]
     assert "error" not in wh and wh["workers"] >= 1 and wh["cores"] == wh["workers"] * wh["threads_per_worker"] and wh["value"] > 0
-    assert abs(d["gpu_over_cpu_whole_host"] - d["value"] / wh["value"]) < 1e-6 * d["gpu_over_cpu_whole_host"]
+    assert "cpu_quota_cpus" in cb and cb["cpu_quota_source"]
+    if cb["cpu_quota_cpus"] is not None:
+        assert wh["cores"] <= max(cb["cpu_quota_cpus"], wh["threads_per_worker"])
+    assert cb["best"]["value"] == max(cb["single_process_value"], wh["value"])
+    assert abs(d["gpu_over_cpu"] - d["value"] / cb["best"]["value"]) < 1e-6 * d["gpu_over_cpu"]
+    assert "gpu_over_cpu_whole_host" not in d
 
 
 def test_two_ranks_aggregate(gpu):
@@ -82,7 +89,7 @@ def test_default_headline_line_carries_the_other_baseline_configs(gpu):
                        capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert REQUIRED <= set(d) and d["config"]["workload"] == "wnet_h256_d36_T200" and d["dtype"] == "f32"
+    assert REQUIRED <= set(d) and d["config"]["workload"] == "wnet_h256_d36_T200" and d["dtype"].startswith("f32-equivalent")
     rf = d["roofline"]
     assert 0 < rf["frac"] < 1 and rf["executed_flops_per_launch"] < rf["algorithmic_flops_per_launch"]
     assert abs(rf["achieved"] - rf["executed_flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * rf["achieved"]
@@ -91,7 +98,8 @@ def test_default_headline_line_carries_the_other_baseline_configs(gpu):
     ops = {"unet_d128_n6_T200 B=128 (README operating point)", "unet_d64_n6_T200 B=256 (README operating point)"}
     assert set(ex) == {"unet_d64_n6_T200", "unet_d32_n6_T50_cond", "unet_d128_n6_T200 --mode train"} | ops
     for name, leg in ex.items():
-        assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["dtype"] == "f32", (name, leg)
+        want = "f32" if name.endswith("--mode train") else "f32-equivalent"      # (the training leg's value is the exact-f32 step)
+        assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["dtype"].startswith(want), (name, leg)
         if name not in ops:
             assert leg["roofline"]["bound"] == "mfma" and 0 < leg["roofline"]["frac"] < 1, name
     for name in ops:     # the reference's documented batch sizes: 8x / 16x the tested batch through the same 32-bit offsets
@@ -106,11 +114,22 @@ def test_default_headline_line_carries_the_other_baseline_configs(gpu):
     assert abs(c3["value"] - 16 * 16000 / (200 * c3["ms_per_step"] * 1e-3)) < 1e-6 * c3["value"]
     tr = ex["unet_d128_n6_T200 --mode train"]
     assert tr["config"]["batch_per_gpu"] == 32 and "whole_step_frac" in tr["roofline"]
-    # opt-in split legs ride beside the f32 legs, never in their place
+    # the exact-f32 legs ride beside the split ones, each with its own roofline
     for name in ("unet_d64_n6_T200", "unet_d32_n6_T50_cond"):
-        assert ex[name]["extra_bf16x6"]["ms_per_step"] > 0 and ex[name]["extra_f16x3"]["ms_per_step"] > 0
+        x32 = ex[name]["extra_f32_exact"]
+        assert x32["ms_per_step"] > 0 and x32["dtype"] == "f32" and x32["state_finite"] and ex[name]["state_finite"]
+        assert abs(x32["roofline"]["peak"] - 157.3) < 1e-6 and abs(ex[name]["roofline"]["peak"] - 2500.0 / 6) < 1e-6
+        # tail bytes: four tensor transits per block (g, x, out, ynext), the convolution in front of it two
+        rf3 = ex[name]["roofline"]
+        assert rf3["fftconv"]["algorithmic_bytes_per_step"] * 2 == rf3["algorithmic_bytes_per_step"]
     t6 = tr["extra_bf16x6"]
     assert t6["dtype"].startswith("f32-equivalent") and t6["ms_per_step"] > 0 and abs(t6["final_loss"] - tr["final_loss"]) < 1e-3
+    assert d["extra_f32_exact"]["ms_per_step"] > d["ms_per_step"] and d["extra_f32_exact"]["state_finite"]
+    # the LAST key of the line is a compact digest of every config's number (the driver keeps only a tail of the line)
+    assert list(d)[-1] == "summary" and len(json.dumps(d["summary"])) <= 1500, len(json.dumps(d["summary"]))
+    sm = d["summary"]
+    assert abs(sm["C2 wnet_h256_d36 B16"]["ms"] - d["ms_per_step"]) < 1e-3 * d["ms_per_step"]
+    assert sm["C3 unet_d64 B16"]["f32_ms"] > 0 and sm["C4 unet_d32 cond B32"]["ms"] > 0 and sm["C5 unet_d128 train B32/GPU"]["f32_ms"] > 0
 
 
 @pytest.mark.parametrize("mode", ["sample", "train"])

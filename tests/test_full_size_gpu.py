@@ -21,13 +21,29 @@ def _inputs(B, L, seed):
     return audio, steps
 
 
+def _f64_one_clip(cfg, net, audio, steps, mel=None):
+    """float64 evaluation of the oracle graph on ONE clip of the config at its full length: the yardstick both GPU
+    arithmetics (exact-f32 MFMA, 3-term bf16 split) are measured against."""
+    sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        if cfg["model"]["_name_"] == "wavenet":
+            return own.wavenet_forward(sd64, cfg["model"], audio.double(), steps)
+        return osa.sashimi_forward(sd64, cfg["model"], audio.double(), steps, mel_spec=None if mel is None else mel.double())
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
 @pytest.mark.parametrize("config", ["wnet_h256_d36_T200", "unet_d64_n6_T200"])
-def test_config_at_full_size(gpu, config):
+def test_config_at_full_size(gpu, config, precision):
+    """BASELINE configs 2 and 3 at B = 16, L = 16000, under the exact-f32 path and under the fp32-equivalent 3-term bf16
+    split the bench also times at this size (`precision="bf16x6"`): bitwise batch independence / determinism, one clip
+    against the fp32 oracle at the full length, and -- for the split -- that clip's error against a float64 evaluation
+    within 2x the exact-f32 path's."""
     cfg = bench.CONFIGS[config]
     B, L = cfg["B"], cfg["L"]
     assert (B, L) == (16, 16000)
     torch.manual_seed(3)
     net = cases.build_ours(dict(cfg["model"]), 91).to(gpu)
+    net.set_option("precision", precision)
     audio, steps = _inputs(B, L, 92)
     with torch.no_grad():
         full = net((audio.to(gpu), steps.to(gpu)))
@@ -38,23 +54,38 @@ def test_config_at_full_size(gpu, config):
     assert torch.equal(full[2], full[7])                         # equal clips -> equal results, wherever they sit
     assert torch.equal(full[3:4], one)                           # independent of the batch neighbours, bitwise
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    with torch.no_grad():
-        if cfg["model"]["_name_"] == "wavenet":
-            ref = own.wavenet_forward(sd, cfg["model"], audio[3:4], steps[3:4])
-        else:
-            ref = osa.sashimi_forward(sd, cfg["model"], audio[3:4], steps[3:4])
+
+    def oracle32():
+        with torch.no_grad():
+            if cfg["model"]["_name_"] == "wavenet":
+                return own.wavenet_forward(sd, cfg["model"], audio[3:4], steps[3:4])
+            return osa.sashimi_forward(sd, cfg["model"], audio[3:4], steps[3:4])
+    ref = cases.cached(("full_size_f32", config), oracle32)       # same seeds under both precisions
     assert rel_err(one.cpu(), ref) < REL_TOL
+    if precision != "f32":
+        ref64 = cases.cached(("full_size_f64", config), lambda: _f64_one_clip(cfg, net, audio[3:4], steps[3:4]))
+        with torch.no_grad():
+            net.set_option("precision", "f32")
+            one32 = net((audio[3:4].to(gpu), steps[3:4].to(gpu)))
+        e_split, e_f32 = rel_err(one.cpu(), ref64), rel_err(one32.cpu(), ref64)
+        print(f"{config} clip 3 at L={L}: max-rel error vs float64 f32-MFMA {e_f32:.3e} | {precision} {e_split:.3e}; "
+              f"the two GPU paths directly {rel_err(one, one32):.3e}")
+        assert not torch.equal(one, one32)                       # the split path really ran
+        assert e_split <= 2.0 * e_f32, (e_split, e_f32)
 
 
-def test_config4_at_full_size(gpu):
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+def test_config4_at_full_size(gpu, precision):
     """BASELINE config 4 at its workload: unet_d32_n6 mel-conditional, B = 32, L = 16000, mel [32, 80, 63].  Batch
     independence / determinism (bitwise), a mel row conditions only its own clip, a batch-1 mel broadcasts
-    (`generate.py:140,155`), one clip against the CPU oracle at the full length, and the T = 50 graph sampler."""
+    (`generate.py:140,155`), one clip against the CPU oracle at the full length, and the T = 50 graph sampler -- under the
+    exact-f32 tails and under the 3-term bf16 split (then also: error against float64 within 2x the f32 path's)."""
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
     cfg = bench.CONFIGS["unet_d32_n6_T50_cond"]
     B, L, Tmel = cfg["B"], cfg["L"], cfg["Tmel"]
     assert (B, L, Tmel) == (32, 16000, 63)
     net = cases.build_ours(dict(cfg["model"]), 95).to(gpu)
+    net.set_option("precision", precision)
     audio, steps = _inputs(B, L, 96)
     steps = steps.clamp(max=49.0)
     mel = torch.cat([cases.mel_inputs(1, Tmel, 300 + i) for i in range(B)])
@@ -73,19 +104,34 @@ def test_config4_at_full_size(gpu):
     keep = [i for i in range(B) if i != 5]
     assert torch.equal(changed[keep], full[keep]) and not torch.equal(changed[5], full[5])
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    with torch.no_grad():
-        ref = osa.sashimi_forward(sd, cfg["model"], audio[3:4], steps[3:4], mel_spec=mel[3:4])
+
+    def oracle32():
+        with torch.no_grad():
+            return osa.sashimi_forward(sd, cfg["model"], audio[3:4], steps[3:4], mel_spec=mel[3:4])
+    ref = cases.cached(("full_size_f32", "c4"), oracle32)
     assert rel_err(one.cpu(), ref) < REL_TOL
+    if precision != "f32":
+        ref64 = cases.cached(("full_size_f64", "c4"), lambda: _f64_one_clip(cfg, net, audio[3:4], steps[3:4], mel[3:4]))
+        with torch.no_grad():
+            net.set_option("precision", "f32")
+            one32 = net((audio[3:4].to(gpu), steps[3:4].to(gpu)), mel_spec=mel[3:4].to(gpu))
+            net.set_option("precision", precision)
+        e_split, e_f32 = rel_err(one.cpu(), ref64), rel_err(one32.cpu(), ref64)
+        print(f"config 4 clip 3: max-rel error vs float64 f32-MFMA {e_f32:.3e} | {precision} {e_split:.3e}; "
+              f"the two GPU paths directly {rel_err(one, one32):.3e}")
+        assert not torch.equal(one, one32) and e_split <= 2.0 * e_f32, (e_split, e_f32)
     dh = calc_diffusion_hyperparams(**cfg["diffusion"])
     a = sampling(net, (B, 1, L), dh, condition=mel.to(gpu), seed=5, use_graph=True)
     b = sampling(net, (B, 1, L), dh, condition=mel.to(gpu), seed=5, use_graph=True)
     assert torch.equal(a, b) and torch.isfinite(a).all() and torch.equal(a[2], a[2]) and not torch.equal(a[2], a[3])
 
 
-def test_sampler_at_full_size_is_deterministic(gpu):
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+def test_sampler_at_full_size_is_deterministic(gpu, precision):
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams, sampling
     cfg = bench.CONFIGS["wnet_h256_d36_T200"]
     net = cases.build_ours(dict(cfg["model"]), 93).to(gpu)
+    net.set_option("precision", precision)
     dh = calc_diffusion_hyperparams(3, 1e-4, 0.05)
     a = sampling(net, (16, 1, 16000), dh, seed=5, use_graph=True)
     b = sampling(net, (16, 1, 16000), dh, seed=5, use_graph=False)

@@ -90,8 +90,10 @@ def test_embedding_mlp_and_fc_t_rows_match_the_oracle(gpu, backbone):
     print(f"{backbone}: emb_mlp rel err {rel_err(got, ref):.2e}; {found} fc_t rows located in part_t")
 
 
-def test_transposed_layernorm_on_the_reference_fixture(gpu):
-    """ln/x [2, 6, 40] -> HIP LayerNorm -> ln/y.  The fixture enters as a 6-channel "audio" through an identity init
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+def test_transposed_layernorm_on_the_reference_fixture(gpu, precision):
+    """(Under `precision="bf16x6"` too: whatever arithmetic the option selects for the block around it, the LayerNorm the
+    fixture goes through must stay the fixture's.)  ln/x [2, 6, 40] -> HIP LayerNorm -> ln/y.  The fixture enters as a 6-channel "audio" through an identity init
     conv scaled by 1/2; its bias shifts the tensor above the ReLU (LayerNorm is shift-invariant down the channel column),
     the only block is switched off (output_linear = 0, ff.2 = 0: it returns its input, and `sashimi.py:301` adds the
     input once more: 2 (x/2 + 8) = x + 16), and `norm` carries the fixture's (m, s)."""
@@ -100,6 +102,7 @@ def test_transposed_layernorm_on_the_reference_fixture(gpu):
     B, H, L = x.shape
     cfg = cases.ss_cfg(d_model=H, in_channels=H, n_layers=1, L=L, pool=[], unet=False, diffusion_step_embed_dim_mid=64)
     net = cases.build_ours(cfg, 5).to(gpu)
+    net.set_option("precision", precision)
     sd = net.state_dict()
     shift = 16.0
     assert float(x.min()) > -shift
@@ -124,14 +127,18 @@ def test_transposed_layernorm_on_the_reference_fixture(gpu):
     assert rel_err(got, oss.transposed_ln(x + shift, torch.tensor(float(m)), torch.tensor(float(s)))) < 2e-6
 
 
-@pytest.mark.parametrize("H", [8, 32, 64, 128])
-def test_ff_branch_matches_the_oracle(gpu, H):
-    """out = x1 + FF(LN2(x1)) (`sashimi.py:179-184`) with the S4 branch off (x1 = x), plus the input once more
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+@pytest.mark.parametrize("H", [8, 32, 64, 128, 256])
+def test_ff_branch_matches_the_oracle(gpu, H, precision):
+    """(`precision="bf16x6"`: the same FF through the split tails -- `s4_tail_chain6_kernel` at H = 32 / 64,
+    `s4_tail_wide6_kernel` at 128, `gemm_slab_split` at 256; H = 8 has no split instance and stays on the generic kernel.)
+    out = x1 + FF(LN2(x1)) (`sashimi.py:179-184`) with the S4 branch off (x1 = x), plus the input once more
     (`sashimi.py:301`, fused into the tail): out - 2x is FF(LN2(x)) as the HIP tail computes it -- generic kernels
     (H = 8), the register-chained tail (32, 64), the LDS-tile tail (128)."""
     L, B = 512, 2
     cfg = cases.ss_cfg(d_model=H, n_layers=1, L=L, pool=[], unet=False, diffusion_step_embed_dim_mid=64)
     net = cases.build_ours(cfg, 41 + H).to(gpu)
+    net.set_option("precision", precision)
     sd = net.state_dict()
     with torch.no_grad():
         sd["c_layers.0.layer.output_linear.0.weight"].zero_()
@@ -147,5 +154,5 @@ def test_ff_branch_matches_the_oracle(gpu, H):
         ref = oss.ff(sdc, "c_layers.0.ff", oss.transposed_ln(x, sdc["c_layers.0.norm2.m"], sdc["c_layers.0.norm2.s"]))
     got = out - 2 * x
     err = rel_err(got, ref)
-    print(f"H={H}: FF branch rel err {err:.2e} (|FF| max {float(ref.abs().max()):.3f}, |x| max {float(x.abs().max()):.3f})")
+    print(f"H={H} {precision}: FF branch rel err {err:.2e} (|FF| max {float(ref.abs().max()):.3f}, |x| max {float(x.abs().max()):.3f})")
     assert err < 2e-5, err
