@@ -218,7 +218,17 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     const int ntl = ((nblk << log2d) + 31) >> 5;           // tiles of 32 pairs per batch element
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
-    const int q0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
+    // Order of the tiles inside a clip.  A tile reads its own 2 x 32 positions AND two halos of 32 (shifts -d and +2d): the
+    // second half of the previous block of 2d and the first half of the next one -- the main columns of the tiles d/32 tile
+    // numbers away.  d >= 64: the BLOCK index runs fastest (tile t -> block t % nblk, 32-pair slice t / nblk), so that the tiles
+    // that share columns are neighbours in launch order = run at the same time on CUs of one XCD and meet in its L2 (4 MB:
+    // one round of 32 tiles already moves 6 MB through it); linear order left every x element to be fetched twice.
+    const int tic = tile % ntl;                             // tile number inside the clip
+#ifdef WN_TILE_ORDER_LINEAR
+    const int q0 = __builtin_amdgcn_readfirstlane(tic * 32);
+#else
+    const int q0 = __builtin_amdgcn_readfirstlane(log2d >= 6 ? ((tic % nblk) << log2d) + (tic / nblk) * 32 : tic * 32);
+#endif
     const int q = q0 + l31;                                // first-half position number of this lane's column
     const int p = ((q >> log2d) << (log2d + 1)) + (q & (dil - 1));
 
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(C * 2, (C >= 128 ? 2 : 1)) void wn_layer_bx6_kernel
     // Keyed by the tile's number INSIDE its clip (consecutive workgroups of an XCD run consecutive tiles: xcd_remap), never by
     // the batch index: the summation order of a position must not depend on where its clip sits in the batch
     // (tests/test_full_size_gpu.py: equal clips give equal bits, a clip alone == the clip inside a batch of 16).
-    const int rot = __builtin_amdgcn_readfirstlane((int)((unsigned)(q0 >> 5) % NCB));
+    const int rot = __builtin_amdgcn_readfirstlane((int)((unsigned)tic % NCB));
 #endif
     auto chunk_of = [&](int cb) { const int c = cb + rot; return c >= NCB ? c - NCB : c; };
     constexpr int NPIECE = RPW / 2;                // staging requests (row pairs) per wave and chunk

@@ -168,7 +168,17 @@ __global__ __launch_bounds__(C * 2, 2) void wn_layer_wino_kernel(WnLayerArgs a, 
     // per C2 step; the loop costs 26 spilled registers and the extra barrier exposes the skew between the two waves of a SIMD.)
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int b = __builtin_amdgcn_readfirstlane(tile / ntl);
-    const int q0 = __builtin_amdgcn_readfirstlane((tile % ntl) * 32);
+    // Order of the tiles inside a clip.  A tile reads its own 2 x 32 positions AND two halos of 32 (shifts -d and +2d): the
+    // second half of the previous block of 2d and the first half of the next one -- the main columns of the tiles d/32 tile
+    // numbers away.  d >= 64: the BLOCK index runs fastest (tile t -> block t % nblk, 32-pair slice t / nblk), so that the tiles
+    // that share columns are neighbours in launch order = run at the same time on CUs of one XCD and meet in its L2 (4 MB:
+    // one round of 32 tiles already moves 6 MB through it); linear order left every x element to be fetched twice.
+    const int tic = tile % ntl;                             // tile number inside the clip
+#ifdef WN_TILE_ORDER_LINEAR
+    const int q0 = __builtin_amdgcn_readfirstlane(tic * 32);
+#else
+    const int q0 = __builtin_amdgcn_readfirstlane(log2d >= 6 ? ((tic % nblk) << log2d) + (tic / nblk) * 32 : tic * 32);
+#endif
     // first-half position of this lane's column
     const int q = q0 + l31;
     const int p = ((q >> log2d) << (log2d + 1)) + (q & (dil - 1));
