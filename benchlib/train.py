@@ -60,8 +60,9 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
     if world > 1:      # the exchange as the last timed step saw it, per rank: first bucket launch -> last wait()
         red = net._dws_grad_reducer
         dp_overhead = {"allreduce_ms_per_rank": ddist.gather_over_ranks(float(red.allreduce_ms() or 0.0), red_dev),
+                       "exposed_ms_per_rank": ddist.gather_over_ranks(float(red.exposed_ms() or 0.0), red_dev),
                        "buckets": len(red.buckets), "bucket_mbytes": [b.flat.numel() * 4 / 2 ** 20 for b in red.buckets],
-                       "gradient_slots": red.last_stats}
+                       "bucket_ready": red.bucket_ready_points(), "gradient_slots": red.last_stats}
     if world == 1 and not ddist.dist.is_initialized() and os.environ.get("DWS_BENCH_NO_DP_OVERHEAD") is None:
         # What data parallelism adds to ONE rank's step besides the wire time: the same steps inside a 1-rank RCCL group
         # (apply_gradient_allreduce: gradients written into the flat buckets, hooks, bucketed asynchronous all-reduces,
@@ -85,7 +86,9 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
                            "buckets": len(red.buckets), "bucket_mbytes": [b.flat.numel() * 4 / 2 ** 20 for b in red.buckets],
                            "gradient_slots": red.last_stats,
                            # first bucket launch -> last wait() of the last step (HIP events on the gradients' stream)
-                           "allreduce_ms": red.allreduce_ms()}
+                           "allreduce_ms": red.allreduce_ms(),
+                           # end of backward (its last kernel) -> last wait(): what the step could not hide behind backward
+                           "exposed_ms": red.exposed_ms(), "bucket_ready": red.bucket_ready_points()}
             red.remove()
             del net._dws_grad_reducer
         except Exception as e:      # noqa: BLE001 -- reported in the line

@@ -64,6 +64,12 @@ _SIGS = {
     "dws_model_get_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_f32p, ctypes.c_int64, ctypes.c_void_p]),
     "dws_model_get_grads": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p),
                                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
+    "dws_model_set_grad_sinks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p),
+                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                                                ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
+    "dws_model_grad_group_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "dws_model_grad_ready_seq": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p),
+                                                ctypes.POINTER(ctypes.c_int32)]),
     "dws_model_read_tap": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_f32p, ctypes.c_int64, ctypes.c_void_p]),
     "dws_sampler_run": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.POINTER(ctypes.c_float),
                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),

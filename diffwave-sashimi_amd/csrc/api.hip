@@ -19,6 +19,8 @@ dws_model::~dws_model() {
         if (copy_consumed[i]) (void)hipEventDestroy(copy_consumed[i]);
         if (copy_pinned[i]) (void)hipHostFree(copy_pinned[i]);
     }
+    for (auto& g : grad_groups)
+        if (g.ev) (void)hipEventDestroy(g.ev);
     for (auto* p : params) delete p;
 }
 
@@ -53,7 +55,98 @@ float* dws_model::G(const std::string& name) {
         if (p->grad.ensure(p->nbytes()) != DWS_OK) return nullptr;
         hipMemset(p->grad.p, 0, p->nbytes());
     }
+    if (in_backward && !grad_touch.empty()) {      // staged hand-over: this gradient is (still) being produced at flush point grad_seq
+        grad_touch[it->second] = grad_seq;
+        const int g = grad_group_of[it->second];
+        if (g >= 0 && grad_groups[g].flushed) grad_groups[g].touched_after_flush = true;
+    }
     return p->grad.f();
+}
+
+int dws_model::set_grad_sinks(int32_t count, const char* const* names, float* const* dsts, const int64_t* numels,
+                              const int32_t* groups, int32_t ngroups) {
+    for (auto& g : grad_groups)
+        if (g.ev) (void)hipEventDestroy(g.ev);
+    grad_groups.clear();
+    grad_group_of.assign(params.size(), -1);
+    grad_sink.assign(params.size(), nullptr);
+    grad_touch.assign(params.size(), -1);
+    grad_touch_prev.clear();
+    grad_order_known = false;
+    if (count == 0) { grad_touch.clear(); return DWS_OK; }
+    grad_groups.resize((size_t)ngroups);
+    for (int i = 0; i < count; ++i) {
+        auto it = index.find(names[i]);
+        DWS_CHECK(it != index.end(), DWS_ERR_INVALID, "unknown parameter '%s'", names[i]);
+        dws::ParamSpec* p = params[it->second];
+        DWS_CHECK(p->dtype == 0 && (int64_t)p->numel() == numels[i] && dsts[i], DWS_ERR_INVALID,
+                  "'%s': gradient sink of %lld elements for a tensor of %zu", names[i], (long long)numels[i], p->numel());
+        DWS_CHECK(groups[i] >= 0 && groups[i] < ngroups, DWS_ERR_INVALID, "'%s': group %d of %d", names[i], groups[i], ngroups);
+        grad_group_of[it->second] = groups[i];
+        grad_sink[it->second] = dsts[i];
+        grad_groups[groups[i]].params.push_back(it->second);
+    }
+    for (auto& g : grad_groups) DWS_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+    return DWS_OK;
+}
+
+void dws_model::grad_begin() {
+    in_backward = true;
+    grad_seq = 0;
+    std::fill(grad_touch.begin(), grad_touch.end(), -1);
+    for (auto& g : grad_groups) g.flushed = g.touched_after_flush = false;
+}
+
+int dws_model::grad_flush(GradGroup& g, hipStream_t s) {
+    g.copy.begin();
+    for (int pi : g.params) {
+        dws::ParamSpec* p = params[pi];
+        const bool was = in_backward;
+        in_backward = false;               // (fetching the buffer for the copy is not a production of the gradient)
+        float* src = G(p->name);
+        in_backward = was;
+        DWS_CHECK(src, DWS_ERR_HIP, "could not allocate the gradient of '%s'", p->name.c_str());
+        g.copy.add(src, grad_sink[pi], p->numel());
+    }
+    DWS_TRY(g.copy.run(s));
+    DWS_HIP(hipEventRecord(g.ev, s));
+    g.flushed = true;
+    g.touched_after_flush = false;
+    return DWS_OK;
+}
+
+int dws_model::grad_point(hipStream_t s) {
+    if (!in_backward || grad_groups.empty()) return DWS_OK;
+    if (grad_order_known)
+        for (auto& g : grad_groups)
+            if (!g.flushed && g.ready_seq <= grad_seq) DWS_TRY(grad_flush(g, s));
+    ++grad_seq;
+    return DWS_OK;
+}
+
+int dws_model::grad_end(hipStream_t s) {
+    if (!in_backward) return DWS_OK;
+    // whatever is left, and any group a late write invalidated (the learnt order was wrong for it: re-copied, its event
+    // re-recorded -- the host waits on the events only after backward has returned, so it sees this record)
+    bool order_held = true;
+    for (auto& g : grad_groups) {
+        if (g.touched_after_flush) order_held = false;
+        if (!g.flushed || g.touched_after_flush) DWS_TRY(grad_flush(g, s));
+    }
+    in_backward = false;
+    if (grad_groups.empty()) return DWS_OK;
+    // learn: a group is ready after the flush point of its last-produced gradient.  The order of THIS backward is used by the
+    // next one (the graph is static); a backward that disagrees with its predecessor -- new shapes, another config, a late
+    // write caught above -- makes the next one a recording-only backward again.
+    const bool same = grad_touch_prev.empty() || grad_touch_prev == grad_touch;
+    for (auto& g : grad_groups) {
+        int r = 0;
+        for (int pi : g.params) r = std::max(r, grad_touch[pi] + 1);
+        g.ready_seq = r;
+    }
+    grad_order_known = same && order_held;
+    grad_touch_prev = grad_touch;
+    return DWS_OK;
 }
 
 int dws_model::set_option(const std::string& key, const std::string& value) {
@@ -190,7 +283,36 @@ int dws_model_forward_train(dws_model* m, const float* audio, const float* steps
 
 int dws_model_backward(dws_model* m, const float* dout, void* stream) {
     DWS_CHECK(m && dout, DWS_ERR_INVALID, "dws_model_backward: null argument");
-    return m->backward(dout, (hipStream_t)stream);
+    m->grad_begin();
+    const int rc = m->backward(dout, (hipStream_t)stream);
+    if (rc != DWS_OK) { m->in_backward = false; return rc; }
+    return m->grad_end((hipStream_t)stream);
+}
+
+int dws_model_set_grad_sinks(dws_model* m, int32_t count, const char* const* names, float* const* dsts, const int64_t* numels,
+                             const int32_t* groups, int32_t ngroups) {
+    DWS_CHECK(m && count >= 0 && ngroups >= 0 && (count == 0 || (names && dsts && numels && groups && ngroups > 0)), DWS_ERR_INVALID,
+              "dws_model_set_grad_sinks: null argument");
+    return m->set_grad_sinks(count, names, dsts, numels, groups, ngroups);
+}
+
+int dws_model_grad_group_wait(dws_model* m, int32_t group, void* waiting_stream) {
+    DWS_CHECK(m && group >= 0 && (size_t)group < m->grad_groups.size(), DWS_ERR_INVALID, "dws_model_grad_group_wait: group %d of %zu",
+              group, m ? m->grad_groups.size() : (size_t)0);
+    DWS_CHECK(m->grad_groups[group].flushed, DWS_ERR_STATE, "dws_model_grad_group_wait: no backward has handed group %d over", group);
+    DWS_HIP(hipStreamWaitEvent((hipStream_t)waiting_stream, m->grad_groups[group].ev, 0));
+    return DWS_OK;
+}
+
+int dws_model_grad_ready_seq(dws_model* m, int32_t count, const char* const* names, int32_t* seq_out) {
+    DWS_CHECK(m && names && seq_out && count >= 0, DWS_ERR_INVALID, "dws_model_grad_ready_seq: null argument");
+    DWS_CHECK(!m->grad_touch_prev.empty(), DWS_ERR_STATE, "dws_model_grad_ready_seq: no backward with gradient sinks has run");
+    for (int i = 0; i < count; ++i) {
+        auto it = m->index.find(names[i]);
+        DWS_CHECK(it != m->index.end(), DWS_ERR_INVALID, "unknown parameter '%s'", names[i]);
+        seq_out[i] = m->grad_touch_prev[it->second];
+    }
+    return DWS_OK;
 }
 
 int dws_model_get_grad(dws_model* m, const char* name, float* dst, int64_t numel, void* stream) {

@@ -96,6 +96,16 @@ __device__ __forceinline__ float dws_gelu_grad(float x) {   // Phi(x) + x phi(x)
     return fmaf(x * 0.39894228040143267794f, ez, cdf);
 }
 
+// Per-DEVICE launch state: hipFuncSetAttribute, the CU count and occupancy are properties of a device, not of the process -- a
+// launcher's "done once" flag / cached count is an array indexed by the current device's ordinal (one process per GPU is
+// the product layout; a process that drives several GPUs still gets every device set up).
+constexpr int DWS_MAX_DEVICES = 16;
+inline int current_device_slot() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return ((unsigned)d < (unsigned)DWS_MAX_DEVICES) ? d : 0;
+}
+
 // XCD-aware bijective remap of a linear block id (guide T1): hardware places
 // block b on XCD b % 8; give every XCD a contiguous chunk of the tile space so
 // neighbouring tiles (which share halo rows) hit the same L2.

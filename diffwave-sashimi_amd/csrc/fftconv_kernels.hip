@@ -657,7 +657,8 @@ bool fftconv_supported(int L, int* log2m) {
 }
 
 static int cu_count() {
-    static int n = 0;
+    static int n_dev[DWS_MAX_DEVICES] = {};
+    int& n = n_dev[current_device_slot()];
     if (!n) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -679,7 +680,8 @@ static int fft_trace_launch(FftConvArgs a, int nwg, hipStream_t s) {
     auto kern = fused ? fftconv_kernel<LOG2M, C::THREADS, true, C::FUSED> : fftconv_kernel<LOG2M, C::THREADS, true>;
     constexpr int NP = FftPlan<LOG2M>::N16 - 1;
     const int T4 = (FftPlan<LOG2M>::TAIL4 && !fused) ? 1 : 0, NST = 3 + NP + T4 + 1 + T4 + NP + 2;   // fused: the pair stage carries both tails
-    static bool attr = false;
+    static bool attr_dev[DWS_MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device_slot()];
     if (!attr) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;
@@ -735,7 +737,8 @@ static int launch_fc(const FftConvArgs& a_in, hipStream_t s) {
     // A/B switch, read once: DWS_FFT_NO_FUSED_TAIL=1 (separate tail / pair / tail passes, scalar pair arithmetic)
     static const bool fused = C::FUSED && getenv("DWS_FFT_NO_FUSED_TAIL") == nullptr;
     auto kern = fused ? fftconv_kernel<LOG2M, C::THREADS, false, C::FUSED> : fftconv_kernel<LOG2M, C::THREADS>;
-    static bool attr = false;
+    static bool attr_dev[DWS_MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device_slot()];
     if (!attr) {
         DWS_HIP(hipFuncSetAttribute((const void*)fftconv_kernel<LOG2M, C::THREADS, false, C::FUSED>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
@@ -767,7 +770,8 @@ static int launch_fcorr(const FftCorrArgs& a, hipStream_t s) {
     if (LOG2M >= 14 && half) {
         constexpr int TH = C::THREADS > 512 ? 512 : C::THREADS;
         auto kern = fftcorr_kernel<LOG2M, TH>;
-        static bool attr = false;
+        static bool attr_dev[DWS_MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device_slot()];
         if (!attr) {
             DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
             attr = true;
@@ -777,7 +781,8 @@ static int launch_fcorr(const FftCorrArgs& a, hipStream_t s) {
     }
     constexpr int TH = C::THREADS;
     auto kern = fftcorr_kernel<LOG2M, TH>;
-    static bool attr = false;
+    static bool attr_dev[DWS_MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device_slot()];
     if (!attr) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;
@@ -790,7 +795,8 @@ template <int LOG2M>
 static int launch_rf(const float* in, float* out, const float* tw, const float* twn, int H, hipStream_t s) {
     using C = FcCfg<LOG2M>;
     auto kern = rfft_rows_kernel<LOG2M, C::THREADS>;
-    static bool attr = false;
+    static bool attr_dev[DWS_MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device_slot()];
     if (!attr) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;
@@ -855,7 +861,8 @@ int launch_fftconv_seg(const FftConvSegArgs& a, hipStream_t s) {
     constexpr int TH = 512, S = 1 << FFTCONV_SEG_LOG2M;
     ProfileScope ps("fftconv_seg", s);
     auto kern = fftconv_seg_kernel<FFTCONV_SEG_LOG2M, TH>;
-    static bool attr = false;
+    static bool attr_dev[DWS_MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device_slot()];
     if (!attr) {
         DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr = true;

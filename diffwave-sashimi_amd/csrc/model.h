@@ -115,6 +115,32 @@ struct dws_model {
     const void* g_noise = nullptr;
     uint64_t g_seed = 0;
 
+    // ---- staged gradient hand-over (data-parallel overlap, dws_model_set_grad_sinks): the host names a destination and a
+    // GROUP (its all-reduce bucket) per parameter; backward() copies a group's gradients to their destinations (one launch)
+    // and records the group's event the moment the group's last gradient has been produced, so the host can start that
+    // bucket's all-reduce while the rest of backward still runs.  When a gradient is final is LEARNT: G() stamps every
+    // access during a backward with the number of the flush point (grad_point) it precedes; the first backward after the
+    // sinks (or the model's graph) changed only records and flushes everything at its end.
+    struct GradGroup {
+        std::vector<int> params;       // parameter indices
+        dws::CopyBatch copy;           // grads -> sinks, table uploaded once
+        hipEvent_t ev = nullptr;       // recorded behind the group's copy
+        int ready_seq = 0;             // flush point after which every gradient of the group is final (learnt)
+        bool flushed = false, touched_after_flush = false;
+    };
+    std::vector<GradGroup> grad_groups;
+    std::vector<int> grad_group_of;        // per parameter: group or -1
+    std::vector<float*> grad_sink;         // per parameter: destination or null
+    std::vector<int> grad_touch, grad_touch_prev;   // per parameter: flush point of the last G() of this / the previous backward
+    bool grad_order_known = false, in_backward = false;
+    int grad_seq = 0;
+    int set_grad_sinks(int32_t count, const char* const* names, float* const* dsts, const int64_t* numels, const int32_t* groups,
+                       int32_t ngroups);
+    void grad_begin();                 // start of a backward
+    int grad_point(hipStream_t s);     // a flush opportunity inside backward (after a layer / block)
+    int grad_end(hipStream_t s);       // end of a backward: flush what is left, learn the order
+    int grad_flush(GradGroup& g, hipStream_t s);
+
     virtual ~dws_model();
     dws::ParamSpec* add_param(const std::string& name, std::vector<int64_t> shape, int dtype = 0);
     float* P(const std::string& name) const;  // raw device pointer of a parameter

@@ -380,7 +380,8 @@ static int launch_chain_t(const S4TailArgs& a, hipStream_t s) {
     using T = ChainCfg<H, 2>;
     ProfileScope ps("s4_tail_mfma_chain", s);
     const size_t lds = (size_t)T::LDS_FLOATS * 4;
-    static int slots = 0;
+    static int slots_dev[DWS_MAX_DEVICES] = {};
+    int& slots = slots_dev[current_device_slot()];
     if (slots == 0) {
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain_kernel<H, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain_kernel<H, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -635,7 +635,8 @@ template <typename P>
 static int launch_wide6_p(const S4TailArgs& a, hipStream_t s) {
     using T = Wide6Cfg<128, 2, P::NT>;
     ProfileScope ps(P::NT == 3 ? "s4_tail_mfma_wide6" : "s4_tail_mfma_wide_f16x3", s);
-    static int ncu = 0;
+    static int ncu_dev[DWS_MAX_DEVICES] = {};
+    int& ncu = ncu_dev[current_device_slot()];
     if (ncu == 0) {
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_wide6_kernel<P, 128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_wide6_kernel<P, 128, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
@@ -694,7 +695,8 @@ static int launch_chain6_t(const S4TailArgs& a, hipStream_t s) {
     using T = Chain6Cfg<H, 2, P::NT>;
     ProfileScope ps(P::NT == 3 ? "s4_tail_mfma_chain6" : "s4_tail_mfma_chain_f16x3", s);
     const size_t lds = (size_t)T::LDS_BYTES;
-    static int slots = 0;
+    static int slots_dev[DWS_MAX_DEVICES] = {};
+    int& slots = slots_dev[current_device_slot()];
     if (slots == 0) {
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain6_kernel<P, H, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_chain6_kernel<P, H, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -627,7 +627,8 @@ static int launch_tail_split_t(const S4TailArgs& a, hipStream_t s) {
     ProfileScope ps(SP::NT == 3 ? "s4_tail_mfma_tile6" : "s4_tail_mfma_tile_f16x3", s);
     const int ntl = ceil_div(a.L, T::P);
     const size_t lds = (size_t)T::LDS_FLOATS * 4;
-    static bool attr_set = false;
+    static bool attr_set_dev[DWS_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[current_device_slot()];
     if (!attr_set) {
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, false, SP>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -644,7 +645,8 @@ static int launch_tail_t(const S4TailArgs& a, hipStream_t s) {
     const int ntl = ceil_div(a.L, T::P);
     const size_t lds = (size_t)T::LDS_FLOATS * 4;
     const bool no_vec = getenv("DWS_TAIL_NO_VEC") != nullptr;   // (read per launch: tests switch it inside one process)
-    static bool attr_set = false;
+    static bool attr_set_dev[DWS_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[current_device_slot()];
     if (!attr_set) {
         DWS_HIP(hipFuncSetAttribute((const void*)s4_tail_mfma_kernel<H, WM, WN, NT, 2, true, OCC, KGU>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

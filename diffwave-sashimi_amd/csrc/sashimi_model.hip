@@ -195,6 +195,10 @@ struct SashimiModel : dws_model {
             }
             return set_error(DWS_ERR_UNSUPPORTED, "sashimi: precision=%s is not built (f32 | bf16x6 | f16x3)", value.c_str());
         }
+        if (key == "train_ln_fusion") {     // 0: separate LayerNorm passes in forward_train (parity / A-B runs); default 1
+            train_ln_fusion = value != "0";
+            return DWS_OK;
+        }
         return dws_model::set_option(key, value);
     }
 
@@ -1053,10 +1057,18 @@ struct SashimiModel : dws_model {
     }
 
     // out[b, m, l] = epi(sum_k A[m, k] src[b, k, l])   (tapconv_mfma, T = 1)
+    // LayerNorm fused into a training GEMM's epilogue (TapConvArgs::ln_*): destination, the norm's scalars, optional fc_t rows
+    struct LnFuse { float* out; const float* m; const float* s; const float* pt; int pt_bstride; };
+    bool train_ln_fusion = true;
+    bool ln_fusable(const float* A, int epi, int M, int Lx) const {
+        static const bool off = getenv("DWS_TRAIN_NO_LN_FUSION") != nullptr;     // same-box A/B switch
+        return !off && train_ln_fusion && row_major.find(A) == row_major.end() && tapconv_ln_supported(epi, M, Lx);
+    }
     int gemm(const float* A, int M, int K, const float* src, float* out, int Lx, int epi, const float* bias,
-             const float* res, const float* addend, const float* aux, float* out2, hipStream_t s) {
+             const float* res, const float* addend, const float* aux, float* out2, hipStream_t s, const LnFuse* ln = nullptr) {
         auto it = row_major.find(A);
         if (it != row_major.end()) {
+            DWS_CHECK(!ln, DWS_ERR_STATE, "gemm: LayerNorm epilogue requested on the plain-FMA path");
             DWS_CHECK(it->second.M == M && it->second.K == K, DWS_ERR_STATE, "gemm: operand registered as %d x %d, used as %d x %d",
                       it->second.M, it->second.K, M, K);
             GemmRowsArgs g{};
@@ -1070,6 +1082,7 @@ struct SashimiModel : dws_model {
         q.addin = (epi == 0) ? aux : nullptr; q.addscale = 1.f;
         q.B = (int)B; q.L = Lx;
         q.split = bf16x6 ? 1 : 0;      // precision = bf16x6: the pointwise GEMMs of the training step on the bf16 matrix cores
+        if (ln) { q.ln_out = ln->out; q.ln_m = ln->m; q.ln_s = ln->s; q.ln_pt = ln->pt; q.ln_pt_bstride = ln->pt_bstride; }
         return launch_tapconv_mfma(q, s);
     }
 
@@ -1159,6 +1172,7 @@ struct SashimiModel : dws_model {
         DWS_TRY(launch_linear_rows(emb.f(), P("fc_t1.weight"), P("fc_t1.bias"), h1.f(), nB, Ein, Emid, 1, s, ta1.f()));
         DWS_TRY(launch_linear_rows(h1.f(), P("fc_t2.weight"), P("fc_t2.bias"), h2.f(), nB, Emid, Eout, 1, s, ta2.f()));
         DWS_TRY(launch_linear_rows(h2.f(), Wt_all.f(), bt_all.f(), part_t.f(), nB, Eout, pt_total, 0, s));
+        bool ln1_done = false;      // this block's LN1 came out of the previous block's epilogue
         for (size_t i = 0; i < plan.size(); ++i) {
             const Exec& e = plan[i];
             SLayer* l = e.l;
@@ -1168,8 +1182,11 @@ struct SashimiModel : dws_model {
                 Stage* st = stages[l->stage];
                 const int H = l->H, Ls = l->L;
                 const std::string& p = l->prefix;
-                DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, l->t_u.f(), nB, H,
-                                  Ls, (size_t)Ls, s));
+                // LN1(x) + fc_t(e): already written by the previous block's last GEMM when that one could fuse it (below)
+                if (!ln1_done)
+                    DWS_TRY(launch_ln(x, P(p + ".norm1.m"), P(p + ".norm1.s"), part_t.f() + l->pt_off, pt_total, l->t_u.f(), nB, H,
+                                      Ls, (size_t)Ls, s));
+                ln1_done = false;
                 FftTables* t = tables[l->log2m];
                 FftConvArgs fa{};
                 fa.u = l->t_u.f(); fa.g = l->t_g.f(); fa.pre = l->t_a.f(); fa.D = P(p + ".layer.D");
@@ -1177,20 +1194,33 @@ struct SashimiModel : dws_model {
                 fa.kfa = (const c2*)l->kfa.p; fa.kfb = (const c2*)l->kfb.p; fa.kfs = (const c2*)l->kfs.p;
                 fa.B = nB; fa.H = H; fa.L = Ls;
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
+                // LN2(x1) out of the epilogue that produces x1 when the tile holds every channel (H = 128): the separate
+                // LayerNorm pass (read x1, write n2) becomes one extra store
+                bool ln2_done = false;
                 if (tapconv_glu_supported(2 * H, H, Ls)) {   // o and x1 = x + GLU(o) (+ mel) from one kernel
+                    LnFuse f2{l->t_n2.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0};
+                    ln2_done = ln_fusable(l->pAo, 6, 2 * H, Ls);
                     DWS_TRY(gemm(l->pAo, 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 6, P(p + ".layer.output_linear.0.bias"), x,
-                                 nullptr, melBm ? l->melc.f() : nullptr, l->t_x1.f(), s));
+                                 nullptr, melBm ? l->melc.f() : nullptr, l->t_x1.f(), s, ln2_done ? &f2 : nullptr));
                 } else {
                     DWS_TRY(gemm(l->pAo, 2 * H, H, l->t_g.f(), l->t_o.f(), Ls, 2, P(p + ".layer.output_linear.0.bias"),
                                  nullptr, nullptr, nullptr, nullptr, s));
                     DWS_TRY(launch_glu_res(l->t_o.f(), x, melBm ? l->melc.f() : nullptr, l->t_x1.f(), nB, H, Ls, s));
                 }
-                DWS_TRY(launch_ln(l->t_x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, l->t_n2.f(), nB, H, Ls,
-                                  (size_t)Ls, s));
+                if (!ln2_done)
+                    DWS_TRY(launch_ln(l->t_x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, l->t_n2.f(), nB, H, Ls,
+                                      (size_t)Ls, s));
                 DWS_TRY(gemm(l->pA1, FF * H, H, l->t_n2.f(), l->t_f1.f(), Ls, 3, P(p + ".ff.ff.0.conv.bias"), nullptr,
                              nullptr, nullptr, l->t_ge.f(), s));
+                // the NEXT block's LN1(out) + fc_t(e) out of this block's last epilogue (same stage, H = 128 / 256)
+                SLayer* nx = (i + 1 < plan.size() && plan[i + 1].l->kind == L_BLOCK) ? plan[i + 1].l : nullptr;
+                LnFuse f1{};
+                if (nx && nx->H == H && nx->L == Ls && ln_fusable(l->pA2, 4, H, Ls)) {
+                    f1 = LnFuse{nx->t_u.f(), P(nx->prefix + ".norm1.m"), P(nx->prefix + ".norm1.s"), part_t.f() + nx->pt_off, (int)pt_total};
+                    ln1_done = true;
+                }
                 DWS_TRY(gemm(l->pA2, H, FF * H, l->t_ge.f(), l->out.f(), Ls, 4, P(p + ".ff.ff.2.conv.bias"), l->t_x1.f(),
-                             add, nullptr, nullptr, s));
+                             add, nullptr, nullptr, s, ln1_done ? &f1 : nullptr));
             } else if (l->kind == L_DOWN) {
                 DWS_TRY(launch_pool_rearrange(x, l->t_xr.f(), nullptr, 0, 0, nB, l->H, l->p, l->Lout, s));
                 DWS_TRY(gemm(l->pAp, l->Hout, l->H * l->p, l->t_xr.f(), l->out.f(), l->Lout, 2,
@@ -1380,6 +1410,7 @@ struct SashimiModel : dws_model {
                 DWS_TRY(launch_add_into(dy, node_grad(e.add_node), written[e.add_node], node_numel(e.add_node), s));
                 written[e.add_node] = 1;
             }
+            DWS_TRY(grad_point(s));   // staged hand-over: buckets whose last gradient this layer produced leave now
         }
 
         // ---- init_conv: x0 = relu(Wi audio + bi)

@@ -39,7 +39,13 @@ struct TapConvArgs {
     const float* bias; const float* res; const float* addend; const float* aux; float* out2;
     int B, L;
     int split;                   // 1: precision = bf16x6 (3-term bf16 split, six products) where an instance exists (T = 1, L % 4 == 0)
+    // TransposedLayerNorm of the tile's output columns fused into the epilogue (`sashimi.py:17-20`: population std down the
+    // channel column, no eps): epi 4 normalises `out` [B,M,L], epi 6 normalises `out2` = x1 [B,M/2,L];
+    //   ln_out = (ln_s / std) (v - mean + ln_m) (+ ln_pt[b * ln_pt_bstride + row])
+    // Needs the whole channel column in ONE workgroup (tapconv_ln_supported) and the float4 epilogue.
+    float* ln_out; const float* ln_m; const float* ln_s; const float* ln_pt; int ln_pt_bstride;
 };
+bool tapconv_ln_supported(int epi, int M, int L);   // the LayerNorm epilogue exists for this GEMM shape
 bool tapconv_mfma_supported(int M, int K0, int K1, int T);
 bool tapconv_glu_supported(int M, int K, int L);   // epilogue 6 (GLU + residual fused into the 2H x H GEMM)
 int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s);

@@ -31,6 +31,15 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// 16-byte buffer store + the wait state hipcc leaves out (gfx950: a VALU write to the data registers of a 16-byte
+// buffer_store that carries an SGPR offset, in the issue slot right behind it, corrupts the last dword of the last lanes of each
+// 16-lane group -- DESIGN.md 10, found in wavenet_bx6.hip; the LayerNorm epilogue's store loop reproduced it: the next
+// row's normalised values are computed into the registers the store still reads).
+__device__ __forceinline__ void store4_hz(u32x4_t v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    (void)aux;
+    asm volatile("s_nop 1" ::: "memory");
+}
 __device__ __forceinline__ float sigm_b(float x) { return dws_sigmoid(x); }
 
 __device__ __forceinline__ float gelu_b(float x) { return dws_gelu(x); }
@@ -59,7 +68,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // T = 3: measured faster with 2 workgroups per CU than with 3 (456 -> 384 us on the C = 256 adjoint), so the
     // allocation is padded past a third of the 160 KB LDS
     constexpr int LDS_PAD = (T == 3) ? 2304 : 0;
-    constexpr int EPI_FLOATS = (EPI == 1) ? 0 : 4 * 32 * P;   // one 32-row transposition tile per wave (float4 epilogue)
+    // one 32-row transposition tile per wave (float4 epilogue) + the LayerNorm epilogue's column partials [2][4 waves][64]
+    constexpr int EPI_FLOATS = (EPI == 1) ? 0 : 4 * 32 * P + ((EPI == 4 || EPI == 6) ? 2 * 4 * P : 0);
     constexpr int MAIN_FLOATS = 2 * ROWS * P + LDS_PAD + 2 * BOP_FLOATS;
     constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -252,6 +262,54 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int lrow = lane >> 4, p4 = (lane & 15) * 4;
         const int voff = (l0 + p4 < L) ? (lrow * L + l0 + p4) * 4 : OOB;
         const bool has_bias = a.bias != nullptr, has_addin = a.addin != nullptr, has_addend = a.addend != nullptr;
+        // LayerNorm epilogue (EPI 4 / 6, a.ln_out): the NV f32x4 values a lane keeps are rows (.. + lrow) x positions p4..p4+3
+        // of the normalised tensor; the column statistics meet in LDS across the four row groups of a wave (lanes 16 apart)
+        // and the four waves (the workgroup holds ALL channels: tapconv_ln_supported).  Two passes -- mean, then the centred
+        // sum of squares -- as `torch.std_mean` does; every wave of the workgroup passes both barriers.
+        auto ln_finish = [&](auto& keep, auto row_of, int nch) {
+            constexpr int NV = sizeof(keep) / sizeof(f32x4);
+            float* red = lds + 4 * 32 * P;
+            auto column_total = [&](f32x4 part, int which) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    part[j] += __shfl_xor(part[j], 16, 64);
+                    part[j] += __shfl_xor(part[j], 32, 64);
+                }
+                if (lrow == 0) *reinterpret_cast<f32x4*>(red + (which * 4 + wave) * P + p4) = part;
+                __syncthreads();
+                f32x4 t = *reinterpret_cast<const f32x4*>(red + (which * 4) * P + p4);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + (which * 4 + w) * P + p4);
+                return t;
+            };
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NV; ++i) sum += keep[i];
+            const f32x4 mean = column_total(sum, 0) * (1.f / (float)nch);
+            f32x4 sq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const f32x4 dlt = keep[i] - mean;
+                sq += dlt * dlt;
+            }
+            const f32x4 var = column_total(sq, 1) * (1.f / (float)nch);
+            const float ls = a.ln_s[0], lm = a.ln_m[0];
+            f32x4 scale, shift;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                scale[j] = ls / sqrtf(var[j]);
+                shift[j] = lm - mean[j];
+            }
+            __amdgpu_buffer_rsrc_t rLn = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ln_out + (size_t)b * nch * L), 0, nch * L * 4, 0x00020000);
+            const float* pt = a.ln_pt ? a.ln_pt + (size_t)b * a.ln_pt_bstride : nullptr;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int row0 = row_of(i);
+                f32x4 y = scale * (keep[i] + shift);
+                if (pt) y += pt[row0 + lrow];
+                store4_hz(__builtin_bit_cast(u32x4_t, y), rLn, voff, row0 * L4, 0);
+            }
+        };
         if constexpr (EPI == 6) {
             static_assert(MT == 2, "the GLU epilogue pairs two M-tiles per wave");
             const int Hh = M / 2;
@@ -261,7 +319,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res + boff2), 0, HL4, 0x00020000);
             __amdgpu_buffer_rsrc_t rMel = __builtin_amdgcn_make_buffer_rsrc((void*)((a.aux ? a.aux : a.res) + boff2), 0, HL4, 0x00020000);
             const bool has_mel = a.aux != nullptr;
-            f32x4 va[8];
+            f32x4 va[8], x1k[8];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -273,7 +331,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     const int row0 = mt[m] * 32 + it * 4;
                     f32x4 v = *reinterpret_cast<const f32x4*>(wl + (it * 4 + lrow) * P + p4);
                     if (has_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, lrow * 4, row0 * 4, 0));
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rOut, voff, row0 * L4, 0);
+                    store4_hz(__builtin_bit_cast(u32x4_t, v), rOut, voff, row0 * L4, 0);
                     if (m == 0) {
                         va[it] = v;
                     } else {
@@ -282,12 +340,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                         if (has_mel) x1 += buf_load4(rMel, voff, soff2);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x1[j] += va[it][j] * sigm_b(v[j]);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x1), rX1, voff, soff2, 0);
+                        store4_hz(__builtin_bit_cast(u32x4_t, x1), rX1, voff, soff2, 0);
+                        x1k[it] = x1;
                     }
                 }
             }
+            if (a.ln_out) ln_finish(x1k, [&](int i) { return mt[0] * 32 + i * 4; }, Hh);
             return;
         }
+        f32x4 vk[EPI == 4 ? MT * 8 : 1];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -318,14 +379,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     if (has_addend) v += buf_load4(rAdd, voff, soff);
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rOut, voff, soff, 0);
+            store4_hz(__builtin_bit_cast(u32x4_t, v), rOut, voff, soff, 0);
+            if constexpr (EPI == 4) vk[m * 8 + it] = v;
             if (EPI == 3) {
                 f32x4 gq;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) gq[j] = gelu_b(v[j]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, gq), rOut2, voff, soff, 0);
+                store4_hz(__builtin_bit_cast(u32x4_t, gq), rOut2, voff, soff, 0);
             }
         }
+        }
+        if constexpr (EPI == 4) {
+            if (a.ln_out) ln_finish(vk, [&](int i) { return mt[i >> 3] * 32 + (i & 7) * 4; }, M);
         }
         return;
     }
@@ -403,6 +468,15 @@ bool tapconv_glu_supported(int M, int K, int L) {
     return tapconv_mfma_supported(M, K, 0, 1) && M % 256 == 0 && (L & 3) == 0;
 }
 
+// The LayerNorm epilogue needs every channel of a column in one workgroup (128 MT rows, one M-block) and 16-byte rows.
+// epi 4 normalises its M output rows (M = 128 -> MT = 1, M = 256 -> MT = 2); epi 6 its M/2 rows of x1 (M = 256).
+bool tapconv_ln_supported(int epi, int M, int L) {
+    if ((L & 3) != 0) return false;
+    if (epi == 4) return M == 128 || M == 256;
+    if (epi == 6) return M == 256;
+    return false;
+}
+
 // split instances: T = 1, not the gate adjoint, and the 16-byte staging form (the kernel's x4 condition)
 static bool tapconv_split_ok(const TapConvArgs& a) {
     return a.split == 1 && a.T == 1 && a.epi != 1 && a.L % 4 == 0 && ((((size_t)a.src0) | ((size_t)a.src1)) % 16 == 0);
@@ -439,6 +513,8 @@ int launch_tapconv_mfma(const TapConvArgs& a, hipStream_t s) {
     ProfileScope ps(tapconv_split_ok(a) ? "tapconv_bx6" : "tapconv_mfma", s);
     DWS_CHECK(tapconv_mfma_supported(a.M, a.K0, a.K1, a.T), DWS_ERR_UNSUPPORTED, "tapconv_mfma: M=%d K=%d+%d T=%d", a.M,
               a.K0, a.K1, a.T);
+    DWS_CHECK(!a.ln_out || (a.T == 1 && tapconv_ln_supported(a.epi, a.M, a.L)), DWS_ERR_UNSUPPORTED,
+              "tapconv_mfma: no LayerNorm epilogue for epi %d, M=%d, L=%d", a.epi, a.M, a.L);
     if (a.T == 3) {
         DWS_CHECK(a.epi == 0, DWS_ERR_UNSUPPORTED, "tapconv_mfma: T=3 has epilogue 0 only");
         return launch_tc<3, 0>(a, s);
@@ -927,7 +1003,8 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
     if (T == 1 && !a.xact && !a.addc && !no_dma && !no_dma4 && a.L % 4 == 0 && (a.xL ? a.xL : a.L) % 4 == 0 &&
         ((size_t)a.dY | (size_t)a.X) % 16 == 0) {
         constexpr int lds = 2 * 2 * 128 * 64 * 4;
-        static bool attr4 = false;
+        static bool attr4_dev[DWS_MAX_DEVICES] = {};
+    bool& attr4 = attr4_dev[current_device_slot()];
         if (!attr4) {
             DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -937,7 +1014,8 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
         else hipLaunchKernelGGL(wgrad_dma4_kernel<0>, grid, dim3(512), lds, s, a);
     } else if (T == 1 && !a.xact && !a.addc && !no_dma) {
         constexpr int lds = 2 * 2 * 128 * 66 * 4;
-        static bool attr = false;
+        static bool attr_dev[DWS_MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device_slot()];
         if (!attr) {
             DWS_HIP(hipFuncSetAttribute((const void*)wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr = true;

@@ -591,7 +591,8 @@ static int launch_bx3_t(const WnLayerArgs& a, hipStream_t s) {
     using T = Bx3Tile<C, S, PP, WV>;
     ProfileScope ps("wn_layer_bf16x3", s);
     const size_t lds = (size_t)T::LDS_FLOATS * 4;
-    static bool attr = false;
+    static bool attr_dev[DWS_MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device_slot()];
     if (!attr) {
         DWS_HIP(hipFuncSetAttribute((const void*)wn_layer_bf16x3_kernel<C, S, PP, WV, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

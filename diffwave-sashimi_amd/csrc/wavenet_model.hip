@@ -591,6 +591,7 @@ struct WaveNetModel : dws_model {
             DWS_TRY(launch_rowsum_bc(dh, dpt.f() + (size_t)n * C, NL * C, nB, C, nL, s));  // d fc_t(e)[b, n, c]
             if (dx_out) DWS_TRY(launch_dx_combine(dh, dx_out, nact, s));                   // + dx' * sqrt(.5)
             dx_out = dh;
+            DWS_TRY(grad_point(s));   // staged hand-over: buckets whose last gradient this layer produced leave now
         }
         // ---- init_conv: x0 = relu(Wi audio + bi)
         DWS_TRY(launch_relu_bwd(dx_out, tx[0].f(), nact, s));

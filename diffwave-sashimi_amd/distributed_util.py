@@ -91,6 +91,7 @@ class _Bucket:
             n = _real_view(p).numel()
             self.offsets.append((off, n))
             off += n
+        self.index = -1          # position in GradientAllReducer.buckets (= the engine's gradient group)
         self.pending = len(params)
         self.ready = set()
         self.foreign = set()     # slots whose gradient lives in its own storage this backward: copied in, copied back
@@ -106,6 +107,7 @@ class GradientAllReducer:
         if sync_state:
             broadcast_state(module, 0)
         params = [p for p in module.parameters() if p.requires_grad]
+        self._bucket_bytes = bucket_bytes
         self.buckets, self.where = [], {}
         cur, cur_bytes, cur_key = [], 0, None
         # reverse registration order ~ the order gradients become available in backward
@@ -122,6 +124,12 @@ class GradientAllReducer:
             self._close(cur, cur_key)
         self._callback_queued = False
         self._t_first, self._span = None, None
+        # engine modules (models/engine.py) deliver their gradients bucket by bucket DURING backward and record an event per
+        # bucket: set by engine_backward_done() for the backward in flight
+        self._engine, self._engine_names, self._bwd_end, self._exposed = None, None, None, None
+        self._side = None            # the stream the early all-reduces are launched from (waits for a bucket's event only)
+        self._rebucketed = False
+        self.overlapped_buckets = 0  # buckets of the last backward whose all-reduce was launched behind their own event
         self.last_stats = None      # {"in_place": slots found in the arena, "copied": slots copied in and back} of the last backward
         self._handles = []
         for p in params:
@@ -129,14 +137,91 @@ class GradientAllReducer:
 
     def _close(self, params, key):
         b = _Bucket(list(params), key[1], key[0])
+        b.index = len(self.buckets)
         for i, p in enumerate(params):
             self.where[p] = (len(self.buckets), i)
         self.buckets.append(b)
 
-    def _launch(self, b):
+    def engine_backward_done(self, module, names):
+        """Called by the engine's autograd node right after ``dws_model_backward`` returned (every backward kernel and every
+        bucket's hand-over copy + event is enqueued): from here on a complete, purely engine-written bucket is exchanged
+        behind ITS event instead of behind the whole backward."""
+        self._engine, self._engine_names = module, names
+        self._engine_last = (module, names)
+        self._bwd_end = self._stamp()          # the end of backward on the gradients' stream (exposed_ms)
+
+    def _launch(self, b, early_ok=True):
         if self._t_first is None:      # the exchange of a backward starts here: stamp it (allreduce_ms)
             self._t_first = self._stamp()
+        if early_ok and self._engine is not None and not b.foreign and b.flat.is_cuda:
+            from . import _lib
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=b.flat.device)
+            _lib.check(_lib.load().dws_model_grad_group_wait(self._engine._handle, b.index, self._side.cuda_stream))
+            with torch.cuda.stream(self._side):   # the collective's stream waits for what `_side` has queued: the bucket's event
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+            self.overlapped_buckets += 1
+            return
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def bucket_ready_points(self):
+        """Per bucket, the flush point of the engine's last backward after which the bucket's last gradient was final
+        (``dws_model_grad_ready_seq``), and the number of flush points of that backward: a bucket whose point is below the last
+        one left -- copy, event, all-reduce -- while backward was still running.  None without an engine backward."""
+        import ctypes
+        from . import _lib
+        if getattr(self, "_engine_last", None) is None:
+            return None
+        module, names = self._engine_last
+        params = dict(module.named_parameters())
+        n = len(names)
+        seq = (ctypes.c_int32 * n)()
+        _lib.check(_lib.load().dws_model_grad_ready_seq(module._handle, n, (ctypes.c_char_p * n)(*[x.encode() for x in names]), seq))
+        ready = {id(params[x]): int(seq[i]) for i, x in enumerate(names)}
+        return {"bucket_ready_point": [max([ready.get(id(p), -1) for p in b.params]) for b in self.buckets],
+                "last_point": max(ready.values())}
+
+    def exposed_ms(self):
+        """Milliseconds from the end of the engine's backward (its last kernel) to the completion of the last ``wait()`` of
+        the most recent backward: the part of the exchange the step could not hide.  None without an engine backward."""
+        if self._exposed is None:
+            return None
+        t0, t1 = self._exposed
+        t1.synchronize()
+        return t0.elapsed_time(t1)
+
+    def _rebucket_by_readiness(self):
+        """Once, after the first engine backward: re-cut the buckets in the order the engine's backward FINISHES the
+        gradients (``dws_model_grad_ready_seq``; the fc_t rows and the embedding MLP of every block come out of one stacked
+        GEMM at the very end, registration order would put one of them into every bucket and nothing could leave early).
+        Every rank runs the same graph, so every rank cuts the same buckets."""
+        import ctypes
+        from . import _lib
+        names = self._engine_names
+        params = dict(self._engine.named_parameters())
+        mine = [p for b in self.buckets for p in b.params]
+        if set(id(p) for p in mine) != set(id(params[n]) for n in names if params[n].requires_grad):
+            return                                   # foreign parameters in the arena: keep the registration order
+        n = len(names)
+        seq = (ctypes.c_int32 * n)()
+        _lib.check(_lib.load().dws_model_grad_ready_seq(self._engine._handle, n, (ctypes.c_char_p * n)(*[x.encode() for x in names]), seq))
+        ready = {id(params[x]): int(seq[i]) for i, x in enumerate(names)}
+        order = sorted(range(len(mine)), key=lambda i: (ready[id(mine[i])], i))
+        bucket_bytes = self._bucket_bytes
+        self.buckets, self.where = [], {}
+        cur, cur_bytes, cur_key = [], 0, None
+        for i in order:
+            p = mine[i]
+            key = (_real_view(p).dtype, p.device)
+            nbytes = _real_view(p).numel() * _real_view(p).element_size()
+            if cur and (key != cur_key or cur_bytes + nbytes > bucket_bytes):
+                self._close(cur, cur_key)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+            cur_key = key
+        if cur:
+            self._close(cur, cur_key)
 
     def _stamp(self):
         """A point in time on the gradients' device: a recorded CUDA event, or the host clock for CPU tensors."""
@@ -206,7 +291,7 @@ class GradientAllReducer:
                         if g is not None and g.data_ptr() == slot.data_ptr():
                             kept.append((slot, slot.clone()))
                         slot.zero_()
-                self._launch(b)
+                self._launch(b, early_ok=False)      # (the zeroing above runs on the gradients' stream: exchange behind it)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
@@ -220,8 +305,16 @@ class GradientAllReducer:
         for slot, value in kept:
             slot.copy_(value)
         self.last_stats["kept"] = len(kept)
+        end = self._stamp() if (self._t_first is not None or self._bwd_end is not None) else None
         if self._t_first is not None:
-            self._span = (self._t_first, self._stamp())
+            self._span = (self._t_first, end)
+        self._exposed = (self._bwd_end, end) if (self._bwd_end is not None and not isinstance(end, float)) else None
+        self.last_stats["overlapped_buckets"] = self.overlapped_buckets
+        self.overlapped_buckets = 0
+        if self._engine is not None and not self._rebucketed and self.buckets and self.buckets[0].flat.is_cuda:
+            self._rebucketed = True
+            self._rebucket_by_readiness()
+        self._engine = self._bwd_end = None
         self._t_first = None
         self._callback_queued = False
 

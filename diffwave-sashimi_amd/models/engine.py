@@ -39,7 +39,6 @@ class _EngineTrainFn(torch.autograd.Function):
             raise RuntimeError("the engine keeps the activations of ONE training forward: another forward ran on this "
                                "module before this backward (accumulate gradients with forward/backward pairs)")
         d = dout.detach().to(torch.float32).contiguous()
-        _lib.check(lib.dws_model_backward(m._handle, d.data_ptr(), _lib.current_stream()))
         n = len(ctx.meta)
         # Data-parallel runs (distributed_util.GradientAllReducer): the gradients are written straight into the flat
         # all-reduce buckets -- views handed out per backward, adopted by autograd as p.grad without a copy.  A parameter
@@ -47,19 +46,55 @@ class _EngineTrainFn(torch.autograd.Function):
         # BE last step's view of the same slot.
         reducer = getattr(m, "_dws_grad_reducer", None)
         views = reducer.grad_views() if reducer is not None else {}
-        outs = []
+        outs, groups = [], []
         for (_, shape, dtype), p in zip(ctx.meta, m.parameters()):
             v = views.get(id(p)) if (p.grad is None and dtype == torch.float32) else None
             if v is not None and v.device == d.device and v.dtype == torch.float32 and tuple(v.shape) == shape:
                 outs.append(v)
+                groups.append(reducer.where[p][0])          # the bucket the slot belongs to
+            elif reducer is not None:
+                # outside the arena (accumulation into an existing p.grad, a non-fp32 parameter): a PERSISTENT staging tensor,
+                # so that the installed sinks keep their addresses from step to step (autograd adds it into p.grad / the
+                # dtype conversion below copies it: nothing keeps a reference to it)
+                fb = m.__dict__.setdefault("_grad_fallback", {})
+                t = fb.get(ctx.meta[len(outs)][0])
+                if t is None or tuple(t.shape) != shape or t.device != d.device:
+                    t = fb[ctx.meta[len(outs)][0]] = torch.empty(shape, device=d.device, dtype=torch.float32)
+                outs.append(t)
+                groups.append(-1)
             else:
                 outs.append(torch.empty(shape, device=d.device, dtype=torch.float32))
+                groups.append(-1)
         del views
-        names = (ctypes.c_char_p * n)(*[name.encode() for name, _, _ in ctx.meta])
-        dsts = (ctypes.c_void_p * n)(*[g.data_ptr() for g in outs])
-        numels = (ctypes.c_int64 * n)(*[g.numel() for g in outs])
-        _lib.check(lib.dws_model_get_grads(m._handle, n, names, dsts, numels, _lib.current_stream()))   # one launch
-        grads = [g.to(dtype) for g, (_, _, dtype) in zip(outs, ctx.meta)]
+        groups_in = list(groups)        # >= 0: an arena view (handed to autograd as it is)
+        if reducer is not None:
+            # STAGED hand-over: the engine's backward delivers every gradient to its destination itself, bucket by bucket, the
+            # moment a bucket's last gradient exists, and records an event per bucket; the reducer then launches that bucket's
+            # all-reduce on a side stream that waits for the event only -- the exchange overlaps the rest of backward.
+            nb = len(reducer.buckets)
+            groups = [g if g >= 0 else nb for g in groups]          # gradients outside the arena: one last group
+            key = (tuple(g.data_ptr() for g in outs), tuple(groups))
+            if getattr(m, "_sink_key", None) != key:
+                names = (ctypes.c_char_p * n)(*[name.encode() for name, _, _ in ctx.meta])
+                dsts = (ctypes.c_void_p * n)(*[g.data_ptr() for g in outs])
+                numels = (ctypes.c_int64 * n)(*[g.numel() for g in outs])
+                _lib.check(lib.dws_model_set_grad_sinks(m._handle, n, names, dsts, numels, (ctypes.c_int32 * n)(*groups), nb + 1))
+                m._sink_key = key
+            # (no reference to `outs` may be kept: autograd adopts a returned gradient as p.grad only when nobody else holds
+            # it, otherwise it clones.  The destinations outlive the sinks anyway: arena slots and `_grad_fallback` tensors.)
+            _lib.check(lib.dws_model_backward(m._handle, d.data_ptr(), _lib.current_stream()))
+            reducer.engine_backward_done(m, [name for name, _, _ in ctx.meta])
+        else:
+            if getattr(m, "_sink_key", None) is not None:           # the module left data-parallel mode
+                _lib.check(lib.dws_model_set_grad_sinks(m._handle, 0, None, None, None, None, 0))
+                m._sink_key = None
+            _lib.check(lib.dws_model_backward(m._handle, d.data_ptr(), _lib.current_stream()))
+            names = (ctypes.c_char_p * n)(*[name.encode() for name, _, _ in ctx.meta])
+            dsts = (ctypes.c_void_p * n)(*[g.data_ptr() for g in outs])
+            numels = (ctypes.c_int64 * n)(*[g.numel() for g in outs])
+            _lib.check(lib.dws_model_get_grads(m._handle, n, names, dsts, numels, _lib.current_stream()))   # one launch
+        grads = [(g.to(dtype) if (dtype != torch.float32 or gi >= 0 or reducer is None) else g.clone())
+                 for g, gi, (_, _, dtype) in zip(outs, groups_in, ctx.meta)]
         return (None, None, None, None, *grads)
 
 

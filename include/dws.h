@@ -179,6 +179,22 @@ int dws_model_get_grad(dws_model* m, const char* name, float* dst, int64_t numel
 int dws_model_get_grads(dws_model* m, int32_t count, const char* const* names, float* const* dsts, const int64_t* numels,
                         void* stream);
 
+/* Staged hand-over of the gradients for the data-parallel exchange (`distributed_util.py:112-142` flattens and all-reduces
+ * AFTER backward; here the exchange of a bucket starts while backward still runs).  set_grad_sinks names, for `count`
+ * parameters, a device destination and a GROUP (the host's all-reduce bucket) each; it stays in force until it is called
+ * again (count == 0 removes it).  With sinks installed, dws_model_backward itself delivers the gradients: as soon as the last
+ * gradient of a group has been produced it copies the group to its destinations (one launch) and records the group's
+ * event on `stream`; groups left over are delivered at the end, so after backward every destination is written in stream
+ * order (no get_grads call is needed for them).  grad_group_wait makes `waiting_stream` wait for a group's event (call it
+ * after backward has returned: a collective launched on that stream then depends on the group's gradients only, not on
+ * the rest of backward).  When a gradient is final is learnt from the first backward after set_grad_sinks (which delivers
+ * everything at its end); grad_ready_seq reports, per parameter, the flush point (block / layer number in backward order,
+ * -1 = never written) after which its gradient was final in the last backward -- the order a host should bucket in. */
+int dws_model_set_grad_sinks(dws_model* m, int32_t count, const char* const* names, float* const* dsts, const int64_t* numels,
+                             const int32_t* groups, int32_t ngroups);
+int dws_model_grad_group_wait(dws_model* m, int32_t group, void* waiting_stream);
+int dws_model_grad_ready_seq(dws_model* m, int32_t count, const char* const* names, int32_t* seq_out);
+
 /* Debug/parity tap: copy an internal activation into `dst` (device pointer,
  * `capacity` floats).  WaveNet: "pre_final" = ReLU(final_conv[0](skip)) [B,S,L],
  * "skip" [B,S,L], "x" (last residual output) [B,C,L]; the step-only terms: "part_t"

@@ -169,4 +169,4 @@ def test_gradients_written_into_the_bucket_views_are_adopted_without_a_copy(tmp_
         d = json.loads(o.strip().splitlines()[-1])
         assert d["buckets"] >= 2 and d["inside"] and d["ok"] == [True, True, True], d
         # ("kept": retained gradients of non-leaf tensors stashed over the exchange -- none in this worker)
-        assert all(st == {"in_place": 3, "copied": 0, "kept": 0} for st in d["stats"]), d
+        assert all(st == {"in_place": 3, "copied": 0, "kept": 0, "overlapped_buckets": 0} for st in d["stats"]), d

@@ -32,14 +32,20 @@ def run(dp):
         nb = len(net._dws_grad_reducer.buckets)
     dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
     opt = torch.optim.SGD(net.parameters(), lr=0.05)
-    data = torch.randn(2, 2, 1, L, generator=torch.Generator().manual_seed(7)) * 0.3
+    data = torch.randn(5, 2, 1, L, generator=torch.Generator().manual_seed(7)) * 0.3
     losses = []
-    for step in range(2):
+    global per_step
+    per_step = []
+    for step in range(5):
         opt.zero_grad()
         loss = training_loss(net, nn.MSELoss(), data[step].cuda(), dh, generator=torch.Generator().manual_seed(1000 + step))
         losses.append(float(reduce_tensor(loss.detach(), 1)) if dp else float(loss))
         loss.backward()
         opt.step()
+        if dp:
+            red = net._dws_grad_reducer
+            per_step.append({"buckets": len(red.buckets), "stats": red.last_stats, "exposed_ms": red.exposed_ms(),
+                             "allreduce_ms": red.allreduce_ms(), "ready": red.bucket_ready_points()})
     torch.cuda.synchronize()
     global slot_stats
     slot_stats = net._dws_grad_reducer.last_stats if dp else None
@@ -54,7 +60,7 @@ dev = torch.device("cuda", 0)
 mx = ddist.max_over_ranks(1.25, dev)
 ga = ddist.gather_over_ranks(2.5, dev)
 same = all(torch.equal(a, b) for a, b in zip(plain_params, dp_params))
-print(json.dumps({"backend": dist.get_backend(), "world": dist.get_world_size(), "buckets": nb, "same": same, "slots": slot_stats,
+print(json.dumps({"backend": dist.get_backend(), "world": dist.get_world_size(), "buckets": nb, "same": same, "slots": slot_stats, "per_step": per_step,
                   "losses": [plain_losses, dp_losses], "max": mx, "gather": ga}))
 dist.destroy_process_group()
 '''
@@ -85,6 +91,16 @@ def test_one_rank_rccl_group_runs_the_dp_exchange(gpu):
     # zero-copy exchange: the engine wrote every gradient straight into the flat all-reduce buckets (no copy in / back)
     assert d["slots"]["copied"] == 0 and d["slots"]["in_place"] > 100, d["slots"]
     assert d["losses"][0] == d["losses"][1] and d["max"] == 1.25 and d["gather"] == [2.5]
+    # STAGED hand-over (dws_model_set_grad_sinks): the engine's backward delivers the buckets as their last gradient is produced
+    # and every bucket's all-reduce is launched behind ITS event.  Step 1 records the order and re-cuts the buckets by
+    # readiness, step 2 records again for the new buckets, from step 3 on buckets leave in the middle of backward: most of them
+    # are ready before the last flush point (only the stacked fc_t / embedding gradients come at the very end).
+    ps = d["per_step"]
+    assert all(s_["stats"]["copied"] == 0 for s_ in ps) and all(s_["exposed_ms"] is not None and s_["exposed_ms"] >= 0 for s_ in ps)
+    last = ps[-1]
+    assert last["stats"]["overlapped_buckets"] == last["buckets"] >= 3
+    pts, end = last["ready"]["bucket_ready_point"], last["ready"]["last_point"]
+    assert sorted(pts) == pts and pts[-1] == end and sum(p_ < end for p_ in pts) >= len(pts) // 2, last["ready"]
 
 
 def test_bench_timing_collectives_over_rccl(gpu):
