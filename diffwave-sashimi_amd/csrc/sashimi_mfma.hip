@@ -672,7 +672,20 @@ bool s4_tail_mfma_supported(int H, int ff) {
     return ff == 2 && (H == 32 || H == 64 || H == 128 || H == 256 || H == 512);
 }
 
+static int g_tail_split = 0, g_tail_f32 = 0;
+void s4_tail_launch_counts(int* split, int* f32, bool reset) {
+    if (split) *split = g_tail_split;
+    if (f32) *f32 = g_tail_f32;
+    if (reset) g_tail_split = g_tail_f32 = 0;
+}
+static int launch_s4_tail_mfma_impl(int H, const S4TailArgs& a, hipStream_t s, bool* ran_split);
 int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
+    bool ran_split = false;
+    const int rc = launch_s4_tail_mfma_impl(H, a, s, &ran_split);
+    ++(ran_split ? g_tail_split : g_tail_f32);
+    return rc;
+}
+static int launch_s4_tail_mfma_impl(int H, const S4TailArgs& a, hipStream_t s, bool* ran_split) {
     // Tile shapes <H, waves along rows, waves along positions, 32-position tiles per wave, workgroups per CU the register
     // budget is set for, k-group loop unrolled>, each the best of a same-box sweep (`profiles/r02_tail_shapes.txt`): up to
     // H = 128 small tiles win (NT = 1, 32-64 positions: a workgroup is MFMA-active less than a third of its life, and
@@ -681,10 +694,14 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     const int alt = getenv("DWS_TAIL_CFG") ? atoi(getenv("DWS_TAIL_CFG")) : 0;
     // H <= 64: the register-chained kernel (sashimi_chain.hip: a wave owns 32 positions, no LDS round trip between the
     // GEMMs, no barrier); DWS_TAIL_NO_CHAIN=1 keeps the LDS-tile kernel below (A/B runs, tests)
-    if (alt == 0 && a.Ao_c6 && s4_tail_wide6_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr)
-        return launch_s4_tail_wide6(H, a, s);       // precision = bf16x6, H = 128: one wave per SIMD, streamed weights
-    if (alt == 0 && a.Ao_c6 && s4_tail_chain6_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr)
-        return launch_s4_tail_chain6(H, a, s);      // precision = bf16x6: the same chain on the bf16 matrix cores, 3-term split
+    if (alt == 0 && a.Ao_c6 && s4_tail_wide6_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr) {
+        *ran_split = true;
+        return launch_s4_tail_wide6(H, a, s);
+    }       // precision = bf16x6, H = 128: one wave per SIMD, streamed weights
+    if (alt == 0 && a.Ao_c6 && s4_tail_chain6_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr) {
+        *ran_split = true;
+        return launch_s4_tail_chain6(H, a, s);
+    }      // precision = bf16x6: the same chain on the bf16 matrix cores, 3-term split
     if (alt == 0 && a.Ao_c && s4_tail_chain_supported(H, 2) && getenv("DWS_TAIL_NO_CHAIN") == nullptr)
         return launch_s4_tail_chain(H, a, s);
     if (alt == 1) {
@@ -695,6 +712,7 @@ int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
     }
     // precision = bf16x6 / f16x3 at H >= 256: the LDS-tile kernel with its GEMMs on the 16-bit matrix cores
     if (alt == 0 && a.split_on && (a.L & 3) == 0 && getenv("DWS_TAIL_NO_VEC") == nullptr && getenv("DWS_TAIL_NO_SPLIT_TILE") == nullptr) {
+        *ran_split = (H == 256 || H == 512) && (a.split_c6 == WN_SPLIT_BF16X6 || (a.split_c6 == WN_SPLIT_F16X3 && a.wscale_c6));
         if (a.split_c6 == WN_SPLIT_F16X3 && a.wscale_c6) {
             if (H == 256) return launch_tail_split_t<256, 8, 1, 2, 1, SplitF16x2>(a, s);
             if (H == 512) return launch_tail_split_t<512, 16, 1, 1, 1, SplitF16x2>(a, s);

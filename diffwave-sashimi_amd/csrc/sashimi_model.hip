@@ -782,6 +782,7 @@ struct SashimiModel : dws_model {
     }
 
     // everything of the block after the S4 convolution (sashimi.py:177-184, s4.py:1435)
+    int generic_tails = 0;
     int run_tail(SLayer* l, Stage* st, const float* x, const float* addend, const OutLN* next, hipStream_t s) {
         const int H = l->H, Ls = l->L, nB = (int)B;
         const std::string& p = l->prefix;
@@ -808,6 +809,7 @@ struct SashimiModel : dws_model {
             }
             return launch_s4_tail_mfma(H, t, s);
         }
+        ++generic_tails;       // plain-FMA block (channel counts the MFMA tiling does not cover): no split instance
         DWS_TRY(launch_pw_glu_res(st->g.f(), P(p + ".layer.output_linear.0.weight"), P(p + ".layer.output_linear.0.bias"),
                                   x, melBm ? l->melc.f() : nullptr, melBm > 1 ? 1 : 0, st->x1.f(), nB, H, Ls, s));
         DWS_TRY(launch_ln(st->x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, st->n2.f(), nB, H, Ls, (size_t)Ls, s));
@@ -902,6 +904,8 @@ struct SashimiModel : dws_model {
         if (dirty) DWS_TRY(commit(s));
         DWS_CHECK(!step_idx || (tab_T > 0 && tab_version == commit_version), DWS_ERR_STATE, "step-table forward without a current table");
         DWS_CHECK(step_idx || steps, DWS_ERR_INVALID, "forward: steps == null");
+        s4_tail_launch_counts(nullptr, nullptr, true);     // tap "split_launches": which arithmetic THIS forward's tails ran
+        generic_tails = 0;
         if (!step_idx) DWS_TRY(embed_rows(steps, (int)B, emb.f(), h1.f(), h2.f(), part_t.f(), s));
         std::vector<const float*> stack;  // LIFO skip stack (sashimi.py:293-307)
         const float* x = x_init.f();
@@ -1440,6 +1444,15 @@ struct SashimiModel : dws_model {
     int read_tap(const char* tap, float* dst, int64_t capacity, hipStream_t s) override {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "read_tap before prepare/forward");
         const std::string t(tap);
+        if (t == "split_launches") {   // [block tails of the last forward that ran a split instance, those that ran exact-f32 kernels]
+            DWS_CHECK(capacity >= 2, DWS_ERR_INVALID, "tap buffer too small");
+            int sp = 0, f3 = 0;
+            s4_tail_launch_counts(&sp, &f3, false);
+            const float v[2] = {(float)sp, (float)(f3 + generic_tails)};
+            DWS_HIP(hipMemcpyAsync(dst, v, 8, hipMemcpyHostToDevice, s));
+            DWS_HIP(hipStreamSynchronize(s));
+            return DWS_OK;
+        }
         if (t == "pre_final") {
             DWS_CHECK(last_x, DWS_ERR_STATE, "read_tap before forward");
             DWS_CHECK(capacity >= B * D * L, DWS_ERR_INVALID, "tap buffer too small");

@@ -631,6 +631,14 @@ struct WaveNetModel : dws_model {
             DWS_HIP(hipMemcpyAsync(dst, src, (size_t)B * C * L * 4, hipMemcpyDeviceToDevice, s));
             return DWS_OK;
         }
+        if (t == "split_launches") {   // [residual layers per forward on a split instance, on exact-f32 kernels]: all or nothing here
+            DWS_CHECK(capacity >= 2, DWS_ERR_INVALID, "tap buffer too small");   // (set_option refuses a split the channel counts do not cover)
+            const bool sp = mfma_layer && (bf16x3 || bf16x6 || f16x3);
+            const float v[2] = {sp ? (float)NL : 0.f, sp ? 0.f : (float)NL};
+            DWS_HIP(hipMemcpyAsync(dst, v, 8, hipMemcpyHostToDevice, s));
+            DWS_HIP(hipStreamSynchronize(s));
+            return DWS_OK;
+        }
         if (t == "pre_final") {
             DWS_CHECK(capacity >= B * S * L, DWS_ERR_INVALID, "tap buffer too small");
             DWS_TRY(scratch_out.ensure((size_t)B * Cout * L * 4));

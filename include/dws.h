@@ -133,12 +133,26 @@ int dws_model_update_params(dws_model* m, int32_t count, const char* const* name
  *               = "bf16x6" WaveNet residual layers on the bf16 matrix cores at fp32-EQUIVALENT accuracy: every GEMM
  *                          operand as an exact 3-term bf16 split (24 significand bits), the six partial products above
  *                          2^-26 accumulated in fp32, Winograd F(2,3) form (the f32 path's algorithm and roundings).
- *                          WaveNet: inference only.  SaShiMi: the S4 block tails (H <= 128) in sampling; in training the
- *                          pointwise GEMMs and weight gradients of the step.  Error against a float64 evaluation: that
- *                          of the f32 path.
+ *                          WaveNet: inference only.  SaShiMi: the S4 block tails
+ *                          (all H) in sampling; in training the pointwise GEMMs and weight gradients of the step.
+ *                          What "fp32-equivalent" was MEASURED to mean (tests/test_bf16x6_gpu.py, test_full_size_gpu.py,
+ *                          test_split_trajectory_gpu.py): operands are carried exactly, products are exact, the fp32
+ *                          accumulation is the matrix core's own adder, which is NOT an fmaf chain -- fp32-CLASS, not
+ *                          bit-compatible.  GEMM level, error relative to sum |a||b|: 2^-24.1 (K = 16) .. 2^-22.4 (K = 256);
+ *                          on operands spread over 2^(+-12) up to 7.5e-7, i.e. 2 - 3 x a sequential fp32 sum in the same
+ *                          k-block order (torch's own fp32 matmul: 8.7e-7 on the same operands); bound asserted:
+ *                          min(2^-20, 4 x sequential fp32).  Network level against float64: 0.73 .. 1.07 x the exact-f32
+ *                          path's error (WaveNet and SaShiMi, B = 1 .. 32, L = 16000), T = 200 trajectories within 3e-7
+ *                          of the f32 path's.  Results do not depend on the batch position of a clip (bitwise).
+ *                          Where no split instance exists (SaShiMi stages whose length is not a multiple of 4, channel
+ *                          counts the MFMA tiling does not cover, the pooling GEMMs, 3-tap training GEMMs) the f32
+ *                          kernels run: the tap "split_launches" reports how many GEMM launches of the last forward ran
+ *                          split and how many fell back.
  *               = "f16x3"  the same kernels with a 2-term fp16 split of power-of-two scaled operands (22 significand
  *                          bits per operand, three products: half the matrix work of bf16x6).  Inference only.  Accepted
- *                          by the same float64 criterion; activations beyond 2^11 overflow fp16 and yield NaN.
+ *                          by the same float64 criterion; activations beyond 2^11 overflow fp16 and yield NaN, and so
+ *                          does a WaveNet step-embedding row fc_t(e) beyond ~40 at C = 256 (it rides in an fp16 k-block
+ *                          times the weight scale).  An experiment: narrower than the reference's arithmetic, never a default.
  *   "conv_algo" = "winograd" (default) WaveNet residual layers (precision f32) with the dilated 3-tap convolution in
  *                          Winograd F(2,3) form along the dilation stride: 8 C^2 instead of 12 C^2 flop per position,
  *                          one extra fp32 rounding in the weights and in the inputs (same 1e-6 class error); the
