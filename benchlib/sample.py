@@ -176,17 +176,28 @@ def sample_bench(args, cfg, world, rank, dev, ddist, red_dev, extras=True, full=
             # profiles/r*_sashimi_traffic_<config>.json, used only if it was measured on THESE kernels -- same config, f32
             # tails (SQ_INSTS_MFMA x 4096 within 5 % of the tail flops computed above), whole steps (dispatches % blocks == 0)
             traffic, traffic_fc, traffic_note = None, None, None
-            if args.precision == "f32" and not args.batch:
+            if args.precision in ("f32", "bf16x6") and not args.batch:
                 import glob
-                for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sashimi_traffic_%s.json" % args.config)), reverse=True):
+                # fp32-equivalent flops per MFMA instruction: v_mfma_f32_32x32x2_f32 = 4096; six v_mfma_f32_32x32x16_bf16 (32768
+                # each) per fp32-equivalent product term under the 3-term split
+                per_inst = 4096.0 if args.precision == "f32" else 32768.0 / 6.0
+                pats = ["r*_sashimi_traffic_%s_%s.json" % (args.config, args.precision)]
+                if args.precision == "f32":
+                    pats.append("r*_sashimi_traffic_%s.json" % args.config)          # (rounds 4-5: f32 files carry no suffix)
+                tfiles = sorted((f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat))),
+                                key=lambda f: os.path.basename(f)[:3], reverse=True)
+                for tfile in tfiles:
                     tj = json.load(open(tfile))
                     ft, ff_ = tj["families"].get("s4_tail", {}), tj["families"].get("fftconv", {})
                     cnt = ft.get("sq_insts_mfma_per_launch")
                     if tj.get("config") != args.config or not ft.get("dispatches") or ft["dispatches"] % nblocks:
                         traffic_note = "%s refused: config / dispatch count" % os.path.basename(tfile)
-                    elif cnt is None or abs(cnt * 4096 * nblocks / flops - 1) > 0.05:
-                        traffic_note = "%s refused: SQ_INSTS_MFMA x 4096 x %d = %.4g vs tail flops %.4g" % (
-                            os.path.basename(tfile), nblocks, (cnt or 0) * 4096 * nblocks, flops)
+                    elif tj.get("precision", "f32") != args.precision:
+                        traffic_note = "%s refused: measured under precision=%s" % (os.path.basename(tfile), tj.get("precision"))
+                    elif cnt is None or abs(cnt * per_inst * nblocks / flops - 1) > 0.08:
+                        # (the split kernels' bias / correction k-blocks add a few per cent of MFMA instructions to the count)
+                        traffic_note = "%s refused: SQ_INSTS_MFMA x %.0f x %d = %.4g vs tail flops %.4g" % (
+                            os.path.basename(tfile), per_inst, nblocks, (cnt or 0) * per_inst * nblocks, flops)
                     else:
                         traffic = ft["hbm_bytes_per_launch"] * nblocks
                         traffic_fc = ff_.get("hbm_bytes_per_launch", 0) * nblocks if ff_.get("dispatches") else None
