@@ -177,7 +177,8 @@ def summary(result):
             out["C5 unet_d128 train B32/GPU"] = {"ms": r3(o.get("ms_per_step")), "f32_ms": r3(tr.get("ms_per_step")),
                                                  "f32_gemm_frac": r3((tr.get("roofline") or {}).get("frac")),
                                                  "f32_whole_step_frac": r3((tr.get("roofline") or {}).get("whole_step_frac")),
-                                                 "exposed_allreduce_ms": r3((tr.get("dp") or {}).get("exposed_ms"))}
+                                                 "exposed_allreduce_ms": r3((tr.get("dp") or {}).get("exposed_ms")),
+                                                 "f32_gpu_over_cpu": r3(tr.get("gpu_over_cpu"))}
     cb = result.get("cpu_baseline") or {}
     if cb:
         out["cpu"] = {"samples_per_s": r3((cb.get("best") or {}).get("value")), "cores": cb.get("cores"),
@@ -259,10 +260,10 @@ def extra_legs(args, world, rank, dev, ddist, red_dev):
             if args.cpu_train_baseline:
                 out[key]["cpu_baseline"] = cpu_train_baseline(dict(CONFIGS[a.config]))
                 out[key]["gpu_over_cpu"] = out[key]["value"] / out[key]["cpu_baseline"]["value"]
-            else:   # one oracle training step of unet_d128 at B = 1 is ~100 s of host time: beyond a default run's budget
-                out[key]["cpu_baseline"] = {"skipped": "one oracle training step (forward + autograd backward) at B=1 takes "
-                                                       "~100 s on the host: run with --cpu-train-baseline "
-                                                       "(measured once per round: profiles/r04_bench_c5train_cpu.json)"}
+            else:   # one oracle training step of unet_d128 at B = 1, L = 16000 is ~100 s of host time: the default run times a
+                    # BOUNDED sample instead -- one step on a 4000-sample clip through the same network (~25 s)
+                out[key]["cpu_baseline"] = cpu_train_baseline(dict(CONFIGS[a.config]), sample_L=4000)
+                out[key]["gpu_over_cpu"] = out[key]["value"] / out[key]["cpu_baseline"]["value"]
     except Exception as e:      # noqa: BLE001
         out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()

@@ -241,24 +241,32 @@ def cpu_whole_host(config_name, threads, nsteps=2):
                       "after a warm-up, common start; rate = workers x L / (T x slowest worker's mean step)" % (n, threads, nsteps)}
 
 
-def cpu_train_baseline(cfg, seconds_budget=30.0):
+def cpu_train_baseline(cfg, seconds_budget=30.0, sample_L=None):
     """One `train.py:118-143`-style step of the oracle on the host cores at B=1: q-sample, forward, MSE against the noise,
     backward through torch autograd of the reference-equivalent CPU graph (no optimizer: its cost is negligible beside
     the backward).  Bounded sample: a first step that already takes > 8 s IS the sample (it includes the one-time
-    allocator warm-up), otherwise a second step is timed."""
+    allocator warm-up), otherwise a second step is timed.
+    sample_L: the bounded form for the default run -- ONE step on a clip of sample_L samples through the same network built
+    for that length (the oracle regenerates every S4 kernel in every call, 88 % of its step and proportional to the clip
+    length: a full 16000-sample step is ~100 s of host time, a 4000-sample one ~25 s); the rate is samples / second of that
+    step, so it scales to the metric's unit directly."""
     from oracle import sashimi as osa
     from oracle import wavenet as own
     from diffwave_sashimi_amd.models import construct_model
     from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
     ncpu = os.cpu_count() or 1
-    th = min(32, ncpu)
+    quota = cpu_quota()["cpu_quota_cpus"]
+    th = min(32, ncpu) if quota is None else max(1, min(32, ncpu, int(quota)))     # more runnable threads than the quota = throttled
     torch.set_num_threads(th)
     torch.manual_seed(0)
-    net = construct_model(dict(cfg["model"]))
+    mcfg = dict(cfg["model"])
+    L, T = cfg["L"], cfg["diffusion"]["T"]
+    if sample_L and mcfg["_name_"] == "sashimi":
+        mcfg["L"] = L = int(sample_L)
+    net = construct_model(mcfg)
     leaf = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v.clone())
             for k, v in net.state_dict().items()}
     fwd = own.wavenet_forward if cfg["model"]["_name_"] == "wavenet" else osa.sashimi_forward
-    L, T = cfg["L"], cfg["diffusion"]["T"]
     dh = calc_diffusion_hyperparams(**cfg["diffusion"])
     g = torch.Generator().manual_seed(7)
     audio = (torch.rand(1, 1, L, generator=g) * 2 - 1) * 0.3
@@ -272,19 +280,21 @@ def cpu_train_baseline(cfg, seconds_budget=30.0):
         z = torch.randn(audio.shape, generator=g)
         ab = dh["Alpha_bar"][ts]
         xt = torch.sqrt(ab) * audio + torch.sqrt(1 - ab) * z          # `train.py:221`
-        eps = fwd(leaf, cfg["model"], xt, ts.view(1, 1))
+        eps = fwd(leaf, mcfg, xt, ts.view(1, 1))
         loss = torch.nn.functional.mse_loss(eps, z)
         loss.backward()
         return time.perf_counter() - t0
 
     times = [one()]
-    if times[0] < 8.0 or times[0] * 2 < seconds_budget:
+    if not sample_L and (times[0] < 8.0 or times[0] * 2 < seconds_budget):
         times.append(one())
     t = times[-1]
     return {"value": L / t, "unit": "training audio samples/s", "cores": th, "host_cpus": ncpu, "kind": "port",
             "sample": "%d training step(s) (q-sample + forward + MSE + autograd backward of the oracle) at B=1, L=%d with %d "
-                      "threads; the last one is reported" % (len(times), L, th),
-            "ms_per_step_b1": t * 1e3, "steps_ms": [x * 1e3 for x in times], "cpu_model": _cpu_model()}
+                      "threads; the last one is reported%s" % (len(times), L, th, (
+                          " -- bounded sample: a %d-sample clip through the same network built for that length (config: L=%d; "
+                          "full length measured once per round, profiles/r04_bench_c5train_cpu.json)" % (L, cfg["L"])) if sample_L else ""),
+            "ms_per_step_b1": t * 1e3, "steps_ms": [x * 1e3 for x in times], "cpu_model": _cpu_model(), "cpu_quota_cpus": quota}
 
 
 def _cpu_model():
