@@ -64,10 +64,9 @@ struct PwMfmaArgs {
 };
 
 bool s4_tail_mfma_supported(int H, int ff);
-int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s);
-// launches of launch_s4_tail_mfma since the last reset that ran a split-precision instance / an exact-f32 one (host-side
-// counters behind the tap "split_launches": which arithmetic a forward really ran)
-void s4_tail_launch_counts(int* split, int* f32, bool reset);
+// *ran_split (optional) reports whether a split-precision instance was launched or an exact-f32 one (the models count them
+// behind the tap "split_launches": which arithmetic a forward really ran)
+int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s, bool* ran_split = nullptr);
 bool s4_tail_chain_supported(int H, int ff);
 int launch_s4_tail_chain(int H, const S4TailArgs& a, hipStream_t s);
 int launch_chain_permute_cols(const float* w, float* out, int M, int K, hipStream_t s);

@@ -672,18 +672,10 @@ bool s4_tail_mfma_supported(int H, int ff) {
     return ff == 2 && (H == 32 || H == 64 || H == 128 || H == 256 || H == 512);
 }
 
-static int g_tail_split = 0, g_tail_f32 = 0;
-void s4_tail_launch_counts(int* split, int* f32, bool reset) {
-    if (split) *split = g_tail_split;
-    if (f32) *f32 = g_tail_f32;
-    if (reset) g_tail_split = g_tail_f32 = 0;
-}
 static int launch_s4_tail_mfma_impl(int H, const S4TailArgs& a, hipStream_t s, bool* ran_split);
-int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s) {
-    bool ran_split = false;
-    const int rc = launch_s4_tail_mfma_impl(H, a, s, &ran_split);
-    ++(ran_split ? g_tail_split : g_tail_f32);
-    return rc;
+int launch_s4_tail_mfma(int H, const S4TailArgs& a, hipStream_t s, bool* ran_split) {
+    bool dummy = false;
+    return launch_s4_tail_mfma_impl(H, a, s, ran_split ? ran_split : &dummy);
 }
 static int launch_s4_tail_mfma_impl(int H, const S4TailArgs& a, hipStream_t s, bool* ran_split) {
     // Tile shapes <H, waves along rows, waves along positions, 32-position tiles per wave, workgroups per CU the register
@@ -761,6 +753,10 @@ int launch_row_sum(const float* W, float* rs, int O, int K, hipStream_t s) {
 // ---------------------------------------------------------------------------
 // LN: the instance with the LayerNorm epilogue.  (At MT = 4 the accumulators alone are 128 registers and the epilogue's
 // statistics spill ~330 bytes; still 9 us cheaper than the plain instance + a LayerNorm launch: 76.8 vs 69.3 + 16.5 us.)
+// (Round 6, measured and not kept: the same GEMM on the bf16 matrix cores under precision = bf16x6 -- gemm_slab_split is a drop-in
+// for the slab call below.  Same-box A/B: null, C3 4.93 -> 4.96 ms, C4 3.794 -> 3.784 ms per step; the M = 256 DownPool instance
+// got 10 us SLOWER (256 VGPRs, spills).  The kernel is bound by its register-staged gather and its epilogue, not by the fp32
+// MFMA time: profiles/r06_ab_pool_split_dropped.txt.)
 template <int MT, int MODE, bool LN>
 __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(PwMfmaArgs a) {
     constexpr int P = 64, NT = 2, KC = 64;

@@ -782,7 +782,7 @@ struct SashimiModel : dws_model {
     }
 
     // everything of the block after the S4 convolution (sashimi.py:177-184, s4.py:1435)
-    int generic_tails = 0;
+    int n_tail_split = 0, n_tail_f32 = 0;     // block-tail launches of the last forward, by arithmetic
     int run_tail(SLayer* l, Stage* st, const float* x, const float* addend, const OutLN* next, hipStream_t s) {
         const int H = l->H, Ls = l->L, nB = (int)B;
         const std::string& p = l->prefix;
@@ -807,9 +807,12 @@ struct SashimiModel : dws_model {
                 t.e_next = next->e; t.e_stride = next->e_stride;
                 t.e_step = next->e_step; t.e_tstride = next->e_tstride;
             }
-            return launch_s4_tail_mfma(H, t, s);
+            bool ran_split = false;
+            const int rc = launch_s4_tail_mfma(H, t, s, &ran_split);
+            ++(ran_split ? n_tail_split : n_tail_f32);
+            return rc;
         }
-        ++generic_tails;       // plain-FMA block (channel counts the MFMA tiling does not cover): no split instance
+        ++n_tail_f32;          // plain-FMA block (channel counts the MFMA tiling does not cover): no split instance
         DWS_TRY(launch_pw_glu_res(st->g.f(), P(p + ".layer.output_linear.0.weight"), P(p + ".layer.output_linear.0.bias"),
                                   x, melBm ? l->melc.f() : nullptr, melBm > 1 ? 1 : 0, st->x1.f(), nB, H, Ls, s));
         DWS_TRY(launch_ln(st->x1.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), nullptr, 0, st->n2.f(), nB, H, Ls, (size_t)Ls, s));
@@ -904,8 +907,7 @@ struct SashimiModel : dws_model {
         if (dirty) DWS_TRY(commit(s));
         DWS_CHECK(!step_idx || (tab_T > 0 && tab_version == commit_version), DWS_ERR_STATE, "step-table forward without a current table");
         DWS_CHECK(step_idx || steps, DWS_ERR_INVALID, "forward: steps == null");
-        s4_tail_launch_counts(nullptr, nullptr, true);     // tap "split_launches": which arithmetic THIS forward's tails ran
-        generic_tails = 0;
+        n_tail_split = n_tail_f32 = 0;     // tap "split_launches": which arithmetic THIS forward's tails ran
         if (!step_idx) DWS_TRY(embed_rows(steps, (int)B, emb.f(), h1.f(), h2.f(), part_t.f(), s));
         std::vector<const float*> stack;  // LIFO skip stack (sashimi.py:293-307)
         const float* x = x_init.f();
@@ -1445,10 +1447,8 @@ struct SashimiModel : dws_model {
         DWS_CHECK(B > 0, DWS_ERR_STATE, "read_tap before prepare/forward");
         const std::string t(tap);
         if (t == "split_launches") {   // [block tails of the last forward that ran a split instance, those that ran exact-f32 kernels]
-            DWS_CHECK(capacity >= 2, DWS_ERR_INVALID, "tap buffer too small");
-            int sp = 0, f3 = 0;
-            s4_tail_launch_counts(&sp, &f3, false);
-            const float v[2] = {(float)sp, (float)(f3 + generic_tails)};
+            DWS_CHECK(capacity >= 2, DWS_ERR_INVALID, "tap buffer too small");     // (the pooling GEMMs are exact f32 under every precision)
+            const float v[2] = {(float)n_tail_split, (float)n_tail_f32};
             DWS_HIP(hipMemcpyAsync(dst, v, 8, hipMemcpyHostToDevice, s));
             DWS_HIP(hipStreamSynchronize(s));
             return DWS_OK;

@@ -45,6 +45,12 @@ def test_sashimi_bf16x6_error_against_float64_is_that_of_the_f32_path(gpu, name,
         again = net((audio.to(gpu), steps.to(gpu))).cpu()
     assert torch.equal(again, out["f32"][0])                 # switching back restores the f32 path bit for bit
     assert not torch.equal(out["bf16x6"][0], out["f32"][0])  # and the split tails really are another arithmetic
+    with torch.no_grad():      # which arithmetic ran: every block tail of this network on a split instance, none fell back
+        net.set_option("precision", split)
+        net((audio.to(gpu), steps.to(gpu)))
+        tails = net.read_tap("split_launches", (2,)).cpu().tolist()
+        net.set_option("precision", "f32")
+    assert tails == [5.0 * cfg["n_layers"], 0.0], tails
     e = {p: (rel_err(out[p][0], ref), rel_err(out[p][1], ref_pre)) for p in out}
     rms = {p: float(((out[p][1].double() - ref_pre) ** 2).mean().sqrt() / (ref_pre ** 2).mean().sqrt()) for p in out}
     direct = rel_err(out["bf16x6"][1], out["f32"][1])
