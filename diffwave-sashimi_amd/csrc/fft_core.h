@@ -517,6 +517,25 @@ DWS_HD void stage16_fwd_halves(c2 (&x)[16], const Tw16<true>& tl, const Tw16<tru
     }
 }
 
+// the same stage on ONE half (HALF = 0: x[0..7], 1: x[8..15]) with that half's table alone: a caller short of registers builds the
+// two Tw16 tables one after the other instead of holding both (fftcorr_blk_kernel)
+template <int BIT, int HALF>
+DWS_HD void stage16_fwd_half(c2 (&x)[16], const Tw16<true>& t) {
+    static_assert((BIT == 0 || BIT == 1) && (HALF == 0 || HALF == 1), "tail stages");
+#pragma unroll
+    for (int i = 8 * HALF; i < 8 * HALF + 8; ++i) {
+        if (i & (1 << BIT)) continue;
+        const int j = i + (1 << BIT);
+        const int hi = i >> (BIT + 1), nb = 3 - BIT;
+        int rv = 0;
+        for (int q = 0; q < nb; ++q) rv |= ((hi >> q) & 1) << (nb - 1 - q);
+        const int e = rv << BIT, rot = e >> 2, sel = e & 3;
+        const c2 w = BIT == 1 ? t.T2[sel >> 1] : t.T1[sel];
+        if (rot) bfly<false, 1, false, false>(x[i], x[j], w);
+        else bfly<false, 0, false, false>(x[i], x[j], w);
+    }
+}
+
 // What the pass reads from global memory before it can start: the first half's tables and the two tail twiddles.  A kernel
 // may request them ahead of the barrier in front of the pass (TailPre::load) and hand them in.
 struct TailPre {

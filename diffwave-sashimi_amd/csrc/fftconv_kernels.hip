@@ -475,6 +475,161 @@ __global__ __launch_bounds__(THREADS) void fftcorr_kernel(FftCorrArgs a) {
     }
 }
 
+// The same kernel-gradient partials on the BLOCK / MIRROR-BLOCK pair stage of fftconv_kernel (round 6; even plans, one 16-point
+// block per thread).  Per transform the forward radix-4 tail and the real-row bins are ONE pass straight from registers: thread t
+// reads the r3 = 0 half of block t and the r3 = 1 half of its mirror block t' (fft_core.h: pass_tail_pointwise -- contiguous,
+// conflict-free LDS runs), applies the two tail stages with each half's tail twiddle and holds all eight pairs (x[e], x[15 - e]),
+// e even, whose tables are adjacent entries twp[8 t + e/2] / twp[8 t' + e/2].  Nothing is written back to LDS: the separate tail
+// pass, its barrier and the eight scattered bit-reversed pair reads per thread of fftcorr_kernel are gone.  The bins of U are parked
+// per thread ([j][t]: coalesced) in the block's own output slab at M = 16384 (registers), results overwrite it after the last sample.
+template <int LOG2M>
+__global__ __launch_bounds__((1 << LOG2M) / 16) void fftcorr_blk_kernel(FftCorrArgs a) {
+    using P = FftPlan<LOG2M>;
+    static_assert(!P::ODD, "block-order pair stage: even plans");
+    constexpr int M = 1 << LOG2M, THREADS = M / 16;
+    constexpr bool TAILS = P::TAIL4;
+    constexpr bool PARK = LOG2M >= 14;
+    extern __shared__ __attribute__((aligned(16))) c2 X[];
+    const int tid0 = threadIdx.x, h = blockIdx.x, bs = blockIdx.y;
+    const int L = a.L;
+    c2 ua[PARK ? 1 : 8], ub[PARK ? 1 : 8], pa[8], pb[8];
+    c2* __restrict__ o = a.part + ((size_t)bs * a.H + h) * (M + 1);
+    // the self-paired bins (k = 0, M, M/2: thread 0's pair 0) live in LDS, not in eight registers of every thread: the M = 16384
+    // instance runs at the 128-VGPR limit of a 1024-thread workgroup.  [u0, uM, uh.x, uh.y | p0, pM, ph.x, ph.y]; thread 0 only.
+    __shared__ float selfp[8];
+    if (tid0 == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) selfp[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pa[i] = pb[i] = mk(0.f, 0.f);
+    const int b_end = min(a.B, (bs + 1) * a.bchunk);
+    NoStamp st;
+
+    // forward transform of one zero-padded row up to (not including) the radix-4 tail: fftconv_kernel's sequence
+    auto forward = [&](const float* row) {
+        const int tid = opaque(tid0);
+        __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, L * 4, 0x00020000);
+        c2 x[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            x[r] = __builtin_bit_cast(c2, __builtin_amdgcn_raw_buffer_load_b64(rU, (tid + (M / 16) * r) * 8, 0, 0));
+        const c2 ph1 = fwd_twiddle<LOG2M, 1, false>(a.tw, opaque(tid));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 8; r < 16; ++r) x[r] = mk(0.f, 0.f);
+        fft16<false, false, true>(x, mk(1.f, 0.f));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[pidx(tid) + (M / 16 + M / 256) * r] = x[r];
+        __syncthreads();
+        fft_forward_chain<LOG2M, 1, false>(X, a.tw, tid, st, ph1, [] {});
+    };
+    // tail (plans with one) + the eight pairs of this thread: f(j, is_self, zk, zm, wk) for j = 0..7; pair j's even position is
+    // 16 t + 2 j (j < 4) / 16 t' + 2 j (j >= 4), its table index 8 t + j / 8 t' + j
+    auto pairs = [&](auto&& f) {
+        const int t = opaque(tid0), tm = mirror_block(t);
+        // tables of the four pairs whose even position lies in block t first (their round trip runs under the LDS reads and
+        // the tail butterflies); the other four (block t') are requested once the butterflies are done: all eight at once
+        // cost eight more live registers at the 128-VGPR limit of a 1024-thread workgroup (pass_tail_pointwise does the same)
+        c2 wk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wk[i] = a.twp[8 * t + i];
+        c2 x[16];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) x[d] = X[17 * t + d];
+#pragma unroll
+        for (int d = 8; d < 16; ++d) x[d] = X[17 * tm + d];
+        if constexpr (TAILS) {
+            const c2 taul = a.tw[brev_bits(t, LOG2M - 4)], tauh = a.tw[brev_bits(tm, LOG2M - 4)];
+            {   // one half at a time: each tail-twiddle table (6 complex) lives only while its half is transformed
+                const Tw16<true> tl(opaque(taul));
+                stage16_fwd_half<1, 0>(x, tl);
+                stage16_fwd_half<0, 0>(x, tl);
+            }
+            sched_fence();
+            {
+                const Tw16<true> th(opaque(tauh));
+                stage16_fwd_half<1, 1>(x, th);
+                stage16_fwd_half<0, 1>(x, th);
+            }
+            sched_fence();
+        }
+        c2 wk2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wk2[i] = a.twp[8 * tm + 4 + i];
+        if (t == 0) {   // block 0 pairs inside itself (pass_tail_pointwise): route its odd positions into the generic slots
+            const c2 x1 = x[1], x3 = x[3], x5 = x[5], x7 = x[7], x9 = x[9], x11 = x[11], x13 = x[13], x15 = x[15];
+            x[15] = x1; x[13] = x3; x[11] = x7; x[9] = x5; x[7] = x15; x[5] = x13; x[3] = x11; x[1] = x9;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f(j, j == 0 && t == 0, x[2 * j], x[15 - 2 * j], wk[j]);
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);     // bound the parked-bin loads in flight (registers)
+        }
+#pragma unroll
+        for (int j = 4; j < 8; ++j) {
+            f(j, false, x[2 * j], x[15 - 2 * j], wk2[j - 4]);
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+#pragma unroll 1
+    for (int b = bs * a.bchunk; b < b_end; ++b) {
+        forward(a.u + ((size_t)b * a.H + h) * L);
+        pairs([&](int j, bool self, c2 zk, c2 zm, c2 wk) {
+            if (self) {
+                selfp[0] = zk.x + zk.y; selfp[1] = zk.x - zk.y; selfp[2] = zm.x; selfp[3] = -zm.y;      // A[0], A[M], A[M/2] = conj(position 1)
+            } else {
+                c2 k1, k2;
+                pair_bins(zk, zm, wk, k1, k2);
+                if (PARK) {
+                    o[(2 * j) * THREADS + tid0] = k1;
+                    o[(2 * j + 1) * THREADS + tid0] = k2;
+                } else {
+                    ua[PARK ? 0 : j] = k1;
+                    ub[PARK ? 0 : j] = k2;
+                }
+            }
+        });
+        __syncthreads();     // every thread has read its halves: the next transform may overwrite X
+        forward(a.da + ((size_t)b * a.H + h) * L);
+        pairs([&](int j, bool self, c2 zk, c2 zm, c2 wk) {
+            if (self) {
+                selfp[4] = fmaf(selfp[0], zk.x + zk.y, selfp[4]);
+                selfp[5] = fmaf(selfp[1], zk.x - zk.y, selfp[5]);
+                const c2 ph = cadd(mk(selfp[6], selfp[7]), cmulc(cconj(zm), mk(selfp[2], selfp[3])));
+                selfp[6] = ph.x; selfp[7] = ph.y;
+            } else {
+                c2 dk, dm;
+                pair_bins(zk, zm, wk, dk, dm);
+                const c2 uka = PARK ? o[(2 * j) * THREADS + tid0] : ua[PARK ? 0 : j];
+                const c2 ukb = PARK ? o[(2 * j + 1) * THREADS + tid0] : ub[PARK ? 0 : j];
+                pa[j] = cadd(pa[j], cmulc(dk, uka));   // dA * conj(U)
+                pb[j] = cadd(pb[j], cmulc(dm, ukb));
+            }
+        });
+        __syncthreads();
+    }
+    // natural-order bins: pair j of thread t holds A[k], A[M - k], k = brev(its even position)
+    {
+        const int t = tid0, tm = mirror_block(t);
+        if (PARK) __syncthreads();      // (the parked bins of the last sample have been read by their owner only: no hazard; kept cheap)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j == 0 && t == 0) {
+                o[0] = mk(selfp[4], 0.f);
+                o[M] = mk(selfp[5], 0.f);
+                o[M / 2] = mk(selfp[6], selfp[7]);
+            } else {
+                const int p = (j < 4 ? 16 * t : 16 * tm) + 2 * j;
+                const int k = brev(p, LOG2M);
+                o[k] = pa[j];
+                o[M - k] = pb[j];
+            }
+        }
+    }
+}
+
 // Rows longer than the transform (FftConvSegArgs): block = (row, output segment j).  Three input segments (j, j-1, j+1)
 // go through the forward transform; their real-row bins times the matching kernel spectrum accumulate in registers
 // (16 pairs per thread at 512 threads); the sum is re-packed into LDS, inverse-transformed, and its first half is output
@@ -767,6 +922,20 @@ static int launch_fcorr(const FftCorrArgs& a, hipStream_t s) {
     // in the output slab) -- rounds 2-3 ran two groups per thread on 512 threads there (the scalar core needed 256 VGPRs).
     // DWS_FFTCORR_512=1 keeps that shape (A/B runs).
     static const bool half = std::getenv("DWS_FFTCORR_512") != nullptr;
+    static const bool old = std::getenv("DWS_FFTCORR_OLD") != nullptr;      // same-box A/B: the scattered pair stage of rounds 1-5
+    if constexpr (!FftPlan<LOG2M>::ODD) {
+        if (!old && !half) {
+            auto kern = fftcorr_blk_kernel<LOG2M>;
+            static bool attrb_dev[DWS_MAX_DEVICES] = {};
+            bool& attrb = attrb_dev[current_device_slot()];
+            if (!attrb) {
+                DWS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+                attrb = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(a.H, ceil_div(a.B, a.bchunk)), dim3(C::M / 16), C::LDS, s, a);
+            return DWS_OK;
+        }
+    }
     if (LOG2M >= 14 && half) {
         constexpr int TH = C::THREADS > 512 ? 512 : C::THREADS;
         auto kern = fftcorr_kernel<LOG2M, TH>;
