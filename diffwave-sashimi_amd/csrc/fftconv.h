@@ -21,6 +21,8 @@ struct FftConvArgs {
     float* pre;         // also store the pre-activation conv + D u
     int conj_k;         // multiply by conj(K_f): the adjoint (correlation) of the convolution
     int no_act;         // g = conv + D u without the GELU
+    float* rowsum;      // also rowsum[b * rowsum_bstride + h] = sum_l g[b,h,l] (the adjoint pass: d fc_t(e)[b,h] = sum_l du[b,h,l],
+    int rowsum_bstride; //   `sashimi.py:151`); even plans only (fftconv_rowsum_supported): a workgroup owns the whole row
     unsigned long long* trace;   // DWS_FFT_TRACE=1 only: s_memtime stamps [workgroup][wave][row][slot] (fftconv_kernels.hip)
 };
 
@@ -35,6 +37,7 @@ struct FftCorrArgs {
     int B, H, L, bchunk;
 };
 int launch_fftcorr(int log2m, const FftCorrArgs& a, hipStream_t s);
+bool fftconv_rowsum_supported(int log2m);   // FftConvArgs::rowsum is honoured for this transform size
 
 // Rows longer than the largest in-LDS transform (L > 16384: vocoding lengths, `generate.py:156`): segments of
 // S = 16384 samples; output segment j = first half of IFFT(A_j K_f + A_{j-1} Kc' + A_{j+1} Ka') where A_i is the spectrum

@@ -235,7 +235,9 @@ struct RowSchedule {
 // FUSED (plans that end in a radix-4 tail, one 16-point group per thread): forward tail + pair stage + inverse tail are ONE
 // pass (fft_core.h: pass_tail_pointwise) -- a row of M = 16384 goes through LDS in six round trips and six barriers
 // instead of eight and nine.
-template <int LOG2M, int THREADS, bool TRACE = false, bool FUSED = false>
+// RSUM (training, the adjoint pass): the row's sum over its L outputs leaves with it (FftConvArgs::rowsum) -- the values are in
+// registers in the bottom pass, a separate rowsum_bc launch read the whole tensor again (1.5 ms of a C5 step).
+template <int LOG2M, int THREADS, bool TRACE = false, bool FUSED = false, bool RSUM = false>
 __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     using P = FftPlan<LOG2M>;
     static_assert(!TRACE || !P::ODD, "phase stamps: even sizes only");
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
     constexpr int M = 1 << LOG2M;
     constexpr bool DIRECT = !P::ODD;
     extern __shared__ __attribute__((aligned(16))) c2 X[];  // M + M/16 complex
+    static_assert(!RSUM || !FftPlan<LOG2M>::ODD, "row sums: even plans (the bottom pass holds the outputs in registers)");
+    __shared__ float rsum_w[RSUM ? (THREADS + 63) / 64 : 1];
     const int tid = threadIdx.x;
     const int L = a.L, Lc = L / 2;  // L even
     constexpr int NG = (1 << LOG2M) / 16 / THREADS;
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
                     uu[r] = __builtin_bit_cast(c2, __builtin_amdgcn_raw_buffer_load_b64(rUu, (g + (M / 16) * r) * 8, 0, 0));
+                float rs = 0.f;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int vo = (g + (M / 16) * r) * 8;
@@ -363,6 +368,12 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
                     if (a.pre) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rP, vo, 0, 0);
                     const c2 o = a.no_act ? v : mk(gelu_f(v.x), gelu_f(v.y));
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rG, vo, 0, 0);
+                    if constexpr (RSUM) rs += (vo < L * 4) ? (o.x + o.y) : 0.f;      // (L even: a pair lies inside the row or past it)
+                }
+                if constexpr (RSUM) {     // lanes -> wave (fixed order), waves meet in LDS behind the closing barrier
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) rs += __shfl_xor(rs, off);
+                    if ((tid & 63) == 0) rsum_w[tid >> 6] = rs;
                 }
             }
             st();
@@ -371,6 +382,14 @@ __global__ __launch_bounds__(THREADS) void fftconv_kernel(FftConvArgs a) {
             for (int j = tid; j < Lc; j += THREADS) finish(j, X[pidx(j)], u2[j]);
         }
         __syncthreads();   // the next row overwrites X
+        if constexpr (RSUM) {
+            if (tid == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < (THREADS + 63) / 64; ++w) t += rsum_w[w];
+                a.rowsum[(size_t)b * a.rowsum_bstride + h] = t;
+            }
+        }
         // (lgkmcnt(0) + s_barrier instead -- nobody needs this row's global stores to have landed, and __syncthreads()
         // waits for them -- measured no different: 80.5 vs 80.6 us)
         st();
@@ -892,9 +911,17 @@ static int launch_fc(const FftConvArgs& a_in, hipStream_t s) {
     // A/B switch, read once: DWS_FFT_NO_FUSED_TAIL=1 (separate tail / pair / tail passes, scalar pair arithmetic)
     static const bool fused = C::FUSED && getenv("DWS_FFT_NO_FUSED_TAIL") == nullptr;
     auto kern = fused ? fftconv_kernel<LOG2M, C::THREADS, false, C::FUSED> : fftconv_kernel<LOG2M, C::THREADS>;
+    if constexpr (!FftPlan<LOG2M>::ODD) {
+        if (a_in.rowsum) kern = fftconv_kernel<LOG2M, C::THREADS, false, C::FUSED, true>;     // the training adjoint pass
+    } else {
+        DWS_CHECK(a_in.rowsum == nullptr, DWS_ERR_UNSUPPORTED, "fftconv: row sums need an even plan (log2 M = %d)", LOG2M);
+    }
     static bool attr_dev[DWS_MAX_DEVICES] = {};
     bool& attr = attr_dev[current_device_slot()];
     if (!attr) {
+        if constexpr (!FftPlan<LOG2M>::ODD)
+            DWS_HIP(hipFuncSetAttribute((const void*)fftconv_kernel<LOG2M, C::THREADS, false, C::FUSED, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         DWS_HIP(hipFuncSetAttribute((const void*)fftconv_kernel<LOG2M, C::THREADS, false, C::FUSED>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         DWS_HIP(hipFuncSetAttribute((const void*)fftconv_kernel<LOG2M, C::THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -989,6 +1016,8 @@ int launch_fftconv(int log2m, const FftConvArgs& a, hipStream_t s) {
     ProfileScope ps("fftconv", s);
     DWS_FC_DISPATCH(launch_fc, a, s);
 }
+
+bool fftconv_rowsum_supported(int log2m) { return log2m >= 10 && log2m <= 14 && (log2m & 1) == 0; }
 
 int launch_fftcorr(int log2m, const FftCorrArgs& a, hipStream_t s) {
     ProfileScope ps("fftcorr", s);

@@ -1310,6 +1310,8 @@ struct SashimiModel : dws_model {
         const int nB = (int)B, nL = (int)L;
         const int nnodes = (int)plan.size() + 1;
         std::vector<char> written(nnodes, 0);
+        std::vector<float*> gp(nnodes);       // where each node's gradient lives during THIS backward (a skip node may adopt a dy buffer)
+        for (int n = 0; n < nnodes; ++n) gp[n] = node_grad(n);
         size_t wmax = (size_t)D * D;
         for (auto* l : all) {
             if (l->kind == L_BLOCK) wmax = std::max(wmax, (size_t)2 * l->H * l->H * std::max(1, FF));
@@ -1330,7 +1332,7 @@ struct SashimiModel : dws_model {
         DWS_TRY(gemm(tAfT.f(), D, D, dyb.f(), dnf.f(), nL, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
         {
             const int last = nnodes - 1;
-            DWS_TRY(launch_ln_bwd(node_act(last), dnf.f(), P("norm.m"), P("norm.s"), nullptr, node_grad(last), 0, lnpart.f(),
+            DWS_TRY(launch_ln_bwd(node_act(last), dnf.f(), P("norm.m"), P("norm.s"), nullptr, gp[last], 0, lnpart.f(),
                                   nB, D, nL, s));
             DWS_TRY(ln_scalars("norm", nB * ceil_div(nL, 64), s));
             written[last] = 1;
@@ -1340,8 +1342,8 @@ struct SashimiModel : dws_model {
             const Exec& e = plan[i];
             SLayer* l = e.l;
             const float* x = node_act(e.in_node);
-            const float* dy = node_grad(i + 1);
-            float* din = node_grad(e.in_node);
+            const float* dy = gp[i + 1];
+            float* din = gp[e.in_node];
             DWS_CHECK(written[i + 1], DWS_ERR_STATE, "backward: no gradient reached node %d", i + 1);
             const std::string& p = l->prefix;
             if (l->kind == L_BLOCK) {
@@ -1386,10 +1388,13 @@ struct SashimiModel : dws_model {
                 fa.tw = (const c2*)t->tw.p; fa.twp = (const c2*)t->twp.p;
                 fa.kfa = (const c2*)l->kfa.p; fa.kfb = (const c2*)l->kfb.p; fa.kfs = (const c2*)l->kfs.p;
                 fa.B = nB; fa.H = H; fa.L = Ls;
+                // d fc_t(e)[b, h] = sum_l du[b, h, l] leaves with the row (a workgroup owns it) where the plan allows
+                const bool rs_fused = fftconv_rowsum_supported(l->log2m) && getenv("DWS_NO_ROWSUM_FUSION") == nullptr;
+                if (rs_fused) { fa.rowsum = dpt.f() + l->pt_off; fa.rowsum_bstride = (int)pt_total; }
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
                 DWS_TRY(kernel_backward(l, st->dh.f(), s));
                 // u = LN1(x) + fc_t(e): dx = dx1 + LN'(du)
-                DWS_TRY(launch_rowsum_bc(st->du.f(), dpt.f() + l->pt_off, pt_total, nB, H, Ls, s));
+                if (!rs_fused) DWS_TRY(launch_rowsum_bc(st->du.f(), dpt.f() + l->pt_off, pt_total, nB, H, Ls, s));
                 DWS_TRY(launch_ln_bwd(x, st->du.f(), P(p + ".norm1.m"), P(p + ".norm1.s"), st->dx1.f(), din, written[e.in_node],
                                       lnpart.f(), nB, H, Ls, s));
                 DWS_TRY(ln_scalars(p + ".norm1", nblk, s));
@@ -1413,7 +1418,15 @@ struct SashimiModel : dws_model {
                 written[e.in_node] = 1;
             }
             if (e.add_node >= 0) {  // the skip connection receives the same gradient
-                DWS_TRY(launch_add_into(dy, node_grad(e.add_node), written[e.add_node], node_numel(e.add_node), s));
+                // The up path runs first in backward, so the skip node has no gradient yet: instead of COPYING dy into its buffer
+                // (15 copies of up to 262 MB per C5 step, 1.5 ms) the node ADOPTS this layer's dy buffer -- everything of this
+                // layer that reads dy is already enqueued, and the node's own consumer accumulates into it in place later.
+                static const bool copy_skip = getenv("DWS_SKIP_GRAD_COPY") != nullptr;      // same-box A/B switch
+                if (!written[e.add_node] && !copy_skip && node_numel(e.add_node) == node_numel(i + 1)) {
+                    gp[e.add_node] = const_cast<float*>(dy);
+                } else {
+                    DWS_TRY(launch_add_into(dy, gp[e.add_node], written[e.add_node], node_numel(e.add_node), s));
+                }
                 written[e.add_node] = 1;
             }
             DWS_TRY(grad_point(s));   // staged hand-over: buckets whose last gradient this layer produced leave now
@@ -1422,8 +1435,8 @@ struct SashimiModel : dws_model {
         // ---- init_conv: x0 = relu(Wi audio + bi)
         const size_t nact = (size_t)B * D * L;
         DWS_CHECK(written[0], DWS_ERR_STATE, "backward: no gradient reached the init conv");
-        DWS_TRY(launch_relu_bwd(dx_init.f(), x_init.f(), nact, s));
-        DWS_TRY(wgrad(dx_init.f(), train_audio, D, Cin, nL, 0, dWfold.f(), G("init_conv.0.conv.bias"), s));
+        DWS_TRY(launch_relu_bwd(gp[0], x_init.f(), nact, s));      // (node 0 is a skip node too: its gradient may live in an adopted buffer)
+        DWS_TRY(wgrad(gp[0], train_audio, D, Cin, nL, 0, dWfold.f(), G("init_conv.0.conv.bias"), s));
         DWS_TRY(wn_bwd("init_conv.0.conv", dWfold.f(), D, Cin, s));
 
         // ---- step embedding: per-block fc_t (stacked), then the shared swish MLP
