@@ -16,6 +16,22 @@ REL_TOL = 1e-3
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _fit_cpu_threads_to_the_quota()
+
+
+def _fit_cpu_threads_to_the_quota():
+    """The CPU oracle is the checker of every parity test.  torch sizes its thread pool by the host's logical CPUs (256 on the
+    GPU box) while the container may run 16 of them at a time (cgroup cpu.max): hundreds of runnable threads under a 16-CPU
+    quota are throttled, not parallel -- an oracle forward then takes several times longer.  Size the pool to the quota."""
+    try:
+        import torch
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, int(float(q) / float(per)))
+            if n < torch.get_num_threads():
+                torch.set_num_threads(n)
+    except Exception:       # noqa: BLE001 -- no cgroup v2 / no torch: leave the defaults
+        pass
 
 
 def load_golden(name):

@@ -97,3 +97,23 @@ def test_precision_switch_keeps_the_conditioner_of_the_same_mel_tensor(gpu, back
     assert torch.equal(back, first) and torch.equal(again, first)
     assert rel_err(nomel, first) > 1e-2                           # the conditioner matters for this case
     assert rel_err(split, first) < 1e-5 and not torch.equal(split, first)
+
+
+def test_config2_network_T200_trajectory_at_full_length(gpu):
+    """BASELINE config 2's own network (wnet_h256_d36) over its own schedule (T = 200) at its own length (L = 16000), one clip with
+    injected noise: x_0 of the split path within 1e-4 of the exact-f32 path's, and both within 1e-3 of the CPU oracle's loop
+    (200 oracle forwards of the 36-layer network: ~2 minutes of host time)."""
+    import bench
+    from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+    cfg = bench.CONFIGS["wnet_h256_d36_T200"]
+    mcfg, L = dict(cfg["model"]), cfg["L"]
+    net = cases.build_ours(mcfg, 91).to(gpu)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    dh = calc_diffusion_hyperparams(**cfg["diffusion"])
+    onet = lambda inp, mel_spec=None: own.wavenet_forward(sd, mcfg, inp[0], inp[1])
+    out, ref = _trajectories(gpu, net, onet, (1, 1, L), dh, seed=11)
+    e_split_f32 = rel_err(out["bf16x6"], out["f32"])
+    e_f32, e_split = rel_err(out["f32"], ref), rel_err(out["bf16x6"], ref)
+    print(f"wnet_h256_d36 T=200 L={L}: x_0 bf16x6 vs f32 {e_split_f32:.3e}; vs the oracle loop: f32 {e_f32:.3e}, bf16x6 {e_split:.3e}")
+    assert not torch.equal(out["bf16x6"], out["f32"])
+    assert e_split_f32 < 1e-4 and e_f32 < REL_TOL and e_split < REL_TOL
