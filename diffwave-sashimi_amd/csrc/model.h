@@ -61,6 +61,46 @@ struct CopyBatch {
     }
 };
 
+// Weight preparation of a commit as job tables (wavenet_kernels.hip: weight_prep_kernel): the weight-norm folds, MFMA fragment
+// packs and row sums of ALL weights in two launches (folds, then everything that reads a folded or raw weight) instead of one
+// 4-5 us launch each -- a training step commits once per step: 286 launches = 1.35 ms of a config-5 step.  Each job runs the
+// very arithmetic of its single launcher (same block shape, same reduction order): results are bit-identical.
+enum { PREP_FOLD = 0, PREP_PACK = 1, PREP_PACK_T = 2, PREP_ROW_SUM = 3 };
+struct PrepJob { const float* a; const float* b; float* out; int n0, n1, kind, first_block; };
+int prep_job_blocks(int kind, int n0, int n1);
+int launch_weight_prep(const PrepJob* table_dev, int njobs, int nblocks, hipStream_t s);
+
+struct PrepBatch {
+    std::vector<PrepJob> jobs[2], uploaded[2];    // phase 0: folds; phase 1: packs / row sums (may read a phase-0 output)
+    DevBuf table[2];
+    int nblocks[2] = {0, 0};
+    void begin() { jobs[0].clear(); jobs[1].clear(); nblocks[0] = nblocks[1] = 0; }
+    void add(int kind, const float* a, const float* b, float* out, int n0, int n1) {
+        const int ph = kind == PREP_FOLD ? 0 : 1;
+        jobs[ph].push_back({a, b, out, n0, n1, kind, nblocks[ph]});
+        nblocks[ph] += prep_job_blocks(kind, n0, n1);
+    }
+    void fold(const float* v, const float* g, float* out, int O, int inner) { add(PREP_FOLD, v, g, out, O, inner); }
+    void pack(const float* w, float* out, int M, int K) { add(PREP_PACK, w, nullptr, out, M, K); }
+    void pack_t(const float* w, float* out, int O, int K) { add(PREP_PACK_T, w, nullptr, out, O, K); }
+    void row_sum(const float* w, float* rs, int O, int K) { add(PREP_ROW_SUM, w, nullptr, rs, O, K); }
+    int run(hipStream_t s) {
+        for (int ph = 0; ph < 2; ++ph) {
+            if (jobs[ph].empty()) continue;
+            const bool same = jobs[ph].size() == uploaded[ph].size() &&
+                              std::memcmp(jobs[ph].data(), uploaded[ph].data(), jobs[ph].size() * sizeof(PrepJob)) == 0;
+            if (!same) {      // (buffers are allocated once: the first commit of a model, or a re-shaped one)
+                DWS_HIP(hipStreamSynchronize(s));
+                uploaded[ph] = jobs[ph];
+                DWS_TRY(table[ph].ensure(uploaded[ph].size() * sizeof(PrepJob)));
+                DWS_HIP(hipMemcpy(table[ph].p, uploaded[ph].data(), uploaded[ph].size() * sizeof(PrepJob), hipMemcpyHostToDevice));
+            }
+            DWS_TRY(launch_weight_prep((const PrepJob*)table[ph].p, (int)jobs[ph].size(), nblocks[ph], s));
+        }
+        return DWS_OK;
+    }
+};
+
 struct ParamSpec {
     std::string name;
     std::vector<int64_t> shape;

@@ -335,8 +335,11 @@ struct SashimiModel : dws_model {
         add_param("final_conv.2.conv.bias", {Cout});
     }
 
-    int fold(const std::string& p, float* out, int O, int inner, hipStream_t s) {
-        return launch_fold_weight_norm(P(p + ".weight_v"), P(p + ".weight_g"), out, O, inner, s);
+    // commit(): the fold joins the commit's batched weight preparation (PrepBatch: run once, before anything reads `out`)
+    PrepBatch prep, prep_train;
+    int fold(const std::string& p, float* out, int O, int inner, hipStream_t) {
+        prep.fold(P(p + ".weight_v"), P(p + ".weight_g"), out, O, inner);
+        return DWS_OK;
     }
 
     // length the kernel of a block was set up for (its `L` buffer): read back only when an int64 buffer was re-sent
@@ -483,6 +486,10 @@ struct SashimiModel : dws_model {
 
     int commit(hipStream_t s) override {
         if (B > 0) DWS_TRY(resolve_segmented_stages(s));
+        // Pass 1: every fold, fragment pack and row sum of the model as ONE batched preparation (two launches: the folds, then
+        // the packs that read them).  Pass 2: what reads the folded weights through its own launches (chain-ordered and
+        // split fragments) and the S4 kernel generation.
+        prep.begin();
         DWS_TRY(Wi.ensure((size_t)D * Cin * 4));
         DWS_TRY(fold("init_conv.0.conv", Wi.f(), D, Cin, s));
         DWS_TRY(Wt_all.ensure((size_t)pt_total * Eout * 4));
@@ -503,10 +510,47 @@ struct SashimiModel : dws_model {
                     DWS_TRY(l->A1.ensure((size_t)FF * H * H * 4));
                     DWS_TRY(l->A2.ensure((size_t)FF * H * H * 4));
                     DWS_TRY(l->rs1.ensure((size_t)FF * H * 4));
-                    DWS_TRY(launch_pack_a_frag(P(l->prefix + ".layer.output_linear.0.weight"), l->Ao.f(), 2 * H, H, s));
-                    DWS_TRY(launch_pack_a_frag(l->W1.f(), l->A1.f(), FF * H, H, s));
-                    DWS_TRY(launch_pack_a_frag(l->W2.f(), l->A2.f(), H, FF * H, s));
-                    DWS_TRY(launch_row_sum(l->W1.f(), l->rs1.f(), FF * H, H, s));
+                    prep.pack(P(l->prefix + ".layer.output_linear.0.weight"), l->Ao.f(), 2 * H, H);
+                    prep.pack(l->W1.f(), l->A1.f(), FF * H, H);
+                    prep.pack(l->W2.f(), l->A2.f(), H, FF * H);
+                    prep.row_sum(l->W1.f(), l->rs1.f(), FF * H, H);
+                }
+                if (cond) {
+                    for (int i = 0; i < 2; ++i) {
+                        const int sc = d.mel_upsample[i];
+                        DevBuf& w = (i == 0) ? l->melW0 : l->melW1;
+                        DWS_TRY(w.ensure((size_t)3 * 2 * sc * 4));
+                        DWS_TRY(fold(l->prefix + ".upsample_conv2d." + std::to_string(i), w.f(), 1, 3 * 2 * sc, s));
+                    }
+                    DWS_TRY(l->melWc.ensure((size_t)H * MB * 4));
+                    DWS_TRY(fold(l->prefix + ".mel_conv.conv", l->melWc.f(), H, MB, s));
+                }
+            } else {
+                const int O = (l->kind == L_DOWN) ? l->Hout : l->Hout * l->p;
+                const int K = (l->kind == L_DOWN) ? l->H * l->p : l->H;
+                DWS_TRY(l->Wp.ensure((size_t)O * K * 4));
+                DWS_TRY(fold(l->prefix + ".linear.conv", l->Wp.f(), O, K, s));
+                l->mfma = pw_mfma_supported(l->kind == L_DOWN ? 0 : 1, K, O, l->p) && !getenv("DWS_SASHIMI_GENERIC");
+                // shapes the fused pooling kernel does not cover (e.g. 128 -> 64 channels of unet_d32) still run on MFMA:
+                // explicit rearrangement + the position-tile GEMM of the training path
+                l->mfma2 = !l->mfma && tapconv_mfma_supported(O, K, 0, 1) && !getenv("DWS_SASHIMI_GENERIC");
+                if (l->mfma || l->mfma2) {
+                    DWS_TRY(l->Ap.ensure((size_t)O * K * 4));
+                    prep.pack(l->Wp.f(), l->Ap.f(), O, K);
+                }
+            }
+        }
+        DWS_TRY(Wf.ensure((size_t)D * D * 4));
+        DWS_TRY(fold("final_conv.0.conv", Wf.f(), D, D, s));
+        if (wn_final_mfma_supported(D)) {
+            DWS_TRY(Af.ensure((size_t)D * D * 4));
+            prep.pack(Wf.f(), Af.f(), D, D);
+        }
+        DWS_TRY(prep.run(s));
+        for (auto* l : all) {
+            if (l->kind == L_BLOCK) {
+                const int H = l->H;
+                if (l->mfma) {
                     if (s4_tail_chain_supported(H, FF)) {   // chain-ordered columns for the register-chained tail kernel
                         DWS_TRY(chain_tmp.ensure((size_t)FF * H * H * 4));
                         DWS_TRY(l->Ao_c.ensure((size_t)2 * H * H * 4));
@@ -557,36 +601,7 @@ struct SashimiModel : dws_model {
                     }
                 }
                 DWS_TRY(build_kernel(l, s));
-                if (cond) {
-                    for (int i = 0; i < 2; ++i) {
-                        const int sc = d.mel_upsample[i];
-                        DevBuf& w = (i == 0) ? l->melW0 : l->melW1;
-                        DWS_TRY(w.ensure((size_t)3 * 2 * sc * 4));
-                        DWS_TRY(fold(l->prefix + ".upsample_conv2d." + std::to_string(i), w.f(), 1, 3 * 2 * sc, s));
-                    }
-                    DWS_TRY(l->melWc.ensure((size_t)H * MB * 4));
-                    DWS_TRY(fold(l->prefix + ".mel_conv.conv", l->melWc.f(), H, MB, s));
-                }
-            } else {
-                const int O = (l->kind == L_DOWN) ? l->Hout : l->Hout * l->p;
-                const int K = (l->kind == L_DOWN) ? l->H * l->p : l->H;
-                DWS_TRY(l->Wp.ensure((size_t)O * K * 4));
-                DWS_TRY(fold(l->prefix + ".linear.conv", l->Wp.f(), O, K, s));
-                l->mfma = pw_mfma_supported(l->kind == L_DOWN ? 0 : 1, K, O, l->p) && !getenv("DWS_SASHIMI_GENERIC");
-                // shapes the fused pooling kernel does not cover (e.g. 128 -> 64 channels of unet_d32) still run on MFMA:
-                // explicit rearrangement + the position-tile GEMM of the training path
-                l->mfma2 = !l->mfma && tapconv_mfma_supported(O, K, 0, 1) && !getenv("DWS_SASHIMI_GENERIC");
-                if (l->mfma || l->mfma2) {
-                    DWS_TRY(l->Ap.ensure((size_t)O * K * 4));
-                    DWS_TRY(launch_pack_a_frag(l->Wp.f(), l->Ap.f(), O, K, s));
-                }
             }
-        }
-        DWS_TRY(Wf.ensure((size_t)D * D * 4));
-        DWS_TRY(fold("final_conv.0.conv", Wf.f(), D, D, s));
-        if (wn_final_mfma_supported(D)) {
-            DWS_TRY(Af.ensure((size_t)D * D * 4));
-            DWS_TRY(launch_pack_a_frag(Wf.f(), Af.f(), D, D, s));
         }
         DWS_TRY(stack_fc_t.run(s));
         if (!freq_ready) {   // depends on the embedding width only: uploaded (and waited for) once, not on every commit --
@@ -1020,10 +1035,10 @@ struct SashimiModel : dws_model {
             if (packed) {
                 *pA = packed;
             } else {
-                DWS_TRY(launch_pack_a_frag(W, A.f(), O, K, s));
+                prep_train.pack(W, A.f(), O, K);
                 *pA = A.f();
             }
-            DWS_TRY(launch_pack_a_frag_t(W, AT.f(), O, K, s));
+            prep_train.pack_t(W, AT.f(), O, K);     // (pack_train runs the batch: one launch for every weight)
             return DWS_OK;
         }
         // generic: A / AT only serve as keys; AT's storage holds the row-major transpose itself
@@ -1036,6 +1051,7 @@ struct SashimiModel : dws_model {
 
     int pack_train(hipStream_t s) {
         row_major.clear();
+        prep_train.begin();
         for (auto* l : all) {
             if (l->kind == L_BLOCK) {
                 const int H = l->H;
@@ -1053,11 +1069,12 @@ struct SashimiModel : dws_model {
         DWS_TRY(tmp_pack.ensure((size_t)D * D * 4));
         DWS_TRY(tAfT.ensure((size_t)D * D * 4));
         if (tapconv_mfma_supported(D, D, 0, 1)) {
-            DWS_TRY(launch_pack_a_frag_t(Wf.f(), tAfT.f(), D, D, s));
+            prep_train.pack_t(Wf.f(), tAfT.f(), D, D);
         } else {
             DWS_TRY(launch_tapconv_pack_transposed(Wf.f(), tAfT.f(), D, D, 1, D, 0, 1.f, s));
             row_major[tAfT.f()] = RowMajor{tAfT.f(), D, D};
         }
+        DWS_TRY(prep_train.run(s));
         train_pack_version = commit_version;
         return DWS_OK;
     }
@@ -1093,8 +1110,20 @@ struct SashimiModel : dws_model {
     }
 
     // dW[o, c] = sum_{b, l} dY[b, o, l] * act(X[b, c, l]);  db[o] = sum_{b, l} dY[b, o, l] (optional, same pass)
-    int wgrad(const float* dY, const float* X, int O, int Cc, int Lx, int xact, float* dW, float* db, hipStream_t s) {
+    // wn != nullptr: the weight is the weight-normed tensor `*wn` -- its adjoint runs inside the split-K reduce (dv / dg written
+    // directly; dW is not used)
+    int wgrad(const float* dY, const float* X, int O, int Cc, int Lx, int xact, float* dW, float* db, hipStream_t s,
+              const std::string* wn = nullptr) {
+        static const bool wn_separate = getenv("DWS_WN_BWD_SEPARATE") != nullptr;     // same-box A/B switch
+        if (wn && (wn_separate || Cc > WGRAD_WN_MAX_INNER)) {
+            DWS_TRY(wgrad(dY, X, O, Cc, Lx, xact, dW, db, s));
+            return wn_bwd(*wn, dW, O, Cc, s);
+        }
         WgradArgs w{};
+        if (wn) {
+            w.wn_v = P(*wn + ".weight_v"); w.wn_g = P(*wn + ".weight_g");
+            w.wn_dv = G(*wn + ".weight_v"); w.wn_dg = G(*wn + ".weight_g");
+        }
         w.dY = dY; w.X = X; w.B = (int)B; w.O = O; w.C = Cc; w.L = Lx; w.dil = 1; w.xact = xact;
         w.nsplit = wgrad_mfma_nsplit((int)B, O, Cc, Lx, 1);
         DWS_TRY(wpart.ensure((size_t)w.nsplit * O * Cc * 4));
@@ -1159,7 +1188,10 @@ struct SashimiModel : dws_model {
         DWS_TRY(dnf.ensure((size_t)B * D * L * 4));
         DWS_TRY(ta1.ensure((size_t)B * Emid * 4));
         DWS_TRY(ta2.ensure((size_t)B * Eout * 4));
-        DWS_TRY(lnpart.ensure((size_t)B * ceil_div(L, 64) * 2 * 4));
+        ln_slot_floats = (size_t)B * ceil_div(L, 64) * 2;       // a slot per LayerNorm adjoint: two per block + the final norm
+        ln_slots = 1;
+        for (auto* l : all) ln_slots += (l->kind == L_BLOCK) ? 2 : 0;
+        DWS_TRY(lnpart.ensure(ln_slot_floats * ln_slots * 4));
         return DWS_OK;
     }
 
@@ -1299,9 +1331,44 @@ struct SashimiModel : dws_model {
         return DWS_OK;
     }
 
+    // (dm, ds) of a LayerNorm from its adjoint's per-block partials [2][nblk].  Every adjoint of a backward writes its own slot of
+    // lnpart and the sums of all of them run as ONE launch at the end of the backward (ln_scalars_flush) -- they were 61 launches
+    // of 8 us per config-5 step.  The scalars' gradients are therefore final at the end of backward only (G() is called there:
+    // the staged hand-over learns it); they are 122 floats.
+    struct LnPending { float* part; std::string name; int nblk; };
+    std::vector<LnPending> ln_pending;
+    std::vector<SumPairJob> ln_jobs, ln_jobs_uploaded;
+    DevBuf ln_table;
+    size_t ln_slot_floats = 0;
+    int ln_slots = 0;
+    bool ln_deferred() const {
+        static const bool off = getenv("DWS_LN_SCALARS_SEPARATE") != nullptr;     // same-box A/B switch
+        return !off;
+    }
+    float* ln_slot() {      // partial buffer of the NEXT LayerNorm adjoint of this backward
+        if (!ln_deferred() || (int)ln_pending.size() >= ln_slots) return lnpart.f();
+        return lnpart.f() + ln_pending.size() * ln_slot_floats;
+    }
     int ln_scalars(const std::string& p, int nblk, hipStream_t s) {
-        // lnpart holds [2][nblk] = (dm, ds) partials
-        return launch_sum_pair(lnpart.f(), G(p + ".m"), G(p + ".s"), nblk, s);
+        if (!ln_deferred() || (int)ln_pending.size() >= ln_slots)
+            return launch_sum_pair(ln_slot(), G(p + ".m"), G(p + ".s"), nblk, s);
+        ln_pending.push_back({ln_slot(), p, nblk});
+        return DWS_OK;
+    }
+    int ln_scalars_flush(hipStream_t s) {
+        if (ln_pending.empty()) return DWS_OK;
+        ln_jobs.clear();
+        for (auto& e : ln_pending) ln_jobs.push_back({e.part, G(e.name + ".m"), G(e.name + ".s"), e.nblk, 0});
+        ln_pending.clear();
+        const bool same = ln_jobs.size() == ln_jobs_uploaded.size() &&
+                          std::memcmp(ln_jobs.data(), ln_jobs_uploaded.data(), ln_jobs.size() * sizeof(SumPairJob)) == 0;
+        if (!same) {
+            DWS_HIP(hipStreamSynchronize(s));
+            ln_jobs_uploaded = ln_jobs;
+            DWS_TRY(ln_table.ensure(ln_jobs.size() * sizeof(SumPairJob)));
+            DWS_HIP(hipMemcpy(ln_table.p, ln_jobs.data(), ln_jobs.size() * sizeof(SumPairJob), hipMemcpyHostToDevice));
+        }
+        return launch_sum_pair_multi((const SumPairJob*)ln_table.p, (int)ln_jobs.size(), s);
     }
 
     // Adjoint of forward_train, plan steps in reverse (sashimi.py:143-184,277-313).
@@ -1309,6 +1376,7 @@ struct SashimiModel : dws_model {
         DWS_CHECK(trained_fwd, DWS_ERR_STATE, "backward without a preceding forward_train");
         const int nB = (int)B, nL = (int)L;
         const int nnodes = (int)plan.size() + 1;
+        ln_pending.clear();
         std::vector<char> written(nnodes, 0);
         std::vector<float*> gp(nnodes);       // where each node's gradient lives during THIS backward (a skip node may adopt a dy buffer)
         for (int n = 0; n < nnodes; ++n) gp[n] = node_grad(n);
@@ -1327,12 +1395,11 @@ struct SashimiModel : dws_model {
         // generic FMA kernel took 2.3 ms per call on [B, ., L] = 512000 positions)
         DWS_TRY(wgrad(dout, ty.f(), Cout, D, nL, 0, G("final_conv.2.conv.weight"), G("final_conv.2.conv.bias"), s));
         DWS_TRY(launch_final_dy(dout, P("final_conv.2.conv.weight"), ty.f(), dyb.f(), nB, D, Cout, nL, s));
-        DWS_TRY(wgrad(dyb.f(), nfin.f(), D, D, nL, 0, dWfold.f(), G("final_conv.0.conv.bias"), s));
-        DWS_TRY(wn_bwd("final_conv.0.conv", dWfold.f(), D, D, s));
+        { const std::string wn_ = "final_conv.0.conv"; DWS_TRY(wgrad(dyb.f(), nfin.f(), D, D, nL, 0, dWfold.f(), G("final_conv.0.conv.bias"), s, &wn_)); }
         DWS_TRY(gemm(tAfT.f(), D, D, dyb.f(), dnf.f(), nL, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
         {
             const int last = nnodes - 1;
-            DWS_TRY(launch_ln_bwd(node_act(last), dnf.f(), P("norm.m"), P("norm.s"), nullptr, gp[last], 0, lnpart.f(),
+            DWS_TRY(launch_ln_bwd(node_act(last), dnf.f(), P("norm.m"), P("norm.s"), nullptr, gp[last], 0, ln_slot(),
                                   nB, D, nL, s));
             DWS_TRY(ln_scalars("norm", nB * ceil_div(nL, 64), s));
             written[last] = 1;
@@ -1351,16 +1418,14 @@ struct SashimiModel : dws_model {
                 const int H = l->H, Ls = l->L, nblk = nB * ceil_div(Ls, 64);
                 // ff: out = x1 + W2 gelu(f1) + b2, f1 = W1 n2 + b1
                 DWS_TRY(gemm(l->tA2T.f(), FF * H, H, dy, st->d2.f(), Ls, 5, nullptr, nullptr, nullptr, l->t_f1.f(), nullptr, s));
-                DWS_TRY(wgrad(dy, l->t_ge.f(), H, FF * H, Ls, 0, dWfold.f(), G(p + ".ff.ff.2.conv.bias"), s));
-                DWS_TRY(wn_bwd(p + ".ff.ff.2.conv", dWfold.f(), H, FF * H, s));
+                { const std::string wn_ = p + ".ff.ff.2.conv"; DWS_TRY(wgrad(dy, l->t_ge.f(), H, FF * H, Ls, 0, dWfold.f(), G(p + ".ff.ff.2.conv.bias"), s, &wn_)); }
                 DWS_TRY(gemm(l->tA1T.f(), H, FF * H, st->d2.f(), st->dh.f(), Ls, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
-                DWS_TRY(wgrad(st->d2.f(), l->t_n2.f(), FF * H, H, Ls, 0, dWfold.f(), G(p + ".ff.ff.0.conv.bias"), s));
-                DWS_TRY(wn_bwd(p + ".ff.ff.0.conv", dWfold.f(), FF * H, H, s));
+                { const std::string wn_ = p + ".ff.ff.0.conv"; DWS_TRY(wgrad(st->d2.f(), l->t_n2.f(), FF * H, H, Ls, 0, dWfold.f(), G(p + ".ff.ff.0.conv.bias"), s, &wn_)); }
                 // norm2: dx1 = dy + LN'(dn2)
                 // (the GLU adjoint rides on this kernel when it can: d o is written from the d x1 values in registers)
                 const bool glu_fused = ln_bwd_fuses_glu(H);
                 DWS_TRY(launch_ln_bwd(l->t_x1.f(), st->dh.f(), P(p + ".norm2.m"), P(p + ".norm2.s"), dy, st->dx1.f(), 0,
-                                      lnpart.f(), nB, H, Ls, s, glu_fused ? l->t_o.f() : nullptr,
+                                      ln_slot(), nB, H, Ls, s, glu_fused ? l->t_o.f() : nullptr,
                                       glu_fused ? st->d2.f() : nullptr));
                 DWS_TRY(ln_scalars(p + ".norm2", nblk, s));
                 if (melBm) {  // x1 = ... + melc: the block's conditioner sees d x1 (`sashimi.py:160-175`)
@@ -1396,21 +1461,19 @@ struct SashimiModel : dws_model {
                 // u = LN1(x) + fc_t(e): dx = dx1 + LN'(du)
                 if (!rs_fused) DWS_TRY(launch_rowsum_bc(st->du.f(), dpt.f() + l->pt_off, pt_total, nB, H, Ls, s));
                 DWS_TRY(launch_ln_bwd(x, st->du.f(), P(p + ".norm1.m"), P(p + ".norm1.s"), st->dx1.f(), din, written[e.in_node],
-                                      lnpart.f(), nB, H, Ls, s));
+                                      ln_slot(), nB, H, Ls, s));
                 DWS_TRY(ln_scalars(p + ".norm1", nblk, s));
                 written[e.in_node] = 1;
             } else if (l->kind == L_DOWN) {
                 const int K = l->H * l->p, O = l->Hout;
-                DWS_TRY(wgrad(dy, l->t_xr.f(), O, K, l->Lout, 0, dWfold.f(), G(p + ".linear.conv.bias"), s));
-                DWS_TRY(wn_bwd(p + ".linear.conv", dWfold.f(), O, K, s));
+                { const std::string wn_ = p + ".linear.conv"; DWS_TRY(wgrad(dy, l->t_xr.f(), O, K, l->Lout, 0, dWfold.f(), G(p + ".linear.conv.bias"), s, &wn_)); }
                 DWS_TRY(gemm(l->tApT.f(), K, O, dy, pool_scr.f(), l->Lout, 2, nullptr, nullptr, nullptr, nullptr, nullptr, s));
                 DWS_TRY(launch_pool_rearrange(pool_scr.f(), din, nullptr, 1, written[e.in_node], nB, l->H, l->p, l->Lout, s));
                 written[e.in_node] = 1;
             } else {
                 const int K = l->H, O = l->Hout * l->p;   // xl = Wp x + b, [B][O][L_in]
                 DWS_TRY(launch_pool_rearrange(dy, pool_scr.f(), nullptr, 0, 0, nB, l->Hout, l->p, l->L, s));
-                DWS_TRY(wgrad(pool_scr.f(), x, O, K, l->L, 0, dWfold.f(), G(p + ".linear.conv.bias"), s));
-                DWS_TRY(wn_bwd(p + ".linear.conv", dWfold.f(), O, K, s));
+                { const std::string wn_ = p + ".linear.conv"; DWS_TRY(wgrad(pool_scr.f(), x, O, K, l->L, 0, dWfold.f(), G(p + ".linear.conv.bias"), s, &wn_)); }
                 if (written[e.in_node])
                     DWS_TRY(gemm(l->tApT.f(), K, O, pool_scr.f(), din, l->L, 0, nullptr, nullptr, nullptr, din, nullptr, s));
                 else
@@ -1436,8 +1499,7 @@ struct SashimiModel : dws_model {
         const size_t nact = (size_t)B * D * L;
         DWS_CHECK(written[0], DWS_ERR_STATE, "backward: no gradient reached the init conv");
         DWS_TRY(launch_relu_bwd(gp[0], x_init.f(), nact, s));      // (node 0 is a skip node too: its gradient may live in an adopted buffer)
-        DWS_TRY(wgrad(gp[0], train_audio, D, Cin, nL, 0, dWfold.f(), G("init_conv.0.conv.bias"), s));
-        DWS_TRY(wn_bwd("init_conv.0.conv", dWfold.f(), D, Cin, s));
+        { const std::string wn_ = "init_conv.0.conv"; DWS_TRY(wgrad(gp[0], train_audio, D, Cin, nL, 0, dWfold.f(), G("init_conv.0.conv.bias"), s, &wn_)); }
 
         // ---- step embedding: per-block fc_t (stacked), then the shared swish MLP
         DWS_TRY(launch_lin_bwd_w(dpt.f(), h2.f(), dWt_all.f(), dbt_all.f(), nB, Eout, pt_total, s));
@@ -1452,6 +1514,7 @@ struct SashimiModel : dws_model {
         DWS_TRY(launch_lin_bwd_w(dh2.f(), h1.f(), G("fc_t2.weight"), G("fc_t2.bias"), nB, Emid, Eout, s));
         DWS_TRY(launch_lin_bwd_x(dh2.f(), P("fc_t2.weight"), ta1.f(), dh1.f(), nB, Emid, Eout, lin_scratch, s));
         DWS_TRY(launch_lin_bwd_w(dh1.f(), emb.f(), G("fc_t1.weight"), G("fc_t1.bias"), nB, Ein, Emid, s));
+        DWS_TRY(ln_scalars_flush(s));
         DWS_HIP(hipGetLastError());
         return DWS_OK;
     }

@@ -11,6 +11,8 @@ int launch_ln_bwd(const float* x, const float* dy, const float* m_p, const float
                   float* glu_do = nullptr);
 int launch_sum_leading(const float* partial, float* out, size_t n, int k, float scale, hipStream_t s);
 int launch_sum_pair(const float* partial, float* out0, float* out1, int k, hipStream_t s);
+struct SumPairJob { const float* partial; float* out0; float* out1; int k; int pad; };
+int launch_sum_pair_multi(const SumPairJob* table_dev, int njobs, hipStream_t s);   // blockIdx.y = job; same sums as launch_sum_pair
 int launch_glu_res(const float* o, const float* x, const float* mel, float* x1, int B, int H, int L, hipStream_t s);
 int launch_glu_bwd(const float* dx1, const float* o, float* dout, int B, int H, int L, hipStream_t s);
 int launch_pool_rearrange(const float* in, float* out, const float* addend, int dir, int accumulate, int B, int H,

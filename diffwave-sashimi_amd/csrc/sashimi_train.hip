@@ -252,6 +252,27 @@ int launch_sum_pair(const float* partial, float* out0, float* out1, int k, hipSt
     return DWS_OK;
 }
 
+// The same sums for a table of jobs in one launch (blockIdx.y = job): the (dm, ds) partials of every LayerNorm adjoint of a
+// backward are reduced together at its end instead of by one 8 us launch each (61 per config-5 step).
+__global__ __launch_bounds__(256) void sum_pair_multi_kernel(const SumPairJob* __restrict__ jobs) {
+    __shared__ float red[4];
+    const SumPairJob j = jobs[blockIdx.y];
+    const float* p = j.partial + (size_t)blockIdx.x * j.k;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < j.k; i += 256) s += p[i];
+    s = wave_sum_t(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) (blockIdx.x ? j.out1 : j.out0)[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+int launch_sum_pair_multi(const SumPairJob* table_dev, int njobs, hipStream_t s) {
+    if (njobs <= 0) return DWS_OK;
+    hipLaunchKernelGGL(sum_pair_multi_kernel, dim3(2, njobs), dim3(256), 0, s, table_dev);
+    DWS_HIP(hipGetLastError());
+    return DWS_OK;
+}
+
 int launch_sum_leading(const float* partial, float* out, size_t n, int k, float scale, hipStream_t s) {
     if (n <= 64 && k >= 256)
         hipLaunchKernelGGL(sum_leading_wide_kernel, dim3((unsigned)n), dim3(256), 0, s, partial, out, (int)n, k, scale);

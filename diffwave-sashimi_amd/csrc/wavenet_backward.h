@@ -68,7 +68,12 @@ struct WgradArgs {
     float* dbias; float bias_scale;
     int xL;                      // row stride of X in floats (0 = L)
     int split;                   // 1: precision = bf16x6 in the 16-byte single-tap kernel (wgrad_dma4)
+    // optional (T = 1, C <= WGRAD_WN_MAX_INNER): the weight is weight-normed (W = g v / ||v|| per row) -- the split-K reduce
+    // applies the weight-norm adjoint to the row it has just summed and writes dv / dg instead of dW (no folded-gradient
+    // buffer, no separate weight_norm_bwd launch)
+    const float* wn_v; const float* wn_g; float* wn_dv; float* wn_dg;
 };
+constexpr int WGRAD_WN_MAX_INNER = 4096;
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T);
 int launch_wgrad_mfma(const WgradArgs& a, int T, float scale, float* dW, hipStream_t s);
 // The T = 3 weight gradient in Winograd F(2,3) pairing (wavenet_backward_wino.hip): partial is [nsplit][O][C][4]

@@ -980,6 +980,64 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+__device__ __forceinline__ float block_sum_256(float v, float* red) {     // (wavenet_backward.hip's, same order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// The reduce with the weight-norm adjoint on top (WgradArgs::wn_*): block o sums row o of the partials (the element order of
+// wgrad_reduce_kernel), keeps it in LDS, and writes  dg[o] = <dW, v> / ||v||,  dv = (g / ||v||) (dW - dg v / ||v||)  -- the
+// arithmetic of weight_norm_bwd_kernel (wavenet_backward.hip) on the row.  Blocks [O, ...): the bias partials.
+__global__ __launch_bounds__(256) void wgrad_reduce_wn_kernel(const float* __restrict__ partial, size_t n, int nsplit, float scale,
+                                                              const float* __restrict__ v, const float* __restrict__ g,
+                                                              float* __restrict__ dv, float* __restrict__ dg, int O, int inner,
+                                                              const float* __restrict__ partial2, float* __restrict__ dW2,
+                                                              float scale2) {
+    __shared__ float row[WGRAD_WN_MAX_INNER];
+    __shared__ float red[4];
+    const int o = blockIdx.x;
+    if (o >= O) {        // bias partials: one element per thread, fixed order
+        const int i = (o - O) * 256 + threadIdx.x;
+        if (i < O) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int k = 0;
+            for (; k + 4 <= nsplit; k += 4) {
+                s0 += partial2[(size_t)k * O + i]; s1 += partial2[(size_t)(k + 1) * O + i];
+                s2 += partial2[(size_t)(k + 2) * O + i]; s3 += partial2[(size_t)(k + 3) * O + i];
+            }
+            for (; k < nsplit; ++k) s0 += partial2[(size_t)k * O + i];
+            dW2[i] = ((s0 + s1) + (s2 + s3)) * scale2;
+        }
+        return;
+    }
+    const float* vr = v + (size_t)o * inner;
+    const float* pr = partial + (size_t)o * inner;
+    float nn = 0.f, dot = 0.f;
+    for (int i = threadIdx.x; i < inner; i += 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4) {
+            s0 += pr[(size_t)k * n + i]; s1 += pr[(size_t)(k + 1) * n + i];
+            s2 += pr[(size_t)(k + 2) * n + i]; s3 += pr[(size_t)(k + 3) * n + i];
+        }
+        for (; k < nsplit; ++k) s0 += pr[(size_t)k * n + i];
+        const float d = ((s0 + s1) + (s2 + s3)) * scale;
+        row[i] = d;
+        nn = fmaf(vr[i], vr[i], nn);
+        dot = fmaf(d, vr[i], dot);
+    }
+    nn = block_sum_256(nn, red);
+    dot = block_sum_256(dot, red);
+    const float norm = sqrtf(nn), dgo = dot / norm, sc = g[o] / norm;
+    if (threadIdx.x == 0) dg[o] = dgo;
+    for (int i = threadIdx.x; i < inner; i += 256) dv[(size_t)o * inner + i] = sc * (row[i] - dgo * vr[i] / norm);
+}
+
 int wgrad_mfma_nsplit(int B, int O, int C, int L, int T) {
     const int tiles = ceil_div(O, 128) * ceil_div(C, 128) * T;
     const int chunks = B * ceil_div(L, 64);
@@ -1027,6 +1085,14 @@ int launch_wgrad_mfma(const WgradArgs& a_in, int T, float scale, float* dW, hipS
         hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, s, a);
     }
     const size_t n = (size_t)a.O * a.C * T;
+    if (a.wn_v) {
+        DWS_CHECK(T == 1 && a.C <= WGRAD_WN_MAX_INNER && a.wn_g && a.wn_dv && a.wn_dg, DWS_ERR_INVALID,
+                  "wgrad: the fused weight-norm adjoint needs T = 1 and at most %d columns (T=%d C=%d)", WGRAD_WN_MAX_INNER, T, a.C);
+        const int bias_blocks = a.bias_part ? ceil_div(a.O, 256) : 0;
+        hipLaunchKernelGGL(wgrad_reduce_wn_kernel, dim3(a.O + bias_blocks), dim3(256), 0, s, a.partial, n, a.nsplit, scale, a.wn_v,
+                           a.wn_g, a.wn_dv, a.wn_dg, a.O, a.C, (const float*)a.bias_part, a.dbias, a.bias_scale);
+        return DWS_OK;
+    }
     const int blocks1 = (int)ceil_div(n, 1024), blocks2 = a.bias_part ? (int)ceil_div(a.O, 1024) : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks1 + blocks2), dim3(256), 0, s, a.partial, dW, n, a.nsplit, scale,
                        (const float*)a.bias_part, a.dbias, (size_t)a.O, a.bias_scale, blocks1);

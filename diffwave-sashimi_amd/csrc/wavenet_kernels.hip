@@ -14,6 +14,7 @@
 // folded (weight-norm) and pre-packed ONCE into MFMA A-fragment order so every
 // wave streams them with 1 KiB dwordx4 loads from L2.
 #include "dws_common.h"
+#include "model.h"
 #include "wavenet.h"
 
 namespace dws {
@@ -24,22 +25,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Weight preparation (runs once per weight load, not per step)
 // ---------------------------------------------------------------------------
 
-// out[o,:] = g[o] * v[o,:] / ||v[o,:]||_2   (torch weight_norm, dim=0; `wavenet.py:21`)
-__global__ void fold_weight_norm_kernel(const float* __restrict__ v, const float* __restrict__ g,
-                                        float* __restrict__ out, int inner) {
-    const int o = blockIdx.x;
+// out[o,:] = g[o] * v[o,:] / ||v[o,:]||_2   (torch weight_norm, dim=0; `wavenet.py:21`); one 256-thread block per row o
+__device__ __forceinline__ void fold_weight_norm_row(const float* __restrict__ v, const float* __restrict__ g,
+                                                     float* __restrict__ out, int inner, int o, float* red) {
     const float* vr = v + (size_t)o * inner;
     float s = 0.f;
-    for (int i = threadIdx.x; i < inner; i += blockDim.x) s += vr[i] * vr[i];
-    __shared__ float red[256];
+    for (int i = threadIdx.x; i < inner; i += 256) s += vr[i] * vr[i];
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+    for (int st = 128; st > 0; st >>= 1) {
         if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
     const float scale = g[o] / sqrtf(red[0]);
-    for (int i = threadIdx.x; i < inner; i += blockDim.x) out[(size_t)o * inner + i] = vr[i] * scale;
+    for (int i = threadIdx.x; i < inner; i += 256) out[(size_t)o * inner + i] = vr[i] * scale;
+}
+
+__global__ __launch_bounds__(256) void fold_weight_norm_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                               float* __restrict__ out, int inner) {
+    __shared__ float red[256];
+    fold_weight_norm_row(v, g, out, inner, blockIdx.x, red);
 }
 
 int launch_fold_weight_norm(const float* v, const float* g, float* out, int O, int inner, hipStream_t s) {
@@ -67,8 +72,7 @@ int launch_permute_dconv(const float* w, float* out, int C, int KC, hipStream_t 
 // Row-major W[M][K] -> A-fragment order of v_mfma_f32_32x32x2_f32:
 //   pack[mt][kg][lane][j] = W[mt*32 + (lane&31)][(kg*4 + j)*2 + (lane>>5)]
 // so one dwordx4 load per lane yields the A operands of 4 consecutive k-steps.
-__global__ void pack_a_frag_kernel(const float* __restrict__ w, float* __restrict__ out, int M, int K) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_a_frag_at(const float* __restrict__ w, float* __restrict__ out, int M, int K, size_t i) {
     if (i >= (size_t)M * K) return;
     int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
     size_t r = i >> 8;  // mt * (K/8) + kg
@@ -76,17 +80,22 @@ __global__ void pack_a_frag_kernel(const float* __restrict__ w, float* __restric
     int row = mt * 32 + (lane & 31), col = (kg * 4 + j) * 2 + (lane >> 5);
     out[i] = w[(size_t)row * K + col];
 }
+__global__ void pack_a_frag_kernel(const float* __restrict__ w, float* __restrict__ out, int M, int K) {
+    pack_a_frag_at(w, out, M, K, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // The same fragment order for the TRANSPOSE of a row-major W[O][K] (the adjoint GEMM's operand W^T [K][O]) straight from
 // W: one launch instead of transpose-to-scratch + pack (and no shared scratch buffer between consecutive weights).
-__global__ void pack_a_frag_t_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int K) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_a_frag_t_at(const float* __restrict__ w, float* __restrict__ out, int O, int K, size_t i) {
     if (i >= (size_t)O * K) return;
     int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
     size_t r = i >> 8;  // mt * (O/8) + kg   (rows of W^T = K, contraction = O)
     int kg = (int)(r % (O / 8)), mt = (int)(r / (O / 8));
     int row = mt * 32 + (lane & 31), col = (kg * 4 + j) * 2 + (lane >> 5);
     out[i] = w[(size_t)col * K + row];
+}
+__global__ void pack_a_frag_t_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int K) {
+    pack_a_frag_t_at(w, out, O, K, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 int launch_pack_a_frag_t(const float* w, float* out, int O, int K, hipStream_t s) {
@@ -98,6 +107,51 @@ int launch_pack_a_frag_t(const float* w, float* out, int O, int K, hipStream_t s
 int launch_pack_a_frag(const float* w, float* out, int M, int K, hipStream_t s) {
     size_t n = (size_t)M * K;
     hipLaunchKernelGGL(pack_a_frag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, w, out, M, K);
+    return DWS_OK;
+}
+
+// Batched weight preparation (model.h: PrepBatch): block -> job by bisection of the jobs' first_block, then the job's own
+// kernel body on the block's index inside the job.  PREP_ROW_SUM: four rows per block, one per wave (sashimi_mfma.hip:
+// row_sum_kernel's lane-strided sum and butterfly, the same order).
+int prep_job_blocks(int kind, int n0, int n1) {
+    switch (kind) {
+        case PREP_FOLD: return n0;
+        case PREP_ROW_SUM: return ceil_div(n0, 4);
+        default: return (int)ceil_div((size_t)n0 * n1, 256);
+    }
+}
+
+__global__ __launch_bounds__(256) void weight_prep_kernel(const PrepJob* __restrict__ jobs, int njobs) {
+    __shared__ float red[256];
+    int lo = 0, hi = njobs - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {       // the last job whose first_block <= blk (uniform: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const PrepJob j = jobs[lo];
+    const int b = blk - j.first_block;
+    switch (j.kind) {
+        case PREP_FOLD: fold_weight_norm_row(j.a, j.b, j.out, j.n1, b, red); break;
+        case PREP_PACK: pack_a_frag_at(j.a, j.out, j.n0, j.n1, (size_t)b * 256 + threadIdx.x); break;
+        case PREP_PACK_T: pack_a_frag_t_at(j.a, j.out, j.n0, j.n1, (size_t)b * 256 + threadIdx.x); break;
+        default: {
+            const int o = b * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+            if (o < j.n0) {
+                float s = 0.f;
+                for (int k = lane; k < j.n1; k += 64) s += j.a[(size_t)o * j.n1 + k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0) j.out[o] = s;
+            }
+        }
+    }
+}
+
+int launch_weight_prep(const PrepJob* table_dev, int njobs, int nblocks, hipStream_t s) {
+    if (njobs <= 0 || nblocks <= 0) return DWS_OK;
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(nblocks), dim3(256), 0, s, table_dev, njobs);
+    DWS_HIP(hipGetLastError());
     return DWS_OK;
 }
 
