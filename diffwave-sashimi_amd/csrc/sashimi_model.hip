@@ -9,6 +9,7 @@
 // D-skip+GELU -> 1x1+GLU+residual -> LN -> FF -> residual per block.
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -115,6 +116,9 @@ struct SLayer {
     bool mfma = false, mfma2 = false;
     DevBuf Kf;            // rocFFT path: [H][L+1] complex spectrum of the two-sided kernel (n = 2L)
     DevBuf kfa, kfb, kfs; // fused path: pair-ordered spectrum at the power-of-two size (fftconv.h)
+    const void *kfa_v = nullptr, *kfb_v = nullptr, *kfs_v = nullptr;   // what the convolution reads: the buffers above, or this block's
+                                                                       // slice of its group's stacked spectra (KGroup)
+    int grp = -1, gidx = 0;   // training: stacked kernel generation -- group (blocks of one shape) and position in it
     int log2m = 0;        // > 0: fused LDS FFT convolution is used for this block
     bool seg = false;     // stage longer than the largest LDS transform: segmented fused path (fftconv_seg_kernel)
     // training: the Cauchy products of the kernel generation (v, w dt, dt, r: `s4.py:740-775`) are kept per block so the
@@ -152,6 +156,22 @@ struct FftTables {
     DevBuf tw, twn, twp;
 };
 
+// Training: the S4 blocks of one shape (H, L) -- 12 + 12 + 6 in BASELINE config 5 -- generate their kernels, and run the adjoint of
+// that generation, STACKED along H: every launch of the chain (s4_prep, Cauchy, Woodbury, rocFFT, re-placement, spectrum, pair
+// order; and backwards) is indexed by a row h < H and is launched once over n * H rows.  Per block the chain is ~12 launches of
+// 5-80 us each way, latency-bound: 30 blocks x 24 launches = 7.6 ms of a 134 ms step before, three chains each way after.
+struct KGroup {
+    int H = 0, L = 0, log2m = 0;
+    std::vector<SLayer*> layers;
+    DevBuf C, Bp, P, iwr, wim, logdt;      // stacked parameters: [2][Ht][N] complex, [Ht][N] complex x 2, [Ht][N] x 2, [Ht]
+    DevBuf v, wdt, dt, r, kf;              // s4_prep / Cauchy products (read again by the adjoint), spectrum [2][Ht][Lh]
+    DevBuf kfa, kfb, kfs;                  // pair-ordered spectra [Ht][M/2] x 2, [Ht][3]: a block reads its H rows
+    DevBuf dKf, gC, gB, gP, giwr, gwim, glogdt, gD;   // adjoint: stacked spectrum gradient, stacked parameter gradients
+    int pending = 0;                       // blocks of this backward whose correlation has not run yet
+    CopyBatch stack, unstack;
+    int Ht() const { return H * (int)layers.size(); }
+};
+
 struct SashimiModel : dws_model {
     int Cin, Cout, D, NL, E, FF, NS = 32, Ein, Emid, Eout, MB;
     bool cond, unet;
@@ -174,6 +194,8 @@ struct SashimiModel : dws_model {
     DevBuf bpart, fpart, dKf, dKt, dkt, dkf, cgr, cgv, cgw, cpdt, dyb, dnf;
     uint64_t commit_version = 0, train_pack_version = ~0ull;
     bool keep_cauchy = false;         // set by the first forward_train: build_kernel then fills the per-block caches
+    std::vector<KGroup*> kgroups;     // training commits: blocks grouped by shape (build_kernels_stacked)
+    bool kernels_stacked = false;     // the last commit generated the kernels group by group
     bool trained_fwd = false;
     const float* train_audio = nullptr;
     DevBuf mel_in;                    // copy of the installed mel [Bm][MB][Tmel] (conditioner adjoint)
@@ -203,6 +225,7 @@ struct SashimiModel : dws_model {
     }
 
     ~SashimiModel() override {
+        for (auto* g : kgroups) delete g;
         for (auto* l : all) delete l;
         for (auto* s : stages) delete s;
         for (auto& kv : tables) delete kv.second;
@@ -446,6 +469,7 @@ struct SashimiModel : dws_model {
             DWS_TRY(launch_s4_twosided_pow2(ck.f(), cK.f(), H, Lt, Nf, Lk, s));
             DWS_TRY(launch_rfft_rows(lg, cK.f(), cKf.f(), t->tw.f(), t->twn.f(), H, s));
             DWS_TRY(launch_kf_permute(cKf.f(), l->kfa.f(), l->kfb.f(), l->kfs.f(), H, lg, s));
+            if (l->grp < 0) { l->kfa_v = l->kfa.p; l->kfb_v = l->kfb.p; l->kfs_v = l->kfs.p; }   // (a block of a stacked commit keeps reading its group's rows: the tap "k:" regenerates into the block's own buffers)
             l->log2m = lg;
             l->seg = false;
         } else if (stages[l->stage]->seg) {
@@ -480,6 +504,85 @@ struct SashimiModel : dws_model {
             l->log2m = 0;
             l->seg = false;
             stages[l->stage]->rocfft = true;
+        }
+        return DWS_OK;
+    }
+
+    // Can this commit generate the kernels group by group?  Training mode, every block on the fused convolution at its kernel's own
+    // length (what train_supported() asks for anyway).  DWS_S4_KERNELS_PER_BLOCK=1: the per-block chain (same-box A/B).
+    bool stacked_kernels_possible(hipStream_t s) {
+        static const bool off = getenv("DWS_S4_KERNELS_PER_BLOCK") != nullptr;
+        if (off || !keep_cauchy || getenv("DWS_SASHIMI_ROCFFT")) return false;
+        for (auto* l : all) {
+            if (l->kind != L_BLOCK) continue;
+            int lg = 0;
+            int64_t Lk = 0;
+            if (kernel_len(l, s, &Lk) != DWS_OK || Lk != l->L || !fftconv_supported(l->L, &lg) || stages[l->stage]->seg) return false;
+            if (!P("__z." + std::to_string(l->L)) || !P("__omega." + std::to_string(l->L))) return false;
+        }
+        return true;
+    }
+
+    // parameters -> K_f of every block, one chain per group of same-shaped blocks (s4.py:704-807, 1391-1403; build_kernel's chain)
+    int build_kernels_stacked(hipStream_t s) {
+        const int N = NS;
+        for (auto* g : kgroups) g->layers.clear();      // (the run length may have changed since the last commit)
+        for (auto* l : all) {
+            if (l->kind != L_BLOCK) continue;
+            KGroup* g = nullptr;
+            for (auto* c : kgroups)
+                if (c->H == l->H && c->L == l->L) g = c;
+            if (!g) { g = new KGroup(); g->H = l->H; g->L = l->L; kgroups.push_back(g); }
+            l->grp = (int)(std::find(kgroups.begin(), kgroups.end(), g) - kgroups.begin());
+            l->gidx = (int)g->layers.size();
+            g->layers.push_back(l);
+        }
+        for (auto* g : kgroups) {
+            if (g->layers.empty()) continue;
+            const int H = g->H, L = g->L, Ht = g->Ht(), Lk = L, Lh = Lk / 2 + 1;
+            int lg = 0;
+            DWS_CHECK(fftconv_supported(L, &lg), DWS_ERR_STATE, "stacked kernel generation on a stage without the fused convolution");
+            const int M = 1 << lg, Nf = 2 * M;
+            g->log2m = lg;
+            FftTables* t;
+            DWS_TRY(get_tables(lg, &t, s));
+            const size_t HN = (size_t)Ht * N;
+            DWS_TRY(g->C.ensure(2 * HN * 8)); DWS_TRY(g->Bp.ensure(HN * 8)); DWS_TRY(g->P.ensure(HN * 8));
+            DWS_TRY(g->iwr.ensure(HN * 4)); DWS_TRY(g->wim.ensure(HN * 4)); DWS_TRY(g->logdt.ensure((size_t)Ht * 4));
+            DWS_TRY(g->v.ensure(6 * HN * 8)); DWS_TRY(g->wdt.ensure(HN * 8)); DWS_TRY(g->dt.ensure((size_t)Ht * 4));
+            DWS_TRY(g->r.ensure((size_t)6 * Ht * Lh * 8)); DWS_TRY(g->kf.ensure((size_t)2 * Ht * Lh * 8));
+            DWS_TRY(g->kfa.ensure((size_t)Ht * (M / 2) * 8)); DWS_TRY(g->kfb.ensure((size_t)Ht * (M / 2) * 8));
+            DWS_TRY(g->kfs.ensure((size_t)Ht * 3 * 8));
+            DWS_TRY(ck.ensure((size_t)2 * Ht * Lk * 4)); DWS_TRY(cK.ensure((size_t)Ht * Nf * 4)); DWS_TRY(cKf.ensure((size_t)Ht * (M + 1) * 8));
+            // the blocks' parameters into the stacked layout (one launch; the C planes of a block go to their plane of the stack)
+            g->stack.begin();
+            const size_t hn = (size_t)H * N;
+            for (size_t i = 0; i < g->layers.size(); ++i) {
+                const std::string k = g->layers[i]->prefix + ".layer.kernel.kernel";
+                for (int c = 0; c < 2; ++c) g->stack.add(P(k + ".C") + c * hn * 2, g->C.f() + (c * HN + i * hn) * 2, hn * 2);
+                g->stack.add(P(k + ".B"), g->Bp.f() + i * hn * 2, hn * 2);
+                g->stack.add(P(k + ".P"), g->P.f() + i * hn * 2, hn * 2);
+                g->stack.add(P(k + ".inv_w_real"), g->iwr.f() + i * hn, hn);
+                g->stack.add(P(k + ".w_imag"), g->wim.f() + i * hn, hn);
+                g->stack.add(P(k + ".log_dt"), g->logdt.f() + i * H, (size_t)H);
+            }
+            DWS_TRY(g->stack.run(s));
+            const float* z = P("__z." + std::to_string(Lk));
+            DWS_TRY(launch_s4_prep(g->C.f(), g->Bp.f(), g->P.f(), g->iwr.f(), g->wim.f(), g->logdt.f(), g->v.f(), g->wdt.f(), g->dt.f(), Ht, N, s));
+            DWS_TRY(launch_cauchy_sym_fwd_bcast(g->v.f(), z, g->wdt.f(), g->r.f(), 6 * Ht, N, Lh, Ht, s));
+            DWS_TRY(launch_s4_woodbury(g->r.f(), P("__omega." + std::to_string(Lk)), g->dt.f(), g->kf.f(), Ht, Lh, (Lk % 2) == 0, s));
+            DWS_TRY(fft.exec(1, Lk, 2 * Ht, g->kf.p, ck.p, s));
+            DWS_TRY(launch_s4_twosided_pow2(ck.f(), cK.f(), Ht, L, Nf, Lk, s));
+            DWS_TRY(launch_rfft_rows(lg, cK.f(), cKf.f(), t->tw.f(), t->twn.f(), Ht, s));
+            DWS_TRY(launch_kf_permute(cKf.f(), g->kfa.f(), g->kfb.f(), g->kfs.f(), Ht, lg, s));
+            for (size_t i = 0; i < g->layers.size(); ++i) {
+                SLayer* l = g->layers[i];
+                l->kfa_v = g->kfa.f() + i * (size_t)H * (M / 2) * 2;
+                l->kfb_v = g->kfb.f() + i * (size_t)H * (M / 2) * 2;
+                l->kfs_v = g->kfs.f() + i * (size_t)H * 3 * 2;
+                l->Lk = Lk; l->log2m = lg; l->seg = false;
+                l->cache_version = commit_version + 1;      // (commit() bumps commit_version when it is done)
+            }
         }
         return DWS_OK;
     }
@@ -547,6 +650,7 @@ struct SashimiModel : dws_model {
             prep.pack(Wf.f(), Af.f(), D, D);
         }
         DWS_TRY(prep.run(s));
+        kernels_stacked = stacked_kernels_possible(s);
         for (auto* l : all) {
             if (l->kind == L_BLOCK) {
                 const int H = l->H;
@@ -600,9 +704,10 @@ struct SashimiModel : dws_model {
                         l->Ao_c6.release(); l->A1_c6.release(); l->A2_c6.release();
                     }
                 }
-                DWS_TRY(build_kernel(l, s));
+                if (!kernels_stacked) { l->grp = -1; DWS_TRY(build_kernel(l, s)); }
             }
         }
+        if (kernels_stacked) DWS_TRY(build_kernels_stacked(s));
         DWS_TRY(stack_fc_t.run(s));
         if (!freq_ready) {   // depends on the embedding width only: uploaded (and waited for) once, not on every commit --
                              // a training step commits once, and a blocking wait there keeps the host from running ahead of the GPU
@@ -761,7 +866,7 @@ struct SashimiModel : dws_model {
             FftConvArgs fa{};
             fa.u = st->y.f(); fa.g = st->g.f(); fa.D = P(p + ".layer.D");
             fa.tw = (const c2*)t->tw.p; fa.twp = (const c2*)t->twp.p;
-            fa.kfa = (const c2*)l->kfa.p; fa.kfb = (const c2*)l->kfb.p; fa.kfs = (const c2*)l->kfs.p;
+            fa.kfa = (const c2*)l->kfa_v; fa.kfb = (const c2*)l->kfb_v; fa.kfs = (const c2*)l->kfs_v;
             fa.B = nB; fa.H = H; fa.L = Ls;
             DWS_TRY(launch_fftconv(l->log2m, fa, s));
             return run_tail(l, st, x, addend, next, s);
@@ -1229,7 +1334,7 @@ struct SashimiModel : dws_model {
                 FftConvArgs fa{};
                 fa.u = l->t_u.f(); fa.g = l->t_g.f(); fa.pre = l->t_a.f(); fa.D = P(p + ".layer.D");
                 fa.tw = (const c2*)t->tw.p; fa.twp = (const c2*)t->twp.p;
-                fa.kfa = (const c2*)l->kfa.p; fa.kfb = (const c2*)l->kfb.p; fa.kfs = (const c2*)l->kfs.p;
+                fa.kfa = (const c2*)l->kfa_v; fa.kfb = (const c2*)l->kfb_v; fa.kfs = (const c2*)l->kfs_v;
                 fa.B = nB; fa.H = H; fa.L = Ls;
                 DWS_TRY(launch_fftconv(l->log2m, fa, s));
                 // LN2(x1) out of the epilogue that produces x1 when the tile holds every channel (H = 128): the separate
@@ -1278,9 +1383,66 @@ struct SashimiModel : dws_model {
     }
 
     // gradient of the S4 kernel parameters of one block from u and da (s4.py:704-807 backwards)
+    // The adjoint of a group's stacked kernel generation, once the spectrum gradients of all its blocks are in g->dKf
+    // (kernel_backward's chain with Ht = n H rows); the stacked parameter gradients leave for the blocks' tensors in one launch.
+    int group_backward(KGroup* g, hipStream_t s) {
+        const int H = g->H, Ht = g->Ht(), Ls = g->L, Lh = Ls / 2 + 1, N = NS;
+        const int M = 1 << g->log2m, Nf = 2 * M;
+        const size_t HN = (size_t)Ht * N, hn = (size_t)H * N;
+        DWS_TRY(dKt.ensure((size_t)Ht * Nf * 4));
+        DWS_TRY(dkt.ensure((size_t)2 * Ht * Ls * 4));
+        DWS_TRY(dkf.ensure((size_t)2 * Ht * Lh * 8));
+        DWS_TRY(cgr.ensure((size_t)6 * Ht * Lh * 8));
+        DWS_TRY(cgv.ensure(6 * HN * 8));
+        DWS_TRY(cgw.ensure(6 * HN * 8));
+        const int nparts = ceil_div(Lh, 256);
+        DWS_TRY(cpdt.ensure((size_t)Ht * nparts * 4));
+        DWS_TRY(g->gC.ensure(2 * HN * 8)); DWS_TRY(g->gB.ensure(HN * 8)); DWS_TRY(g->gP.ensure(HN * 8));
+        DWS_TRY(g->giwr.ensure(HN * 4)); DWS_TRY(g->gwim.ensure(HN * 4)); DWS_TRY(g->glogdt.ensure((size_t)Ht * 4));
+        DWS_TRY(g->gD.ensure((size_t)Ht * 4));
+        DWS_TRY(fft.exec(1, Nf, Ht, g->dKf.p, dKt.p, s));
+        DWS_TRY(launch_s4_twosided_pow2_bwd(dKt.f(), dkt.f(), g->gD.f(), Ht, Ls, Nf, 1.f / ((float)Nf * (float)Ls), 1.f / (float)Nf, s));
+        DWS_TRY(fft.exec(0, Ls, 2 * Ht, dkt.p, dkf.p, s));
+        DWS_TRY(launch_s4_woodbury_bwd(g->r.f(), P("__omega." + std::to_string(Ls)), g->dt.f(), dkf.f(), cgr.f(), cpdt.f(), Ht, Lh,
+                                       (Ls % 2) == 0, s));
+        DWS_TRY(launch_cauchy_sym_bwd_bcast(g->v.f(), P("__z." + std::to_string(Ls)), g->wdt.f(), cgr.f(), cgv.f(), cgw.f(), 6 * Ht, N, Lh,
+                                            Ht, s));
+        DWS_TRY(launch_s4_prep_bwd(g->C.f(), g->Bp.f(), g->P.f(), g->iwr.f(), g->wim.f(), g->logdt.f(), cgv.f(), cgw.f(), cpdt.f(), nparts,
+                                   g->gC.f(), g->gB.f(), g->gP.f(), g->giwr.f(), g->gwim.f(), g->glogdt.f(), Ht, N, s));
+        g->unstack.begin();
+        for (size_t i = 0; i < g->layers.size(); ++i) {
+            const std::string p = g->layers[i]->prefix, k = p + ".layer.kernel.kernel";
+            for (int c = 0; c < 2; ++c) g->unstack.add(g->gC.f() + (c * HN + i * hn) * 2, G(k + ".C") + c * hn * 2, hn * 2);
+            g->unstack.add(g->gB.f() + i * hn * 2, G(k + ".B"), hn * 2);
+            g->unstack.add(g->gP.f() + i * hn * 2, G(k + ".P"), hn * 2);
+            g->unstack.add(g->giwr.f() + i * hn, G(k + ".inv_w_real"), hn);
+            g->unstack.add(g->gwim.f() + i * hn, G(k + ".w_imag"), hn);
+            g->unstack.add(g->glogdt.f() + i * H, G(k + ".log_dt"), (size_t)H);
+            g->unstack.add(g->gD.f() + i * H, G(p + ".layer.D"), (size_t)H);
+        }
+        return g->unstack.run(s);
+    }
+
     int kernel_backward(SLayer* l, const float* da, hipStream_t s) {
         const int H = l->H, Ls = l->L, Lh = Ls / 2 + 1, N = NS, nB = (int)B;
         const int M = 1 << l->log2m, Nf = 2 * M;
+        if (kernels_stacked && l->grp >= 0) {
+            // this block's spectrum gradient into its rows of the group's stack; the rest of the chain runs once per group
+            KGroup* g = kgroups[l->grp];
+            FftTables* t = tables[l->log2m];
+            const int nbs = std::max(1, std::min(nB, ceil_div(512, H)));
+            const int bchunk = ceil_div(nB, nbs);
+            const int nchunks = ceil_div(nB, bchunk);
+            DWS_TRY(fpart.ensure((size_t)nchunks * H * (M + 1) * 8));
+            DWS_TRY(g->dKf.ensure((size_t)g->Ht() * (M + 1) * 8));
+            FftCorrArgs c{};
+            c.u = l->t_u.f(); c.da = da; c.part = (c2*)fpart.p; c.tw = (const c2*)t->tw.p; c.twp = (const c2*)t->twp.p;
+            c.B = nB; c.H = H; c.L = Ls; c.bchunk = bchunk;
+            DWS_TRY(launch_fftcorr(l->log2m, c, s));
+            DWS_TRY(launch_sum_leading(fpart.f(), g->dKf.f() + (size_t)l->gidx * H * (M + 1) * 2, (size_t)H * (M + 1) * 2, nchunks, 1.f, s));
+            if (--g->pending == 0) DWS_TRY(group_backward(g, s));
+            return DWS_OK;
+        }
         const std::string k = l->prefix + ".layer.kernel.kernel";
         FftTables* t = tables[l->log2m];
         const int nbs = std::max(1, std::min(nB, ceil_div(512, H)));
@@ -1377,6 +1539,7 @@ struct SashimiModel : dws_model {
         const int nB = (int)B, nL = (int)L;
         const int nnodes = (int)plan.size() + 1;
         ln_pending.clear();
+        for (auto* g : kgroups) g->pending = (int)g->layers.size();
         std::vector<char> written(nnodes, 0);
         std::vector<float*> gp(nnodes);       // where each node's gradient lives during THIS backward (a skip node may adopt a dy buffer)
         for (int n = 0; n < nnodes; ++n) gp[n] = node_grad(n);
@@ -1451,7 +1614,7 @@ struct SashimiModel : dws_model {
                 FftConvArgs fa{};
                 fa.u = st->dh.f(); fa.g = st->du.f(); fa.D = P(p + ".layer.D"); fa.conj_k = 1; fa.no_act = 1;
                 fa.tw = (const c2*)t->tw.p; fa.twp = (const c2*)t->twp.p;
-                fa.kfa = (const c2*)l->kfa.p; fa.kfb = (const c2*)l->kfb.p; fa.kfs = (const c2*)l->kfs.p;
+                fa.kfa = (const c2*)l->kfa_v; fa.kfb = (const c2*)l->kfb_v; fa.kfs = (const c2*)l->kfs_v;
                 fa.B = nB; fa.H = H; fa.L = Ls;
                 // d fc_t(e)[b, h] = sum_l du[b, h, l] leaves with the row (a workgroup owns it) where the plan allows
                 const bool rs_fused = fftconv_rowsum_supported(l->log2m) && getenv("DWS_NO_ROWSUM_FUSION") == nullptr;
