@@ -142,7 +142,7 @@ def train_bench(args, cfg, world, rank, dev, ddist, red_dev=None, emit=True):
                        "parallelism": "dp%d, bucketed asynchronous RCCL all-reduce of the gradients" % world},
             "per_rank_ms_per_step": per_rank_ms, "process_group": ddist.group_info(),
             "per_rank_final_loss": per_rank_loss, "per_rank_param_digest": per_rank_param_digest,
-            "final_loss": float(loss), **({"dp": dp_overhead} if dp_overhead else {})})
+            "final_loss": float(loss.detach()), **({"dp": dp_overhead} if dp_overhead else {})})
     del net, opt
     torch.cuda.empty_cache()
     if not emit:
