@@ -228,3 +228,57 @@ def test_layernorm_fused_into_the_training_gemms_changes_nothing(gpu, precision)
     worst = max((float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-4 * gmax), k) for k in g0)
     print(f"worst gradient difference fused vs separate: {worst[0]:.2e} ({worst[1]})")
     assert worst[0] < 2e-4, worst
+
+
+_KGROUP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["DWS_ROOT"])
+import torch, torch.nn as nn
+from tests import cases
+from tests.test_sashimi_training_gpu import TRAIN_CASES
+from diffwave_sashimi_amd.sampling import calc_diffusion_hyperparams
+from diffwave_sashimi_amd.training import training_loss
+cfg, _ = TRAIN_CASES["d128"]
+net = cases.build_ours(cfg, 15).cuda().train()
+dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
+audio = (torch.rand(2, 1, cfg["L"], generator=torch.Generator().manual_seed(3)) * 2 - 1) * 0.3
+losses = []
+for step in range(2):      # the second step commits again on the same buffers (group bookkeeping is per commit / per backward)
+    net.zero_grad(set_to_none=True)
+    loss = training_loss(net, nn.MSELoss(), audio.cuda(), dh, generator=torch.Generator().manual_seed(5))
+    loss.backward()
+    losses.append(float(loss.detach()))
+torch.cuda.synchronize()
+torch.save({"losses": losses, "grads": {k: p.grad.detach().cpu() for k, p in net.named_parameters()}}, sys.argv[1])
+'''
+
+
+def test_stacked_kernel_generation_is_the_per_block_chain(tmp_path, gpu):
+    """Training commits generate the S4 kernels of all blocks of one shape in ONE chain over n H rows (`s4.py:704-807`; `KGroup` in
+    sashimi_model.hip) and run the chain's adjoint once per group.  Same loss and gradients as one chain per block
+    (`DWS_S4_KERNELS_PER_BLOCK=1`, read once per process: two fresh processes) up to the rounding of rocFFT's batched transforms,
+    on d128 (H = 128 / 256 / 512, two blocks per level and direction: groups of 4 / 4 / 2), over two steps."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    script = tmp_path / "kgroup_worker.py"
+    script.write_text(_KGROUP_WORKER)
+    out = {}
+    for tag, extra in (("stacked", {}), ("per_block", {"DWS_S4_KERNELS_PER_BLOCK": "1"})):
+        env = dict(os.environ, DWS_ROOT=ROOT, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.pop("DWS_S4_KERNELS_PER_BLOCK", None)
+        env.update(extra)
+        f = tmp_path / (tag + ".pt")
+        r = subprocess.run([sys.executable, str(script), str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = torch.load(f)
+    a, b = out["stacked"], out["per_block"]
+    assert a["losses"][0] == a["losses"][1] and b["losses"][0] == b["losses"][1], (a["losses"], b["losses"])   # deterministic re-commit
+    assert abs(a["losses"][0] - b["losses"][0]) <= 2e-6 * abs(b["losses"][0]), (a["losses"], b["losses"])
+    g1, g0 = a["grads"], b["grads"]
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    worst = max((float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-4 * gmax), k) for k in g0)
+    kern = max((float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-4 * gmax), k) for k in g0 if ".kernel.kernel." in k or k.endswith("layer.D"))
+    print(f"stacked vs per-block: loss {a['losses'][0]:.7f} / {b['losses'][0]:.7f}; worst gradient difference {worst[0]:.2e} ({worst[1]}), S4 parameters {kern[0]:.2e} ({kern[1]})")
+    assert worst[0] < 2e-4, worst
