@@ -35,6 +35,11 @@ class _NPLRKernelParams(nn.Module):
         self.inv_w_real = nn.Parameter(p["inv_w_real"])
         self.w_imag = nn.Parameter(p["w_imag"])
         self.register_buffer("L", torch.tensor(0))
+        # the per-parameter optimizer hints of `OptimModule.register` (`models/s4.py:508-518`, called at `:634-638` with lr=None
+        # since `sashimi.py:126` builds `S4(d_model, l_max=L, bidirectional=True)`): weight decay 0, no own learning rate.  C is a
+        # plain parameter there (`:631`).  The reference's `train.py:91` ignores them; `train.py`'s `optim_param_groups` reads them.
+        for name in ("log_dt", "B", "P", "inv_w_real", "w_imag"):
+            getattr(self, name)._optim = {"weight_decay": 0.0}
 
 
 class _S4Params(nn.Module):

@@ -134,8 +134,34 @@ def dataloader(dataset_cfg, batch_size, num_gpus, unconditional=True, rank=0, nu
                                        num_workers=num_workers, pin_memory=False, drop_last=True)
 
 
+def optim_param_groups(net, honour_hints=False):
+    """What the optimizer is built from.  Default: `net.parameters()`, i.e. ONE group -- the reference's `train.py:91` (and its
+    checkpoints' `optimizer_state_dict`, `:104-107,159`).  `honour_hints=True` (`+train.honour_optim_hints=true`): the S4 kernel
+    parameters carry `_optim = {"weight_decay": 0.0[, "lr": ...]}` (`models/s4.py:508-518`), and every distinct hint becomes its
+    own parameter group after the plain one, the way the S4 authors' own training harness consumes them.  Under the reference's
+    Adam (no weight decay) and SaShiMi's lr=None construction the update is the same; the group layout differs, so such a run's
+    optimizer state does not load into a one-group run and vice versa."""
+    params = list(net.parameters())
+    if not honour_hints:
+        return params
+    plain = [p for p in params if not getattr(p, "_optim", None)]
+    groups = [{"params": plain}]
+    keys = []
+    for p in params:
+        h = getattr(p, "_optim", None)
+        if not h:
+            continue
+        k = tuple(sorted(h.items()))
+        if k not in keys:
+            keys.append(k)
+            groups.append({"params": [], **dict(k)})
+        groups[1 + keys.index(k)]["params"].append(p)
+    return groups
+
+
 def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, ckpt_iter, n_iters, iters_per_ckpt,
-          iters_per_logging, learning_rate, batch_size_per_gpu, name=None, exp_root="exp", num_workers=4, precision=None):
+          iters_per_logging, learning_rate, batch_size_per_gpu, name=None, exp_root="exp", num_workers=4, precision=None,
+          honour_optim_hints=False):
     """``train.py:49-196``."""
     from .distributed_util import apply_gradient_allreduce, reduce_tensor
     from .models import construct_model
@@ -157,7 +183,9 @@ def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, c
     if num_gpus > 1:
         net = apply_gradient_allreduce(net)
     learning_rate = float(learning_rate)
-    optimizer = torch.optim.Adam(net.parameters(), lr=learning_rate)
+    groups = optim_param_groups(net, str(honour_optim_hints).lower() in ("1", "true"))
+    own_lr = [isinstance(g, dict) and "lr" in g for g in groups] if isinstance(groups[0], dict) else [False]
+    optimizer = torch.optim.Adam(groups, lr=learning_rate)
 
     if ckpt_iter == "max":
         ckpt_iter = find_max_epoch(checkpoint_directory)
@@ -168,7 +196,9 @@ def train(rank, num_gpus, diffusion_cfg, model_cfg, dataset_cfg, generate_cfg, c
             net.load_state_dict(checkpoint["model_state_dict"])
             if "optimizer_state_dict" in checkpoint:
                 optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
-                optimizer.param_groups[0]["lr"] = learning_rate      # `train.py:111-112`
+                for g, own in zip(optimizer.param_groups, own_lr):    # `train.py:111-112` (one group there); a hinted lr stays
+                    if not own:
+                        g["lr"] = learning_rate
             print(f"Successfully loaded model at iteration {ckpt_iter}")
         except Exception as e:   # the reference swallows the error the same way (`train.py:115-117`)
             print(f"Model checkpoint found at iteration {ckpt_iter}, but was not successfully loaded ({e}) - "

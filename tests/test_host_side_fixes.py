@@ -260,3 +260,47 @@ def test_build_staleness_follows_contents_not_mtimes(monkeypatch, tmp_path):
     monkeypatch.setattr(build, "_headers", lambda: real + [str(extra)])
     assert build.needs_build()
     assert all(build._cmd_changed("hipcc", s) for s in build.sources())
+
+
+def test_s4_optimizer_hints_and_param_groups():
+    """`OptimModule.register` (`models/s4.py:508-518`, called at `:634-638`; `sashimi.py:126` passes no lr) tags log_dt, B, P,
+    inv_w_real, w_imag with `_optim = {"weight_decay": 0.0}`; C (`:631`) and everything else carry none.  The reference's
+    `train.py:91` ignores the tags (one Adam group): that is `optim_param_groups`' default, so its optimizer state dicts load;
+    `honour_hints=True` cuts one extra group per distinct hint, and under Adam without weight decay the step is the same."""
+    from diffwave_sashimi_amd.train import optim_param_groups
+    cfg = cases.ss_cfg(d_model=16, n_layers=1, L=256, diffusion_step_embed_dim_mid=32)
+    net = cases.build_ours(cfg, 3)
+    hinted = {k for k, p in net.named_parameters() if getattr(p, "_optim", None)}
+    assert hinted and all(k.rsplit(".", 1)[1] in ("log_dt", "B", "P", "inv_w_real", "w_imag") and ".kernel.kernel." in k for k in hinted)
+    n_blocks = sum(1 for k, _ in net.named_parameters() if k.endswith(".kernel.kernel.C"))
+    assert len(hinted) == 5 * n_blocks
+    assert all(p._optim == {"weight_decay": 0.0} for k, p in net.named_parameters() if k in hinted)
+    plain = optim_param_groups(net)
+    assert [id(p) for p in plain] == [id(p) for p in net.parameters()]
+    groups = optim_param_groups(net, honour_hints=True)
+    assert len(groups) == 2 and groups[1]["weight_decay"] == 0.0 and "lr" not in groups[1]
+    ids = [id(p) for g in groups for p in g["params"]]
+    assert sorted(ids) == sorted(id(p) for p in net.parameters()) and len(set(ids)) == len(ids)
+    assert {id(p) for p in groups[1]["params"]} == {id(p) for k, p in net.named_parameters() if k in hinted}
+    # one Adam step either way from the same gradients
+    gen = torch.Generator().manual_seed(0)
+    grads = [torch.randn(p.shape, generator=gen) for p in net.parameters()]
+    start = [p.detach().clone() for p in net.parameters()]
+    results = []
+    for honour in (False, True):
+        with torch.no_grad():
+            for p, s in zip(net.parameters(), start):
+                p.copy_(s)
+        opt = torch.optim.Adam(optim_param_groups(net, honour), lr=2e-4)
+        for p, g in zip(net.parameters(), grads):
+            p.grad = g.clone()
+        opt.step()
+        results.append([p.detach().clone() for p in net.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*results))
+    # a hint with its own learning rate becomes its own group and keeps that rate
+    first = next(p for k, p in net.named_parameters() if k in hinted)
+    first._optim = {"weight_decay": 0.0, "lr": 1e-3}
+    groups = optim_param_groups(net, honour_hints=True)
+    assert len(groups) == 3 and sum(1 for g in groups if g.get("lr") == 1e-3 and len(g["params"]) == 1) == 1
+    opt = torch.optim.Adam(groups, lr=2e-4)
+    assert sorted(g["lr"] for g in opt.param_groups) == [2e-4, 2e-4, 1e-3]
