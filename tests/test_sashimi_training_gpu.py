@@ -242,14 +242,27 @@ cfg, _ = TRAIN_CASES["d128"]
 net = cases.build_ours(cfg, 15).cuda().train()
 dh = calc_diffusion_hyperparams(50, 1e-4, 0.05)
 audio = (torch.rand(2, 1, cfg["L"], generator=torch.Generator().manual_seed(3)) * 2 - 1) * 0.3
+import ctypes
+from diffwave_sashimi_amd import _lib
+lib = _lib.load()
 losses = []
-for step in range(2):      # the second step commits again on the same buffers (group bookkeeping is per commit / per backward)
+for step in range(3):      # later steps commit again on the same buffers (group bookkeeping is per commit / per backward)
     net.zero_grad(set_to_none=True)
+    if step == 2:          # which chain ran: Cauchy launches (forward at the commit, adjoint in the backward) of the last step
+        _lib.check(lib.dws_profile_enable(b"cauchy_sym"))
     loss = training_loss(net, nn.MSELoss(), audio.cuda(), dh, generator=torch.Generator().manual_seed(5))
     loss.backward()
     losses.append(float(loss.detach()))
+    if step < 2:
+        with torch.no_grad():      # what an optimizer step does to the engine: new tensor versions -> upload + commit (same values)
+            for p in net.parameters():
+                p.mul_(1.0)
 torch.cuda.synchronize()
-torch.save({"losses": losses, "grads": {k: p.grad.detach().cpu() for k, p in net.named_parameters()}}, sys.argv[1])
+n, ms = ctypes.c_int64(), ctypes.c_double()
+_lib.check(lib.dws_profile_query(ctypes.byref(n), ctypes.byref(ms)))
+lib.dws_profile_disable()
+torch.save({"losses": losses, "cauchy_launches": n.value,
+            "grads": {k: p.grad.detach().cpu() for k, p in net.named_parameters()}}, sys.argv[1])
 '''
 
 
@@ -257,7 +270,7 @@ def test_stacked_kernel_generation_is_the_per_block_chain(tmp_path, gpu):
     """Training commits generate the S4 kernels of all blocks of one shape in ONE chain over n H rows (`s4.py:704-807`; `KGroup` in
     sashimi_model.hip) and run the chain's adjoint once per group.  Same loss and gradients as one chain per block
     (`DWS_S4_KERNELS_PER_BLOCK=1`, read once per process: two fresh processes) up to the rounding of rocFFT's batched transforms,
-    on d128 (H = 128 / 256 / 512, two blocks per level and direction: groups of 4 / 4 / 2), over two steps."""
+    on d128 (H = 128 / 256 / 512, two blocks per level and direction: groups of 4 / 4 / 2), over three steps."""
     import os
     import subprocess
     import sys
@@ -274,7 +287,12 @@ def test_stacked_kernel_generation_is_the_per_block_chain(tmp_path, gpu):
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = torch.load(f)
     a, b = out["stacked"], out["per_block"]
-    assert a["losses"][0] == a["losses"][1] and b["losses"][0] == b["losses"][1], (a["losses"], b["losses"])   # deterministic re-commit
+    # the switch took: one Cauchy launch per block and direction against one per group (the first training commit of a model is
+    # always per block -- the Cauchy products are kept from the first forward_train on -- hence the count on a later step)
+    print(f"Cauchy launches of one step: stacked {a['cauchy_launches']}, per block {b['cauchy_launches']}")
+    assert 0 < a["cauchy_launches"] < b["cauchy_launches"], (a["cauchy_launches"], b["cauchy_launches"])
+    assert len(set(b["losses"])) == 1, b["losses"]                                     # deterministic re-commit
+    assert all(abs(x - a["losses"][0]) <= 2e-6 * abs(a["losses"][0]) for x in a["losses"]), a["losses"]   # per block, then stacked twice
     assert abs(a["losses"][0] - b["losses"][0]) <= 2e-6 * abs(b["losses"][0]), (a["losses"], b["losses"])
     g1, g0 = a["grads"], b["grads"]
     gmax = max(float(v.abs().max()) for v in g0.values())
