@@ -165,7 +165,7 @@ def test_config5_training_step_at_full_size(gpu):
         loss = nn.MSELoss()(net((x_t[sl], steps[sl].view(-1, 1))), z[sl])
         loss.backward()
         torch.cuda.synchronize()
-        return float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
 
     l_full, g_full = grads(slice(0, B))
     l_again, g_again = grads(slice(0, B))
