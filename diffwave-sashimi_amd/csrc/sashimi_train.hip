@@ -2,6 +2,7 @@
 // (`models/sashimi.py:17-20,36-58,143-184`, `models/s4.py:704-807,1391-1437`).
 // The GEMMs run on tapconv_mfma / wgrad_mfma (wavenet_backward_mfma.hip), the FFT
 // convolution adjoints on fftconv_kernels.hip.
+#include <cstdint>
 #include <cstdlib>
 
 #include "sashimi_train.h"
@@ -372,9 +373,51 @@ __global__ void pool_rearrange_kernel(const float* __restrict__ in, float* __res
     }
 }
 
+// The same maps with a thread owning the P phases of one pooled position: the long side is one 4P-byte access per lane (a wave
+// covers 64 P consecutive floats), the wide side P dwords per lane that are consecutive across the lanes of a row -- both sides
+// in full cache lines.  (The per-element kernel above touches the wide side in 64-byte runs: a wave's 64 long positions are 16
+// pooled positions of 4 rows.)
+template <int P>
+__global__ __launch_bounds__(256) void pool_rearrange_vec_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 const float* __restrict__ addend, int dir, int accumulate,
+                                                                 int Lp, size_t npool) {
+    typedef float vecP __attribute__((ext_vector_type(P)));
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (b h, lp)
+    if (t >= npool) return;
+    const size_t bh = t / Lp;
+    const int lp = (int)(t % Lp);
+    const size_t i = t * P;                         // long index of phase 0: bh * (Lp P) + lp P
+    const size_t w = bh * P * Lp + lp;              // wide index of phase 0; phase s is s * Lp further on
+    if (dir == 0) {
+        const vecP v = *reinterpret_cast<const vecP*>(in + i);
+#pragma unroll
+        for (int q = 0; q < P; ++q) out[w + (size_t)q * Lp] = v[q];
+    } else {
+        vecP v;
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = in[w + (size_t)q * Lp];
+        if (addend) v += *reinterpret_cast<const vecP*>(addend + i);
+        if (accumulate) v += *reinterpret_cast<const vecP*>(out + i);
+        *reinterpret_cast<vecP*>(out + i) = v;
+    }
+}
+
 int launch_pool_rearrange(const float* in, float* out, const float* addend, int dir, int accumulate, int B, int H,
                           int p, int Lp, hipStream_t s) {
     const size_t n = (size_t)B * H * p * Lp;
+    static const bool per_element = getenv("DWS_POOL_REARRANGE_OLD") != nullptr;      // same-box A/B
+    // the long-side tensors are accessed as P-float vectors: rows start at multiples of Lp P floats, so the base pointers decide
+    const uintptr_t long_side = (uintptr_t)(dir == 0 ? (const void*)in : (const void*)out) | (uintptr_t)addend;
+    if (!per_element && (p == 2 || p == 4) && long_side % (4 * p) == 0) {
+        const size_t npool = n / p;
+        if (p == 4)
+            hipLaunchKernelGGL(pool_rearrange_vec_kernel<4>, dim3(ceil_div(npool, 256)), dim3(256), 0, s, in, out, addend, dir,
+                               accumulate, Lp, npool);
+        else
+            hipLaunchKernelGGL(pool_rearrange_vec_kernel<2>, dim3(ceil_div(npool, 256)), dim3(256), 0, s, in, out, addend, dir,
+                               accumulate, Lp, npool);
+        return DWS_OK;
+    }
     hipLaunchKernelGGL(pool_rearrange_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, addend, dir, accumulate,
                        H, p, Lp, n);
     return DWS_OK;
