@@ -143,7 +143,7 @@ def test_dp_matches_single_process_full_batch(tmp_path, world, PB):
         x, t, z = torch.cat(xs), torch.cat(ts), torch.cat(zs)
         opt.zero_grad()
         loss = nn.MSELoss()(net((x, t.view(PB * world, 1))), z)
-        assert abs(float(loss) - outs[0]["losses"][step]) < 1e-6
+        assert abs(float(loss.detach()) - outs[0]["losses"][step]) < 1e-6
         loss.backward()
         opt.step()
     for a, p in zip(outs[0]["params"], net.parameters()):
